@@ -1,0 +1,335 @@
+"""CPU ORACLE — test infrastructure, NOT product code.
+
+A plain-torch (fp32 or fp64, CPU) restatement of the reference's
+``TimesformerMultiTaskingModelSigLIP`` forward (``/root/reference/models/
+modeling_timesformer_siglip.py:1299-1354``), its KV-cached streaming variant
+(``/root/reference/downstream/VideoQA/llava/model/multimodal_encoder/timesformer_encoder.py``,
+"vqa_enc" below) and the two loss heads BASELINE.json config #3 names.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the
+product package ``streamformer_amd`` never does (and fails loudly without its HIP library).
+
+How it is pinned: the reference has no tests or golden vectors for this path, so
+``oracle/make_golden.py`` imports the reference in the build container, loads the SAME seeded
+state_dict into both, asserts this restatement equals the reference (fp32, <=2e-5 max-abs;
+fp64 restatement vs fp32 reference agrees to fp32 round-off) and writes the reference's outputs to
+``tests/golden/*.npz``.  ``tests/test_oracle_golden.py`` re-checks the restatement against those
+files on every run, so the oracle that travels to the GPU box is the one the reference vouched for.
+
+The arithmetic is torch ATen CPU (addmm/bmm/softmax/erf-gelu/layer_norm) exactly like the
+reference's (torch pin 2.5.1 there, 2.10.0 here); what is restated is the op *sequence* and data
+layout.  The layout is deliberately different from the reference's: the residual stream is kept
+frame-major ``[B, T, N, D]`` (the reference keeps patch-major ``(B, N*T, D)``, modeling:452-457),
+which is how the HIP path stores it; ``hidden_states`` are permuted back on request.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------
+# small pieces
+# --------------------------------------------------------------------------------------------
+def _lin(x: Tensor, sd: Dict[str, Tensor], name: str) -> Tensor:
+    b = sd.get(name + ".bias")
+    return F.linear(x, sd[name + ".weight"], b)
+
+
+def _ln(x: Tensor, sd: Dict[str, Tensor], name: str, eps: float) -> Tensor:
+    # nn.LayerNorm(D, eps=layer_norm_eps): modeling:860-865, 878-880, 1251, 1138
+    return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
+
+
+def _act(cfg, x: Tensor) -> Tensor:
+    # ACT2FN[config.hidden_act] (modeling:814-817).  "gelu" is the exact erf form.
+    a = cfg.hidden_act
+    if a == "gelu":
+        return F.gelu(x)
+    if a in ("gelu_new", "gelu_pytorch_tanh"):
+        return F.gelu(x, approximate="tanh")
+    if a == "relu":
+        return F.relu(x)
+    if a == "selu":
+        return F.selu(x)
+    raise ValueError(f"unsupported hidden_act {a!r}")
+
+
+def _lora_lin(x: Tensor, sd: Dict[str, Tensor], name: str, lora_name: str) -> Tensor:
+    """``dense(x) + lora_b(lora_a(x))`` with no scaling factor: modeling:536-551, 649-664, 748-754."""
+    y = _lin(x, sd, name)
+    a = sd.get(lora_name + "_lora_a.weight")
+    if a is not None:
+        y = y + F.linear(F.linear(x, a), sd[lora_name + "_lora_b.weight"])
+    return y
+
+
+def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, mask: Optional[Tensor]) -> Tensor:
+    """softmax((q k^T) * d^-0.5 [+ mask]) v per head.  q:[G,Lq,D] k,v:[G,Lk,D] -> [G,Lq,D].
+
+    Follows modeling:577-609 / 690-711: scores are scaled AFTER the matmul, masked positions are
+    filled with -inf (modeling:599-601) before the softmax.
+    """
+    G, Lq, D = q.shape
+    Lk = k.shape[1]
+    d = D // heads
+    qh = q.reshape(G, Lq, heads, d).transpose(1, 2)
+    kh = k.reshape(G, Lk, heads, d).transpose(1, 2)
+    vh = v.reshape(G, Lk, heads, d).transpose(1, 2)
+    s = (qh @ kh.transpose(-2, -1)) * (d ** -0.5)
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    p = s.softmax(dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(G, Lq, D), p
+
+
+# --------------------------------------------------------------------------------------------
+# embeddings  (modeling:336-350, 380-457;  vqa_enc:307-375 for the streaming offset)
+# --------------------------------------------------------------------------------------------
+def time_embedding_rows(sd, cfg, t_past: int, t_new: int, streaming: bool) -> Tensor:
+    """Rows of the time-embedding table used for frames ``t_past .. t_past+t_new-1`` -> [t_new, D].
+
+    Full clip (modeling:435-450): slice when T < num_frames, ``interpolate(mode="nearest")`` when
+    T > num_frames (index map floor(t * num_frames / T)).  Streaming (vqa_enc:328-369): direct
+    rows while ``t_past+t_new <= num_frames``; the reference raises past that, so
+    does this restatement.
+    """
+    te = sd["embeddings.time_embeddings"][0]  # [num_frames, D]
+    nf = te.shape[0]
+    total = t_past + t_new
+    if streaming:
+        if total > nf:
+            raise ValueError(
+                f"streaming past config.num_frames={nf} time-embedding rows (needed {total}); the "
+                "reference raises here too (vqa_enc:343-348)")
+        return te[t_past:total]
+    assert t_past == 0
+    if t_new <= nf:
+        return te[:t_new]
+    idx = torch.floor(torch.arange(t_new, dtype=torch.float64) * (nf / t_new)).long().clamp_(max=nf - 1)
+    return te[idx]
+
+
+def position_embedding(sd, cfg, H: int, W: int) -> Tensor:
+    """[N', D] position table for an H x W input (modeling:380-411)."""
+    pe = sd["embeddings.position_embeddings"]  # [1, N, D]
+    N, D = pe.shape[1], pe.shape[2]
+    P = cfg.patch_size
+    npatch = (H // P) * (W // P)
+    if npatch == N and W == H:
+        return pe[0]
+    M = int(math.sqrt(N))
+    assert N == M * M
+    w0, h0 = W // P, H // P
+    grid = pe.float().reshape(1, M, M, D).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=(w0, h0), mode="bicubic", antialias=True)
+    return grid.permute(0, 2, 3, 1).reshape(-1, D).to(pe.dtype)
+
+
+def patchify(pixels: Tensor, P: int) -> Tensor:
+    """[B,T,C,H,W] -> [B,T,N,C*P*P] with columns in (c, ph, pw) order and n = row*(W/P)+col.
+
+    Conv2d(k=P, s=P) (modeling:329-334, 344-348) is exactly this matrix times
+    ``weight.reshape(D, C*P*P)^T``.
+    """
+    B, T, C, H, W = pixels.shape
+    gh, gw = H // P, W // P
+    x = pixels[..., : gh * P, : gw * P].reshape(B, T, C, gh, P, gw, P)
+    return x.permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, gh * gw, C * P * P)
+
+
+def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False) -> Tensor:
+    B, T, C, H, W = pixels.shape
+    w = sd["embeddings.patch_embeddings.projection.weight"]
+    x = patchify(pixels, cfg.patch_size) @ w.reshape(w.shape[0], -1).t()
+    x = x + sd["embeddings.patch_embeddings.projection.bias"]
+    x = x + position_embedding(sd, cfg, H, W)[None, None]          # broadcast over B, T
+    if cfg.attention_type != "space_only":
+        x = x + time_embedding_rows(sd, cfg, t_past, T, streaming)[None, :, None, :]
+    return x  # [B, T, N, D]
+
+
+# --------------------------------------------------------------------------------------------
+# one encoder layer (modeling:900-1004), frame-major
+# --------------------------------------------------------------------------------------------
+def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = None,
+                  collect: Optional[dict] = None) -> Tensor:
+    """h: [B, T, N, D].  ``kv`` (streaming): dict with 'k','v' tensors [B, T_past, N, D] or empty."""
+    B, T, N, D = h.shape
+    heads = cfg.num_attention_heads
+    eps = cfg.layer_norm_eps
+    p = f"encoder.layer.{i}."
+
+    if cfg.attention_type != "divided_space_time":
+        # StreamFormer only ever instantiates the divided branch (modeling:934-1004); the other two
+        # TimeSformer modes (modeling:914-933) are outside the hot path and not restated.
+        raise NotImplementedError(cfg.attention_type)
+
+    # ---- temporal attention over T for each (b, n): modeling:937-958 ------------------------
+    xt = _ln(h, sd, p + "temporal_layernorm", eps)                  # [B,T,N,D]
+    qkv = _lin(xt, sd, p + "temporal_attention.attention.qkv")
+    q, k, v = qkv.split(D, dim=-1)
+    t_past = 0
+    if kv is not None:
+        if "k" in kv:                                                # vqa_enc:517-518 cache.update
+            t_past = kv["k"].shape[1]
+            k = torch.cat([kv["k"], k], dim=1)
+            v = torch.cat([kv["v"], v], dim=1)
+        kv["k"], kv["v"] = k, v
+    Tk = k.shape[1]
+    to_bn = lambda z: z.permute(0, 2, 1, 3).reshape(B * N, z.shape[1], D)
+    mask = None
+    if cfg.enable_causal_temporal:                                   # modeling:594-601; vqa_enc:533-537
+        qi = torch.arange(T)[:, None] + t_past
+        mask = torch.arange(Tk)[None, :] <= qi                      # [T, Tk] True = keep
+    ctx, _ = _mha(to_bn(q), to_bn(k), to_bn(v), heads, mask)
+    ctx = ctx.reshape(B, N, T, D).permute(0, 2, 1, 3)
+    res_t = _lin(_lin(ctx, sd, p + "temporal_attention.output.dense"), sd, p + "temporal_dense")
+    h1 = h + torch.tanh(sd[p + "temporal_attention_gating"]) * res_t   # modeling:955-958
+
+    # ---- spatial attention over N for each (b, t): modeling:962-996 --------------------------
+    xs = _ln(h1, sd, p + "layernorm_before", eps).reshape(B * T, N, D)
+    qkv = _lora_lin(xs, sd, p + "attention.attention.qkv", p + "attention.attention.qkv")
+    q, k, v = qkv.split(D, dim=-1)
+    ctx, probs = _mha(q, k, v, heads, None)
+    xs = _lora_lin(ctx, sd, p + "attention.output.dense", p + "attention.output.dense")
+    h2 = h1 + xs.reshape(B, T, N, D)                                 # residual onto h1 (modeling:993-996)
+
+    # ---- MLP: modeling:997-1000, 819-837 ---------------------------------------------------------
+    y = _lin(_act(cfg, _lin(_ln(h2, sd, p + "layernorm_after", eps), sd, p + "intermediate.dense")),
+             sd, p + "output.dense")
+    out = h2 + y
+    if collect is not None:
+        collect.setdefault("h1", []).append(h1)
+        collect.setdefault("h2", []).append(h2)
+        collect.setdefault("attentions", []).append(probs)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# pooling head (modeling:1141-1154; nn.MultiheadAttention with packed in_proj [q;k;v])
+# --------------------------------------------------------------------------------------------
+def pooling_head(sd, cfg, x: Tensor) -> Tensor:
+    """x: [G, N, D] (post-LN tokens of G frames) -> [G, D]."""
+    G, N, D = x.shape
+    heads = cfg.num_attention_heads
+    w, b = sd["head.attention.in_proj_weight"], sd["head.attention.in_proj_bias"]
+    probe = sd["head.probe"].reshape(1, 1, D).expand(G, 1, D)
+    q = F.linear(probe, w[:D], b[:D])
+    k = F.linear(x, w[D:2 * D], b[D:2 * D])
+    v = F.linear(x, w[2 * D:], b[2 * D:])
+    ctx, _ = _mha(q, k, v, heads, None)
+    a = _lin(ctx, sd, "head.attention.out_proj")                      # [G,1,D]
+    y = _ln(a, sd, "head.layernorm", cfg.layer_norm_eps)
+    y = _lin(_act(cfg, _lin(y, sd, "head.mlp.fc1")), sd, "head.mlp.fc2")
+    return (a + y)[:, 0]
+
+
+# --------------------------------------------------------------------------------------------
+# whole forward
+# --------------------------------------------------------------------------------------------
+def cast_state_dict(sd: Dict[str, Tensor], dtype: torch.dtype) -> Dict[str, Tensor]:
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def to_patch_major(h: Tensor) -> Tensor:
+    """[B,T,N,D] -> the reference's (B, N*T, D) token order (token = n*T + t, modeling:452-457)."""
+    B, T, N, D = h.shape
+    return h.permute(0, 2, 1, 3).reshape(B, N * T, D)
+
+
+@torch.no_grad()
+def forward(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
+            collect: Optional[dict] = None, cache: Optional[List[dict]] = None) -> Dict[str, Tensor]:
+    """Full-clip forward (``cache is None``) or one streaming call (``cache`` = list of per-layer dicts).
+
+    Returns ``last_hidden_state [B,T,N,D]``, ``pooler_output [B,T,D]`` and, on request,
+    ``hidden_states``: L+1 tensors in the reference's patch-major ``(B, N*T, D)`` order
+    (modeling:1031-1051, 1352).
+    """
+    pixels = pixels.to(next(iter(sd.values())).dtype)
+    streaming = cache is not None
+    t_past = 0
+    if streaming and cache and "k" in cache[0]:
+        t_past = cache[0]["k"].shape[1]
+    h = embeddings(sd, cfg, pixels, t_past=t_past, streaming=streaming)
+    if collect is not None:
+        collect["embeddings"] = h
+    hs = []
+    for i in range(cfg.num_hidden_layers):
+        if output_hidden_states:
+            hs.append(to_patch_major(h))
+        h = layer_forward(sd, cfg, i, h, kv=(cache[i] if streaming else None), collect=collect)
+        if collect is not None:
+            collect.setdefault("layer_out", []).append(h)
+    if output_hidden_states:
+        hs.append(to_patch_major(h))
+    B, T, N, D = h.shape
+    seq = _ln(h, sd, "post_layernorm", cfg.layer_norm_eps)            # modeling:1330
+    pooled = pooling_head(sd, cfg, seq.reshape(B * T, N, D)).reshape(B, T, D)
+    out = {"last_hidden_state": seq, "pooler_output": pooled}
+    if output_hidden_states:
+        out["hidden_states"] = hs
+    return out
+
+
+def new_cache(cfg) -> List[dict]:
+    return [dict() for _ in range(cfg.num_hidden_layers)]
+
+
+def merge_lora(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """W += B @ A for every LoRA pair; returns a dict without the lora keys (inference-time fold)."""
+    out = {k: v for k, v in sd.items() if "_lora_" not in k}
+    for k in sd:
+        if k.endswith("_lora_a.weight"):
+            base = k[: -len("_lora_a.weight")]
+            out[base + ".weight"] = out[base + ".weight"] + sd[base + "_lora_b.weight"] @ sd[k]
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# loss heads of BASELINE config #3 (modeling:221-237, 2238-2282, 2324-2351)
+# --------------------------------------------------------------------------------------------
+def siglip_loss(img: Tensor, txt: Tensor, logit_scale_exp: Tensor, logit_bias: Tensor,
+                negative_only: bool = False) -> Tensor:
+    """SigLipLoss._loss (modeling:221-237): -sum(logsigmoid(labels * logits)) / B, labels = 2I-1."""
+    logits = logit_scale_exp * img @ txt.t() + logit_bias
+    n = img.shape[0]
+    labels = -torch.ones(n, txt.shape[0], dtype=img.dtype)
+    if not negative_only:
+        labels = labels + 2 * torch.eye(n, dtype=img.dtype)
+    return -F.logsigmoid(labels * logits).sum() / n
+
+
+def retrieval_loss(pooler: Tensor, text_features: Tensor, logit_scale: Tensor, logit_bias: Tensor,
+                   other_rank_text: Optional[List[Tensor]] = None) -> Tensor:
+    """TimesformerVideoRetrievalHead.forward (modeling:2324-2351), world_size 1 unless
+    ``other_rank_text`` lists the other ranks' text features (negatives only, modeling:250-280)."""
+    img = pooler[:, -1, :]
+    img = img / img.norm(p=2, dim=-1, keepdim=True)
+    txt = text_features / text_features.norm(p=2, dim=-1, keepdim=True)
+    loss = siglip_loss(img, txt, logit_scale.exp(), logit_bias)
+    for t in other_rank_text or []:
+        t = t / t.norm(p=2, dim=-1, keepdim=True)
+        loss = loss + siglip_loss(img, t, logit_scale.exp(), logit_bias, negative_only=True)
+    return loss
+
+
+def localization_loss(pooler: Tensor, label_emb: Tensor, labels: Tensor, logit_scale: Tensor,
+                      logit_bias: Tensor) -> Tensor:
+    """TimesformerUniversalLocalizationHead.forward, training branch (modeling:2238-2282), with one
+    label-embedding table [L, D] shared by the batch (the synthetic config uses one dataset)."""
+    B, T, D = pooler.shape
+    img = pooler / pooler.norm(p=2, dim=-1, keepdim=True)
+    total = pooler.new_zeros(())
+    for i in range(B):
+        logits = (img[i] @ label_emb.t()) * logit_scale.exp() + logit_bias      # [T, L]
+        target = -torch.ones_like(logits)
+        fg = labels[i] >= 0
+        target[torch.arange(T)[fg], labels[i][fg]] = 1
+        total = total + (-F.logsigmoid(target * logits).sum() / T)
+    return total / B
