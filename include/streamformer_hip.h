@@ -1,0 +1,160 @@
+/*
+ * streamformer_hip.h — C ABI of the MI355X (gfx950) StreamFormer encoder hot path.
+ *
+ * The reference has no FFI seam: the path is a torch.nn.Module,
+ * TimesformerMultiTaskingModelSigLIP (reference models/modeling_timesformer_siglip.py:1241-1354).
+ * This header is the boundary a binding would use instead of that module's forward; the Python
+ * mirror of the module (streamformer_amd/modeling.py) binds it with ctypes, INTEGRATION.md shows
+ * the stub.  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on
+ *     success or a negative sf_status; sf_last_error() gives the message of the last failure on the
+ *     calling thread.
+ *   - All device buffers passed in (pixels, outputs, workspace) are CALLER-allocated and
+ *     caller-owned; the library never frees them and never synchronises the stream.  Weights and
+ *     KV-caches are library-owned device memory.
+ *   - All work is enqueued on the caller's hipStream_t (pass torch.cuda.current_stream()).
+ *   - A handle is bound to one device and may be used from one thread at a time.
+ *   - Layout: activations are FRAME-major [B, T, N, D] row-major (token row = (b*T + t)*N + n),
+ *     not the reference's patch-major (B, N*T, D) (modeling:452-457).
+ */
+#ifndef STREAMFORMER_HIP_H
+#define STREAMFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sf_encoder sf_encoder;   /* opaque: config + packed weights on one device        */
+typedef struct sf_cache sf_cache;       /* opaque: temporal K/V cache of one stream (all layers) */
+typedef void* sf_stream;                /* hipStream_t                                          */
+
+typedef enum {
+  SF_OK = 0,
+  SF_ERR_INVALID = -1,      /* bad argument / unsupported configuration                      */
+  SF_ERR_STATE = -2,        /* call order (e.g. forward before finalize, missing weight)     */
+  SF_ERR_HIP = -3,          /* HIP runtime error (message carries hipGetErrorString)         */
+  SF_ERR_WORKSPACE = -4,    /* workspace too small                                           */
+  SF_ERR_UNKNOWN_KEY = -5,  /* sf_load_tensor: not a weight of this model (ignored keys OK)  */
+  SF_ERR_CAPACITY = -6      /* streaming past the cache / time-embedding capacity            */
+} sf_status;
+
+typedef enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_F64 = 3 } sf_dtype;
+
+/* Arithmetic mode of the matrix products (reported as "dtype" by bench.py):
+ *   SF_COMPUTE_BF16   : bf16 operands, fp32 accumulate, one MFMA pass            (throughput)
+ *   SF_COMPUTE_BF16X3 : x = xh+xl, w = wh+wl, xh*wh + xh*wl + xl*wh, fp32 acc   (fp32-accurate)
+ * Residual stream, LayerNorm statistics, softmax and GELU are fp32 in both.                   */
+typedef enum { SF_COMPUTE_BF16 = 0, SF_COMPUTE_BF16X3 = 1 } sf_compute;
+
+/* Plain-old-data mirror of StreamformerConfig (reference models/configuration_streamformer.py:90-135). */
+typedef struct {
+  int32_t image_size, patch_size, num_channels, num_frames;
+  int32_t hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+  int32_t hidden_act;              /* 0 = "gelu" (exact erf); 1 = "gelu_new"/tanh; 2 = "relu" */
+  int32_t qkv_bias;                /* bool */
+  int32_t enable_causal_temporal;  /* bool: causal (modeling:887) vs bidirectional (:894)     */
+  int32_t add_lora_spatial;        /* bool: expect *_lora_{a,b}.weight (rank 32, modeling:1280) */
+  float layer_norm_eps;
+} sf_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* replaces TimesformerMultiTaskingModelSigLIP.__init__ (modeling:1244-1258) */
+int sf_create(const sf_config* cfg, int device, sf_encoder** out);
+void sf_destroy(sf_encoder* enc);
+const char* sf_last_error(void);
+int sf_abi_version(void);
+
+/* ---- weights: replaces from_pretrained()/load_state_dict() (modeling:1066-1075) -------------
+ * `key` is the reference state_dict key, without any "timesformer." prefix.
+ * The host buffer is borrowed only for the duration of the call.  Keys that are not weights of
+ * this model return SF_ERR_UNKNOWN_KEY (callers may ignore it for buffers such as "...mask").   */
+int sf_load_tensor(sf_encoder* enc, const char* key, const void* host_ptr, int dtype,
+                   const int64_t* shape, int ndim);
+/* Packs weights for the kernels and uploads them.  merge_lora: fold W += B*A (inference).
+ * fuse_temporal_proj: fold temporal_dense o temporal_attention.output.dense into one matrix
+ * (modeling:947-954 are two Linear layers with nothing in between).                            */
+int sf_finalize_weights(sf_encoder* enc, int compute, int merge_lora, int fuse_temporal_proj);
+/* number of weight tensors still missing (0 when complete); names via sf_last_error()          */
+int sf_missing_weights(sf_encoder* enc);
+
+/* ---- full-clip forward: replaces .forward(pixel_values) (modeling:1299-1354) -----------------
+ * pixels_dev         [B,T,C,H,W] contiguous, dtype pixel_dtype (SF_F32 or SF_BF16)
+ * last_hidden_dev    fp32 [B,T,N,D]   (post-LayerNorm tokens, modeling:1330,1342-1346)
+ * pooler_dev         fp32 [B,T,D]     (modeling:1338-1340)
+ * hidden_states_dev  NULL, or fp32 [L+1,B,T,N,D]: the input of every layer + the last output
+ *                    (modeling:1031-1051), FRAME-major (the Python mirror permutes views)
+ * pos_dev            NULL to use the loaded position table (needs H==W==image_size), else an
+ *                    fp32 [N',D] table already resized on the host (modeling:380-411)
+ */
+int sf_workspace_bytes(sf_encoder* enc, int B, int T, int H, int W, size_t* out);
+int sf_forward(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, int T, int H, int W,
+               float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
+               const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+
+/* ---- streaming forward with a temporal KV-cache ----------------------------------------------
+ * replaces forward(..., past_key_values, use_cache=True) of the VideoQA copy
+ * (reference downstream/VideoQA/llava/model/multimodal_encoder/timesformer_encoder.py:1316-1392;
+ * cache update :517-518, offset causal mask :522-546, time-embedding offset :328-369).
+ * The cache holds, per layer, the temporal K/V rows of every frame seen so far.                 */
+int sf_cache_create(sf_encoder* enc, int B, int max_frames, int H, int W, sf_cache** out);
+int sf_cache_reset(sf_cache* cache);            /* TimesformerVisionTower.clear_cache (:1528) */
+int sf_cache_length(const sf_cache* cache);     /* DynamicCache.get_seq_length()              */
+size_t sf_cache_bytes(const sf_cache* cache);
+void sf_cache_destroy(sf_cache* cache);
+int sf_stream_workspace_bytes(sf_encoder* enc, const sf_cache* cache, int T_new, size_t* out);
+int sf_forward_stream(sf_encoder* enc, sf_cache* cache, const void* pixels_dev, int pixel_dtype,
+                      int T_new, float* last_hidden_dev, float* pooler_dev, const float* pos_dev,
+                      void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+
+/* ---- single operators (each is one kernel of the path; used by the parity tests) ----------- */
+/* nn.LayerNorm(D, eps) rows (modeling:860-865,878-880,1251): x fp32 [rows,D] -> y fp32 [rows,D] */
+int sf_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                    int rows, int D, float eps, sf_stream stream);
+/* nn.Linear (+ optional exact-erf GELU, + optional residual): y = act(x W^T + b) [+ alpha*() + r]
+ * x fp32 [M,K], w fp32 [N,K], b fp32 [N] or NULL, resid fp32 [M,N] or NULL, y fp32 [M,N].
+ * Operands are rounded/split on device exactly as the encoder does for `compute`.               */
+int sf_op_linear(const float* x_dev, const float* w_dev, const float* b_dev, const float* resid_dev,
+                 float alpha, int gelu, float* y_dev, int M, int N, int K, int compute,
+                 void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+size_t sf_op_linear_workspace_bytes(int M, int N, int K);
+/* softmax(q k^T / sqrt(d)) v per head over `groups` independent sequences
+ * (modeling:688-717 spatial; :575-615 temporal with causal=1 and past offset).
+ * qkv fp32 [groups, Lq|Lk, 3*D] packed as the qkv Linear emits it; ctx fp32 [groups, Lq, D].
+ * Spatial: seq stride = rows are contiguous tokens.  Temporal goes through the same entry with
+ * `row_stride` (in rows) between consecutive sequence positions.                                */
+int sf_op_attention(const float* qkv_dev, float* ctx_dev, int groups, int L, int heads, int head_dim,
+                    int causal, int temporal_layout, int N_tokens, int compute,
+                    void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+size_t sf_op_attention_workspace_bytes(int groups, int L, int heads, int head_dim);
+
+/* ---- loss heads of the multitask pre-training step (BASELINE config #3) ---------------------
+ * retrieval: TimesformerVideoRetrievalHead.forward + SigLipLoss._loss (modeling:2324-2351,221-237)
+ * localization: TimesformerUniversalLocalizationHead.forward (modeling:2238-2282)
+ * pooler fp32 [B,T,D]; text fp32 [Bt,D] (un-normalised); label_emb fp32 [L,D]; labels int32 [B,T]
+ * (-1 = background).  pos_offset: column of `text` that is row 0's positive (rank*B when `text` is
+ * the all-gathered [world*B, D] table, modeling:250-280; -1 = negatives only).
+ * Outputs: loss_dev fp32 [1]; grad_pooler_dev fp32 [B,T,D] or NULL;
+ * grad_scalars_dev fp32 [2] = d loss / d (logit_scale, logit_bias) or NULL.                     */
+int sf_retrieval_loss(const float* pooler_dev, const float* text_dev, int B, int T, int D, int Bt,
+                      int pos_offset, float logit_scale, float logit_bias, float* loss_dev,
+                      float* grad_pooler_dev, float* grad_scalars_dev, sf_stream stream);
+int sf_localization_loss(const float* pooler_dev, const float* label_emb_dev, const int32_t* labels_dev,
+                         int B, int T, int D, int L, float logit_scale, float logit_bias,
+                         float* loss_dev, float* grad_pooler_dev, float* grad_scalars_dev,
+                         sf_stream stream);
+
+/* ---- introspection for bench/roofline ------------------------------------------------------- */
+/* Enqueue `iters` back-to-back launches of the dominant GEMM (the MLP up-projection shape of the
+ * loaded model at M rows) between two HIP events on `stream` and return the mean launch time.   */
+int sf_bench_gemm(sf_encoder* enc, int M, int which, int iters, void* workspace_dev,
+                  size_t workspace_bytes, sf_stream stream, float* mean_ms_out, double* flops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STREAMFORMER_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of ``libstreamformer_hip.so`` (the C ABI in ``include/streamformer_hip.h``).
+
+There is no fallback: if the shared library is missing or does not load, importing this module
+raises, and so does every product path that needs it.  ``torch`` is imported first on purpose — the
+library is linked against ``libamdhip64.so.7`` by SONAME only, so it binds to the HIP runtime torch
+has already loaded and shares its device context, allocator pointers and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below: shared HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstreamformer_hip.so")
+
+SF_OK = 0
+SF_ERR_INVALID, SF_ERR_STATE, SF_ERR_HIP, SF_ERR_WORKSPACE, SF_ERR_UNKNOWN_KEY, SF_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
+SF_F32, SF_BF16, SF_F16, SF_F64 = 0, 1, 2, 3
+SF_COMPUTE_BF16, SF_COMPUTE_BF16X3 = 0, 1
+
+
+class SfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "image_size", "patch_size", "num_channels", "num_frames", "hidden_size", "num_hidden_layers",
+        "num_attention_heads", "intermediate_size", "hidden_act", "qkv_bias", "enable_causal_temporal",
+        "add_lora_spatial")] + [("layer_norm_eps", C.c_float)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"streamformer_hip error {code}: {msg}")
+        self.code = code
+
+
+# name -> (restype, argtypes): every symbol include/streamformer_hip.h declares
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "sf_create": (_I, [C.POINTER(SfConfig), _I, C.POINTER(_P)]),
+    "sf_destroy": (None, [_P]),
+    "sf_last_error": (C.c_char_p, []),
+    "sf_abi_version": (_I, []),
+    "sf_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64), _I]),
+    "sf_finalize_weights": (_I, [_P, _I, _I, _I]),
+    "sf_missing_weights": (_I, [_P]),
+    "sf_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
+    "sf_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sf_cache_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
+    "sf_cache_reset": (_I, [_P]),
+    "sf_cache_length": (_I, [_P]),
+    "sf_cache_bytes": (_SZ, [_P]),
+    "sf_cache_destroy": (None, [_P]),
+    "sf_stream_workspace_bytes": (_I, [_P, _P, _I, C.POINTER(_SZ)]),
+    "sf_forward_stream": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "sf_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "sf_op_linear": (_I, [_P, _P, _P, _P, _F, _I, _P, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sf_op_linear_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "sf_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sf_op_attention_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "sf_retrieval_loss": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "sf_localization_loss": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "sf_bench_gemm": (_I, [_P, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double)]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m streamformer_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no non-HIP fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int) -> None:
+    if code != SF_OK:
+        raise NativeError(code, (lib.sf_last_error() or b"").decode(errors="replace"))
+
+
+def ptr(t) -> int:
+    """Device/host address of a tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

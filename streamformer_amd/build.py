@@ -1,0 +1,65 @@
+"""Build the HIP shared library in-tree:  streamformer_amd/libstreamformer_hip.so
+
+    python -m streamformer_amd.build          # or __graft_entry__.build()
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box
+with the repo snapshot; nothing is JIT-built at import time.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libstreamformer_hip.so")
+SOURCES = ["sf_gemm.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "sf_common.h"),
+               os.path.join(os.path.dirname(HERE), "include", "streamformer_hip.h")]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if force or _stale(obj, [srcp] + headers):
+            cmd = [hipcc, *FLAGS, "-c", srcp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

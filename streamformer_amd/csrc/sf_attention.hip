@@ -1,0 +1,496 @@
+// Attention kernels of the encoder path (gfx950, MFMA 16x16x32 bf16):
+//   spatial  : softmax(q k^T d^-0.5) v over the N patches of one frame   (reference modeling:688-717)
+//   temporal : the same over the frames of one patch, causal + KV-cache  (modeling:575-615;
+//              streaming copy vqa_enc:491-560: cache append, offset causal mask)
+//   pooling  : one learned query against the N tokens of a frame         (modeling:1141-1148)
+//
+// Shared structure ("swapped" QK^T): the wave computes S^T = K Q^T, so in the MFMA C layout a lane
+// holds, for ONE query (column = lane&15), 4 keys per 16-key tile.  The softmax row reduction is
+// then in-lane + two xor-shuffles (lanes 16/32 apart), and the exponentiated tile is already in the
+// B-operand layout of the second MFMA, O^T = V^T P^T (no LDS round trip for P).  To make the 8
+// k-elements a lane feeds to that MFMA contiguous keys, the K rows of each 32-key pair of tiles are
+// read in a permuted order (MFMA row i of half hh <-> key 32*kt2 + 8*(i>>2) + 4*hh + (i&3)).
+// V is transposed on its way into LDS (V^T[d][key]) so the A-operand is one ds_read_b128.
+// ACC = the fp32-accurate mode: fp32 inputs are split into bf16 hi+lo and every product becomes
+// hi*hi + hi*lo + lo*hi (same three-term scheme as the GEMM).
+#include "sf_common.h"
+
+#define HD 64  // head_dim supported by these kernels (SigLIP-base/large: 64)
+
+SF_DEVICE f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+
+// K-tile LDS swizzle: the 16 keys one ds_read_b128 lane group touches are
+// {8a + 4hh + r : a in 0..3, r in 0..3}; (r&1) picks the 128-byte half of the 256-byte bank row, so
+// the slot XOR must separate (r>>1, a): 8 values.
+SF_DEVICE int kswz(int key) { return ((key >> 1) & 1) | (((key >> 3) & 3) << 1); }
+
+// load 8 consecutive elements (bf16 or fp32 storage) as floats
+template <bool F32>
+SF_DEVICE void load8(const void* base, size_t elem_off, float (&out)[8]) {
+  if (F32) {
+    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(base) + elem_off);
+    const f32x4_t a = p[0], b = p[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[j] = a[j]; out[4 + j] = b[j]; }
+  } else {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(base) + elem_off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[2 * j] = bf2f(v[j] & 0xffffu); out[2 * j + 1] = bf2f(v[j] >> 16); }
+  }
+}
+
+// MFMA operand fragment straight from global memory: 8 consecutive elements -> bf16x8 (hi [, lo])
+template <bool F32>
+SF_DEVICE void load_frag(const void* base, size_t elem_off, bf16x8_t& hi, bf16x8_t& lo) {
+  if (F32) {
+    float f[8];
+    load8<true>(base, elem_off, f);
+    unsigned int h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf(f[j], h[j], l[j]);
+    u32x4_t hv = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    u32x4_t lv = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    hi = __builtin_bit_cast(bf16x8_t, hv);
+    lo = __builtin_bit_cast(bf16x8_t, lv);
+  } else {
+    hi = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16_t*>(base) + elem_off);
+    lo = hi;
+  }
+}
+
+// pack 8 probabilities into the B-operand fragment (hi [, lo])
+template <bool ACC>
+SF_DEVICE void pack_p(const f32x4_t& a, const f32x4_t& b, bf16x8_t& hi, bf16x8_t& lo) {
+  unsigned int h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { split_bf(a[j], h[j], l[j]); split_bf(b[j], h[4 + j], l[4 + j]); }
+  u32x4_t hv = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  hi = __builtin_bit_cast(bf16x8_t, hv);
+  if (ACC) {
+    u32x4_t lv = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    lo = __builtin_bit_cast(bf16x8_t, lv);
+  }
+}
+
+template <bool ACC>
+SF_DEVICE void store_ctx(bf16_t* ctx_hi, bf16_t* ctx_lo, size_t off, const f32x4_t& o, float inv) {
+  unsigned int h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_bf(o[j] * inv, h[j], l[j]);
+  *reinterpret_cast<u32x2_t*>(ctx_hi + off) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+  if (ACC) *reinterpret_cast<u32x2_t*>(ctx_lo + off) = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+}
+
+// ================================================================================================
+// spatial attention: block = (frame, head), 4 waves; K and V^T of the head live in LDS
+// ================================================================================================
+template <bool ACC, int MAXNT2>
+__global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int vpitch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int frame = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+  const int N = p.N;
+  const int nkp = (N + 31) & ~31;
+  const int nt2 = nkp >> 5;
+  char* k_hi = smem;
+  char* k_lo = k_hi + (ACC ? nkp * 128 : 0);
+  char* v_hi = k_lo + nkp * 128;
+  char* v_lo = v_hi + (ACC ? HD * vpitch : 0);
+  const size_t row0 = (size_t)frame * N;
+
+  // ---- stage K (swizzled rows) -------------------------------------------------------------------
+  for (int i = tid; i < nkp * 8; i += 256) {
+    const int key = i >> 3, c = i & 7;
+    u32x4_t hv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+    if (key < N) {
+      bf16x8_t a, b;
+      load_frag<ACC>(p.k, (row0 + key) * p.row_pitch_kv + h * HD + c * 8, a, b);
+      hv = __builtin_bit_cast(u32x4_t, a);
+      lv = __builtin_bit_cast(u32x4_t, b);
+    }
+    const int off = key * 128 + ((c ^ kswz(key)) << 4);
+    *reinterpret_cast<u32x4_t*>(k_hi + off) = hv;
+    if (ACC) *reinterpret_cast<u32x4_t*>(k_lo + off) = lv;
+  }
+  // ---- stage V^T: item = (key pair, 8-wide d chunk) -> 8 dword writes {V[2kp][d], V[2kp+1][d]} -----
+  for (int i = tid; i < (nkp >> 1) * 8; i += 256) {
+    const int kp = i >> 3, c = i & 7;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v0[j] = 0.f; v1[j] = 0.f; }
+    if (2 * kp < N) load8<ACC>(p.v, (row0 + 2 * kp) * p.row_pitch_kv + h * HD + c * 8, v0);
+    if (2 * kp + 1 < N) load8<ACC>(p.v, (row0 + 2 * kp + 1) * p.row_pitch_kv + h * HD + c * 8, v1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned int h0, l0, h1, l1;
+      split_bf(v0[j], h0, l0);
+      split_bf(v1[j], h1, l1);
+      const int off = (c * 8 + j) * vpitch + kp * 4;
+      *reinterpret_cast<unsigned int*>(v_hi + off) = h0 | (h1 << 16);
+      if (ACC) *reinterpret_cast<unsigned int*>(v_lo + off) = l0 | (l1 << 16);
+    }
+  }
+  __syncthreads();
+
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    int qi = qt * 16 + l15;
+    const bool qvalid = qi < N;
+    if (!qvalid) qi = N - 1;
+    bf16x8_t qh[2], ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      load_frag<ACC>(p.q, (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
+
+    // ---- S^T = K Q^T ---------------------------------------------------------------------------
+    f32x4_t s[MAXNT2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        if (kt2 < nt2) {
+          const int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
+          const int sw = kswz(key);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int off = key * 128 + (((ks * 4 + g) ^ sw) << 4);
+            const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(k_hi + off);
+            if (ACC) {
+              const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(k_lo + off);
+              acc = mfma16(kl, qh[ks], acc);
+              acc = mfma16(kh, ql[ks], acc);
+            }
+            acc = mfma16(kh, qh[ks], acc);
+          }
+        }
+        s[kt2][hh] = acc;
+      }
+    }
+    // ---- softmax over keys (lane: query l15; keys 32*kt2 + 8*g + 4*hh + r) ------------------------
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt2 * 32 + g * 8 + hh * 4 + r;
+          const float v = (kt2 < nt2 && key < N) ? s[kt2][hh][r] * p.scale : -INFINITY;
+          s[kt2][hh][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = ACC ? expf(s[kt2][hh][r] - mx) : __expf(s[kt2][hh][r] - mx);
+          s[kt2][hh][r] = e;
+          sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // ---- O^T = V^T P^T ----------------------------------------------------------------------------
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+      if (kt2 < nt2) {
+        bf16x8_t ph, pl;
+        pack_p<ACC>(s[kt2][0], s[kt2][1], ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int off = (dt * 16 + l15) * vpitch + (kt2 * 32 + g * 8) * 2;
+          const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(v_hi + off);
+          if (ACC) {
+            const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(v_lo + off);
+            o[dt] = mfma16(vl, ph, o[dt]);
+            o[dt] = mfma16(vh, pl, o[dt]);
+          }
+          o[dt] = mfma16(vh, ph, o[dt]);
+        }
+      }
+    }
+    if (qvalid) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        store_ctx<ACC>(p.ctx_hi, p.ctx_lo, (row0 + qi) * p.D + h * HD + dt * 16 + g * 4, o[dt], inv);
+    }
+  }
+}
+
+static int vt_pitch(int nkp) {
+  // bytes per V^T row: 2*nkp + pad with pitch % 256 in {32, 224}: the 16 d-rows of a ds_read_b128
+  // lane group then fall on 16 distinct 16-byte slots ("LDS layouts").
+  for (int pad = 0; pad < 256; pad += 32) {
+    const int m = (2 * nkp + pad) % 256;
+    if (m == 32 || m == 224) return 2 * nkp + pad;
+  }
+  return 2 * nkp + 32;
+}
+
+hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
+  if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
+  const int nkp = (a.N + 31) & ~31;
+  if (nkp > 32 * 7) return hipErrorInvalidValue;   // N <= 224 patches (16x16 patches of <= 224 px)
+  const int vp = vt_pitch(nkp);
+  const size_t lds = (size_t)(nkp * 128 + HD * vp) * (accurate ? 2 : 1);
+  const dim3 grid(a.frames * a.heads), block(256);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (accurate) hipLaunchKernelGGL((sf_spatial_attn_kernel<true, 7>), grid, block, lds, s, a, vp);
+  else hipLaunchKernelGGL((sf_spatial_attn_kernel<false, 7>), grid, block, lds, s, a, vp);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+// temporal attention: block = (b, n); wave w takes heads w, w+4, ...; K/Q fragments come straight
+// from global memory (one 128-byte line per frame and head), V^T goes through a per-wave LDS patch.
+// Row addressing: see SfAttnArgs.
+// ================================================================================================
+template <bool ACC, int MAXNT2>
+__global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int vpitch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / p.N, n = blockIdx.x % p.N;
+  const int Tk = p.Tk, Tq = p.Tq;
+  const int tkp = (Tk + 31) & ~31;
+  const int nt2 = tkp >> 5;
+  char* v_hi = smem + (size_t)wave * HD * vpitch * (ACC ? 2 : 1);
+  char* v_lo = v_hi + HD * vpitch;
+  const int hiters = (p.heads + 3) >> 2;
+
+  for (int it = 0; it < hiters; ++it) {
+    const int h = it * 4 + wave;
+    const bool hvalid = h < p.heads;
+    __syncthreads();   // previous head's V^T reads are done
+    if (hvalid) {
+      for (int i = lane; i < (tkp >> 1) * 8; i += 64) {
+        const int kp = i >> 3, c = i & 7;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v0[j] = 0.f; v1[j] = 0.f; }
+        if (2 * kp < Tk) load8<ACC>(p.v, (((size_t)b * p.Tcap + 2 * kp) * p.N + n) * p.row_pitch_kv + h * HD + c * 8, v0);
+        if (2 * kp + 1 < Tk) load8<ACC>(p.v, (((size_t)b * p.Tcap + 2 * kp + 1) * p.N + n) * p.row_pitch_kv + h * HD + c * 8, v1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          unsigned int h0, l0, h1, l1;
+          split_bf(v0[j], h0, l0);
+          split_bf(v1[j], h1, l1);
+          const int off = (c * 8 + j) * vpitch + kp * 4;
+          *reinterpret_cast<unsigned int*>(v_hi + off) = h0 | (h1 << 16);
+          if (ACC) *reinterpret_cast<unsigned int*>(v_lo + off) = l0 | (l1 << 16);
+        }
+      }
+    }
+    __syncthreads();
+    if (!hvalid) continue;
+
+    const int nqt = (Tq + 15) >> 4;
+    for (int qt = 0; qt < nqt; ++qt) {
+      int t = qt * 16 + l15;
+      const bool qvalid = t < Tq;
+      if (!qvalid) t = Tq - 1;
+      const size_t qrow = ((size_t)b * p.Tq_cap + p.q_t0 + t) * p.N + n;
+      bf16x8_t qh[2], ql[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        load_frag<ACC>(p.q, qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
+
+      f32x4_t s[MAXNT2][2];
+#pragma unroll
+      for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+          if (kt2 < nt2) {
+            int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
+            key = key < Tk ? key : Tk - 1;                 // clamped rows are masked below
+            const size_t krow = ((size_t)b * p.Tcap + key) * p.N + n;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              bf16x8_t kh, kl;
+              load_frag<ACC>(p.k, krow * p.row_pitch_kv + h * HD + ks * 32 + g * 8, kh, kl);
+              if (ACC) {
+                acc = mfma16(kl, qh[ks], acc);
+                acc = mfma16(kh, ql[ks], acc);
+              }
+              acc = mfma16(kh, qh[ks], acc);
+            }
+          }
+          s[kt2][hh] = acc;
+        }
+      }
+      const int qpos = p.t_past + t;   // absolute frame index of this lane's query
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt2 * 32 + g * 8 + hh * 4 + r;
+            const bool keep = kt2 < nt2 && key < Tk && (!p.causal || key <= qpos);
+            const float v = keep ? s[kt2][hh][r] * p.scale : -INFINITY;
+            s[kt2][hh][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = ACC ? expf(s[kt2][hh][r] - mx) : __expf(s[kt2][hh][r] - mx);
+            s[kt2][hh][r] = e;
+            sum += e;
+          }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+
+      f32x4_t o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+        if (kt2 < nt2) {
+          bf16x8_t ph, pl;
+          pack_p<ACC>(s[kt2][0], s[kt2][1], ph, pl);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const int off = (dt * 16 + l15) * vpitch + (kt2 * 32 + g * 8) * 2;
+            const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(v_hi + off);
+            if (ACC) {
+              const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(v_lo + off);
+              o[dt] = mfma16(vl, ph, o[dt]);
+              o[dt] = mfma16(vh, pl, o[dt]);
+            }
+            o[dt] = mfma16(vh, ph, o[dt]);
+          }
+        }
+      }
+      if (qvalid) {
+        const size_t orow = ((size_t)b * Tq + t) * p.N + n;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          store_ctx<ACC>(p.ctx_hi, p.ctx_lo, orow * p.D + h * HD + dt * 16 + g * 4, o[dt], inv);
+      }
+    }
+  }
+}
+
+hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
+  if (a.D != a.heads * HD || a.Tq <= 0 || a.Tk <= 0 || a.B <= 0 || a.N <= 0) return hipErrorInvalidValue;
+  const int tkp = (a.Tk + 31) & ~31;
+  if (tkp > 32 * 8) return hipErrorInvalidValue;   // <= 256 cached frames per stream
+  const int vp = vt_pitch(tkp);
+  const size_t lds = (size_t)4 * HD * vp * (accurate ? 2 : 1);
+  const dim3 grid(a.B * a.N), block(256);
+#define SF_TL(ACCV, NT)                                                                              \
+  do {                                                                                               \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_kernel<ACCV, NT>),     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+    hipLaunchKernelGGL((sf_temporal_attn_kernel<ACCV, NT>), grid, block, lds, s, a, vp);               \
+  } while (0)
+  const int nt2 = tkp >> 5;
+  if (accurate) {
+    if (nt2 <= 1) SF_TL(true, 1); else if (nt2 <= 2) SF_TL(true, 2); else if (nt2 <= 4) SF_TL(true, 4); else SF_TL(true, 8);
+  } else {
+    if (nt2 <= 1) SF_TL(false, 1); else if (nt2 <= 2) SF_TL(false, 2); else if (nt2 <= 4) SF_TL(false, 4); else SF_TL(false, 8);
+  }
+#undef SF_TL
+  return hipGetLastError();
+}
+
+// ================================================================================================
+// pooling-head attention: one pre-projected, pre-scaled query per head against the N tokens of a
+// frame.  One wave per (frame, head); scores via per-lane 64-long dots, output with lane = d.
+// kv rows: [frames*N, row_pitch] with K in columns [0,D) and V in [D,2D).
+// ================================================================================================
+template <bool F32>
+__global__ __launch_bounds__(256) void sf_pool_attn_kernel(const float* __restrict__ q, const void* __restrict__ kv,
+                                                           int row_pitch, bf16_t* __restrict__ ctx_hi,
+                                                           bf16_t* __restrict__ ctx_lo, int frames, int N,
+                                                           int heads, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= frames * heads) return;
+  const int frame = item / heads, h = item % heads;
+  float* sc = reinterpret_cast<float*>(smem) + (size_t)wave * ((N + 63) & ~63);
+  float qv[HD];
+#pragma unroll
+  for (int j = 0; j < HD; ++j) qv[j] = q[h * HD + j];
+  const size_t row0 = (size_t)frame * N;
+  float mx = -INFINITY;
+  for (int key = lane; key < N; key += 64) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float kk[8];
+      load8<F32>(kv, (row0 + key) * row_pitch + h * HD + c * 8, kk);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(qv[c * 8 + j], kk[j], acc);
+    }
+    sc[key] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int key = lane; key < N; key += 64) {
+    const float e = expf(sc[key] - mx);
+    sc[key] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float acc = 0.f;
+  for (int key = 0; key < N; ++key) {
+    float vv;
+    const size_t off = (row0 + key) * row_pitch + D + h * HD + lane;
+    if (F32) vv = reinterpret_cast<const float*>(kv)[off];
+    else vv = bf2f(reinterpret_cast<const bf16_t*>(kv)[off]);
+    acc = fmaf(sc[key], vv, acc);
+  }
+  acc /= sum;
+  unsigned int hi, lo;
+  split_bf(acc, hi, lo);
+  const size_t o = (size_t)frame * D + h * HD + lane;
+  ctx_hi[o] = (bf16_t)hi;
+  if (ctx_lo) ctx_lo[o] = (bf16_t)lo;
+}
+
+hipError_t sf_launch_pool_attention(const float* q, const void* kv, int kv_is_f32, int row_pitch,
+                                    bf16_t* ctx_hi, bf16_t* ctx_lo, int frames, int N, int heads,
+                                    int D, hipStream_t s) {
+  if (D != heads * HD) return hipErrorInvalidValue;
+  const int items = frames * heads;
+  const size_t lds = (size_t)4 * ((N + 63) & ~63) * sizeof(float);
+  const dim3 grid((items + 3) / 4), block(256);
+  if (kv_is_f32) hipLaunchKernelGGL(sf_pool_attn_kernel<true>, grid, block, lds, s, q, kv, row_pitch, ctx_hi, ctx_lo, frames, N, heads, D);
+  else hipLaunchKernelGGL(sf_pool_attn_kernel<false>, grid, block, lds, s, q, kv, row_pitch, ctx_hi, ctx_lo, frames, N, heads, D);
+  return hipGetLastError();
+}

@@ -1,0 +1,131 @@
+// Shared device helpers and kernel launch declarations (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define SF_DEVICE __device__ __forceinline__
+
+// round-to-nearest-even fp32 -> bf16 (inputs on this path are finite)
+SF_DEVICE unsigned int f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+SF_DEVICE float bf2f(unsigned int b) { return __uint_as_float(b << 16); }
+SF_DEVICE unsigned int pack_bf2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the operand split of SF_COMPUTE_BF16X3
+SF_DEVICE void split_bf(float x, unsigned int& hi, unsigned int& lo) {
+  hi = f2bf(x);
+  lo = f2bf(x - bf2f(hi));
+}
+
+SF_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+SF_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+SF_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+SF_DEVICE float gelu_tanh(float x) {
+  const float k = 0.7978845608028654f;
+  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+SF_DEVICE float apply_act(float x, int act) {
+  return act == 0 ? gelu_erf(x) : (act == 1 ? gelu_tanh(x) : fmaxf(x, 0.0f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM:  C[M,N] = A[M,K] * W[N,K]^T   (both operands K-contiguous bf16; optional lo halves)
+// ------------------------------------------------------------------------------------------------
+enum SfEpilogue {
+  SF_EPI_F32 = 0,        // out_f32 = acc + bias
+  SF_EPI_BF16 = 1,       // out_bf16 (+ out_lo) = acc + bias
+  SF_EPI_ACT_BF16 = 2,   // out_bf16 (+ out_lo) = act(acc + bias)
+  SF_EPI_RESID_F32 = 3,  // out_f32 = resid + alpha * (acc + bias)      (out may alias resid)
+  SF_EPI_EMBED_F32 = 4,  // out_f32 = acc + bias + pos[row % Np] + time[(row / Np) % Tn]
+};
+
+struct SfGemmArgs {
+  const bf16_t* a_hi; const bf16_t* a_lo;   // [M,K]   (a_lo == nullptr unless split)
+  const bf16_t* w_hi; const bf16_t* w_lo;   // [N,K]
+  const float* bias;                        // [N] or nullptr
+  int M, N, K;
+  int epi;
+  int act;                                  // SF_EPI_ACT_BF16: 0 erf-gelu, 1 tanh-gelu, 2 relu
+  float alpha;                              // SF_EPI_RESID_F32
+  const float* resid;                       // [M,N] fp32
+  const float* pos; const float* time_rows; // SF_EPI_EMBED_F32: [Np,N], [Tn,N]
+  int Np, Tn;
+  float* out_f32;                           // [*,ldc]
+  bf16_t* out_hi; bf16_t* out_lo;           // [*,ldc]
+  int ldc;                                  // output row pitch in elements
+  // output row remap (KV-cache appends): out_row = (m / grp_rows) * grp_stride + grp_off + m % grp_rows
+  int grp_rows, grp_stride, grp_off;
+};
+hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// row-wise / elementwise kernels
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over D: x fp32 [rows,D] -> any of {y_f32, y_hi, y_lo} (nullptr = skip)
+hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
+                               bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s);
+// pixels [F,C,H,W] (fp32 or bf16) -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw)
+hipError_t sf_launch_patchify(const void* pixels, int pixel_is_bf16, bf16_t* out_hi, bf16_t* out_lo,
+                              int F, int C, int H, int W, int P, hipStream_t s);
+// fp32 [n] -> bf16 hi (+lo)
+hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
+// gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)
+struct SfRowIndex { int n; int idx[256]; };
+hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// attention
+// ------------------------------------------------------------------------------------------------
+struct SfAttnArgs {
+  // q/k/v element (seq position p of sequence g, head h, dim e) lives at
+  //   base[(g_off(g) + p * pos_stride) * row_pitch + col0 + h*64 + e]
+  // with col0 = 0 / D / 2D for q / k / v.  Either bf16 (fast) or fp32 (accurate) storage.
+  const void* q; const void* k; const void* v;
+  int in_is_f32;
+  int row_pitch_q, row_pitch_kv;     // elements per token row of the q / kv buffers
+  int heads;
+  float scale;
+  // spatial: one sequence per frame: rows [f*N, f*N+N)
+  int N;                              // keys == queries == N tokens
+  int frames;
+  // temporal: sequence over frames for fixed (b, n):
+  //   q rows ((b*Tq_cap + q_t0 + t)*N + n), t < Tq ; kv rows ((b*Tcap + t)*N + n), t < Tk ;
+  //   query t sits at absolute frame t_past + t (causal: keys <= that); ctx rows ((b*Tq + t)*N + n)
+  int B, Tq, Tk, Tcap, t_past, causal, Tq_cap, q_t0;
+  bf16_t* ctx_hi; bf16_t* ctx_lo;     // [rows, D] output (lo only in accurate mode)
+  int D;
+};
+hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
+hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
+// pooling head: one query (probe, pre-projected & pre-scaled, fp32 [D]) vs N keys per frame
+hipError_t sf_launch_pool_attention(const float* q, const void* kv, int kv_is_f32, int row_pitch,
+                                    bf16_t* ctx_hi, bf16_t* ctx_lo, int frames, int N, int heads,
+                                    int D, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// loss heads
+// ------------------------------------------------------------------------------------------------
+hipError_t sf_launch_retrieval_loss(const float* pooler, const float* text, int B, int T, int D, int Bt,
+                                    int pos_offset, float logit_scale, float logit_bias,
+                                    float* loss, float* grad_pooler, float* grad_scalars, hipStream_t s);
+hipError_t sf_launch_localization_loss(const float* pooler, const float* label_emb, const int* labels,
+                                       int B, int T, int D, int L, float logit_scale, float logit_bias,
+                                       float* loss, float* grad_pooler, float* grad_scalars, hipStream_t s);

@@ -1,0 +1,826 @@
+// C-ABI implementation: handle, weight packing, and the launch schedule of the encoder forward
+// (reference TimesformerMultiTaskingModelSigLIP.forward, modeling:1299-1354; layer body :934-1004;
+// streaming copy vqa_enc:1316-1392).  See include/streamformer_hip.h for the contract.
+#include "../../include/streamformer_hip.h"
+#include "sf_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define SF_ABI_VERSION 1
+static const int kLoraRank = 32;  // modeling:1280-1281
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return set_err(SF_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------------------
+static inline uint16_t h_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float h_bf2f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  size_t numel() const { return data.size(); }
+};
+
+struct DevLinear {          // y = x W^T + b ; W [N,K]
+  bf16_t* w_hi = nullptr;
+  bf16_t* w_lo = nullptr;
+  float* bias = nullptr;
+  int N = 0, K = 0;
+};
+struct DevLN { float* g = nullptr; float* b = nullptr; };
+struct DevLayer {
+  DevLN ln_t, ln_b, ln_a;
+  DevLinear t_qkv, t_out, t_dense, t_fused, s_qkv, s_out, up, down;
+  float gate_tanh = 0.f;
+};
+
+struct sf_encoder {
+  sf_config cfg;
+  int device = 0;
+  int N = 0, D = 0, I = 0, L = 0, Kp = 0;
+  std::map<std::string, HostTensor> host;   // staged fp32 copies until finalize
+  std::map<std::string, std::vector<int64_t>> expected;
+  bool finalized = false;
+  int compute = SF_COMPUTE_BF16;
+  bool fused_temporal = false;
+  std::vector<void*> allocs;
+  // device weights
+  DevLinear patch;
+  float* pos = nullptr;       // [N,D]
+  float* time_tab = nullptr;  // [num_frames,D]
+  std::vector<DevLayer> layers;
+  DevLN post_ln, head_ln;
+  DevLinear head_kv, head_out, head_fc1, head_fc2;
+  float* head_q = nullptr;    // [D] probe query, projected and scaled
+  size_t weight_bytes = 0;
+};
+
+struct sf_cache {
+  sf_encoder* enc = nullptr;
+  int B = 0, cap = 0, H = 0, W = 0, N = 0, len = 0;
+  std::vector<void*> qkv;   // per layer [B, cap, N, 3D] (bf16 or fp32 by compute mode)
+  size_t bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// expected weights
+// ------------------------------------------------------------------------------------------------
+static void build_expected(sf_encoder* e) {
+  const sf_config& c = e->cfg;
+  const int64_t D = c.hidden_size, I = c.intermediate_size, P = c.patch_size, C = c.num_channels;
+  const int64_t N = e->N, T = c.num_frames;
+  auto& x = e->expected;
+  x["embeddings.position_embeddings"] = {1, N, D};
+  x["embeddings.time_embeddings"] = {1, T, D};
+  x["embeddings.patch_embeddings.projection.weight"] = {D, C, P, P};
+  x["embeddings.patch_embeddings.projection.bias"] = {D};
+  auto lin = [&](const std::string& p, int64_t out, int64_t in, bool bias) {
+    x[p + ".weight"] = {out, in};
+    if (bias) x[p + ".bias"] = {out};
+  };
+  auto ln = [&](const std::string& p) { x[p + ".weight"] = {D}; x[p + ".bias"] = {D}; };
+  for (int i = 0; i < c.num_hidden_layers; ++i) {
+    const std::string p = "encoder.layer." + std::to_string(i) + ".";
+    x[p + "temporal_attention_gating"] = {};
+    ln(p + "temporal_layernorm");
+    lin(p + "temporal_attention.attention.qkv", 3 * D, D, c.qkv_bias);
+    lin(p + "temporal_attention.output.dense", D, D, true);
+    lin(p + "temporal_dense", D, D, true);
+    ln(p + "layernorm_before");
+    lin(p + "attention.attention.qkv", 3 * D, D, c.qkv_bias);
+    lin(p + "attention.output.dense", D, D, true);
+    if (c.add_lora_spatial) {
+      x[p + "attention.attention.qkv_lora_a.weight"] = {kLoraRank, D};
+      x[p + "attention.attention.qkv_lora_b.weight"] = {3 * D, kLoraRank};
+      x[p + "attention.output.dense_lora_a.weight"] = {kLoraRank, D};
+      x[p + "attention.output.dense_lora_b.weight"] = {D, kLoraRank};
+    }
+    ln(p + "layernorm_after");
+    lin(p + "intermediate.dense", I, D, true);
+    lin(p + "output.dense", D, I, true);
+  }
+  ln("post_layernorm");
+  x["head.probe"] = {1, 1, D};
+  x["head.attention.in_proj_weight"] = {3 * D, D};
+  x["head.attention.in_proj_bias"] = {3 * D};
+  lin("head.attention.out_proj", D, D, true);
+  ln("head.layernorm");
+  lin("head.mlp.fc1", I, D, true);
+  lin("head.mlp.fc2", D, I, true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_abi_version(void) { return SF_ABI_VERSION; }
+extern "C" const char* sf_last_error(void) { return g_err; }
+
+extern "C" int sf_create(const sf_config* cfg, int device, sf_encoder** out) {
+  if (!cfg || !out) return set_err(SF_ERR_INVALID, "sf_create: null argument");
+  const sf_config& c = *cfg;
+  if (c.hidden_size <= 0 || c.num_attention_heads <= 0 || c.hidden_size % c.num_attention_heads)
+    return set_err(SF_ERR_INVALID, "hidden_size %d not divisible by heads %d", c.hidden_size, c.num_attention_heads);
+  if (c.hidden_size / c.num_attention_heads != 64)
+    return set_err(SF_ERR_INVALID, "head_dim %d unsupported: the gfx950 attention kernels are built for head_dim 64",
+                   c.hidden_size / c.num_attention_heads);
+  if (c.hidden_size % 64 || c.intermediate_size % 64)
+    return set_err(SF_ERR_INVALID, "hidden_size and intermediate_size must be multiples of 64");
+  if (c.patch_size % 8 || (c.num_channels * c.patch_size * c.patch_size) % 64)
+    return set_err(SF_ERR_INVALID, "patch_size must be a multiple of 8 and C*P*P a multiple of 64");
+  if (c.image_size % c.patch_size) return set_err(SF_ERR_INVALID, "image_size not a multiple of patch_size");
+  if (c.hidden_act < 0 || c.hidden_act > 2) return set_err(SF_ERR_INVALID, "unsupported hidden_act code %d", c.hidden_act);
+  if (c.num_frames <= 0 || c.num_frames > 256) return set_err(SF_ERR_INVALID, "num_frames must be in 1..256");
+  sf_encoder* e = new sf_encoder();
+  e->cfg = c;
+  e->device = device;
+  e->D = c.hidden_size;
+  e->I = c.intermediate_size;
+  e->L = c.num_hidden_layers;
+  e->N = (c.image_size / c.patch_size) * (c.image_size / c.patch_size);
+  e->Kp = c.num_channels * c.patch_size * c.patch_size;
+  build_expected(e);
+  *out = e;
+  return SF_OK;
+}
+
+static void free_device(sf_encoder* e) {
+  for (void* p : e->allocs) (void)hipFree(p);
+  e->allocs.clear();
+}
+
+extern "C" void sf_destroy(sf_encoder* e) {
+  if (!e) return;
+  free_device(e);
+  delete e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_load_tensor(sf_encoder* e, const char* key, const void* host_ptr, int dtype,
+                              const int64_t* shape, int ndim) {
+  if (!e || !key || !host_ptr || ndim < 0 || (ndim && !shape)) return set_err(SF_ERR_INVALID, "sf_load_tensor: null argument");
+  std::string k(key);
+  if (k.rfind("timesformer.", 0) == 0) k = k.substr(12);   // wrapper checkpoints (base_model_prefix, modeling:1073)
+  auto it = e->expected.find(k);
+  if (it == e->expected.end()) return set_err(SF_ERR_UNKNOWN_KEY, "'%s' is not a weight of this model", key);
+  size_t n = 1, ne = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  for (int64_t d : it->second) ne *= (size_t)d;
+  bool same = n == ne;
+  if (same && (int)it->second.size() == ndim)
+    for (int i = 0; i < ndim; ++i) same = same && it->second[i] == shape[i];
+  if (!same) return set_err(SF_ERR_INVALID, "'%s': shape mismatch (%zu elements given, %zu expected)", key, n, ne);
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.resize(n);
+  switch (dtype) {
+    case SF_F32: memcpy(t.data.data(), host_ptr, n * 4); break;
+    case SF_F64: for (size_t i = 0; i < n; ++i) t.data[i] = (float)((const double*)host_ptr)[i]; break;
+    case SF_BF16: for (size_t i = 0; i < n; ++i) t.data[i] = h_bf2f(((const uint16_t*)host_ptr)[i]); break;
+    case SF_F16: {
+      const uint16_t* p = (const uint16_t*)host_ptr;
+      for (size_t i = 0; i < n; ++i) {
+        const uint32_t s = (p[i] >> 15) & 1, ex = (p[i] >> 10) & 31, m = p[i] & 1023;
+        float v;
+        if (ex == 0) v = ldexpf((float)m, -24);
+        else if (ex == 31) v = m ? NAN : INFINITY;
+        else v = ldexpf((float)(m | 1024), (int)ex - 25);
+        t.data[i] = s ? -v : v;
+      }
+      break;
+    }
+    default: return set_err(SF_ERR_INVALID, "unknown dtype %d", dtype);
+  }
+  e->host[k] = std::move(t);
+  e->finalized = false;
+  return SF_OK;
+}
+
+extern "C" int sf_missing_weights(sf_encoder* e) {
+  if (!e) return set_err(SF_ERR_INVALID, "null handle");
+  int missing = 0;
+  std::string names;
+  for (auto& kv : e->expected)
+    if (!e->host.count(kv.first)) {
+      ++missing;
+      if (names.size() < 800) names += kv.first + " ";
+    }
+  if (missing) set_err(SF_ERR_STATE, "missing %d weights: %s", missing, names.c_str());
+  return missing;
+}
+
+template <typename T>
+static int dev_upload(sf_encoder* e, const std::vector<T>& h, T** out) {
+  void* p = nullptr;
+  const size_t bytes = h.size() * sizeof(T);
+  HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+  e->allocs.push_back(p);
+  if (bytes) HIP_TRY(hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+  e->weight_bytes += bytes;
+  *out = (T*)p;
+  return SF_OK;
+}
+
+static int upload_linear(sf_encoder* e, const std::vector<float>& w, const std::vector<float>* bias, int N,
+                         int K, DevLinear* out) {
+  std::vector<uint16_t> hi(w.size()), lo;
+  const bool split = e->compute == SF_COMPUTE_BF16X3;
+  if (split) lo.resize(w.size());
+  for (size_t i = 0; i < w.size(); ++i) {
+    hi[i] = h_f2bf(w[i]);
+    if (split) lo[i] = h_f2bf(w[i] - h_bf2f(hi[i]));
+  }
+  int rc = dev_upload<uint16_t>(e, hi, &out->w_hi);
+  if (rc) return rc;
+  if (split && (rc = dev_upload<uint16_t>(e, lo, &out->w_lo))) return rc;
+  if (bias && (rc = dev_upload<float>(e, *bias, &out->bias))) return rc;
+  out->N = N;
+  out->K = K;
+  return SF_OK;
+}
+
+static int upload_ln(sf_encoder* e, const std::string& p, DevLN* out) {
+  int rc = dev_upload<float>(e, e->host[p + ".weight"].data, &out->g);
+  if (rc) return rc;
+  return dev_upload<float>(e, e->host[p + ".bias"].data, &out->b);
+}
+
+// W += B A  (lora_b [out, r] x lora_a [r, in]); accumulate in double
+static void merge_lora_into(std::vector<float>& w, const std::vector<float>& a, const std::vector<float>& b,
+                            int out, int in, int r) {
+  for (int o = 0; o < out; ++o)
+    for (int i = 0; i < in; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < r; ++k) acc += (double)b[(size_t)o * r + k] * (double)a[(size_t)k * in + i];
+      w[(size_t)o * in + i] = (float)((double)w[(size_t)o * in + i] + acc);
+    }
+}
+
+extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, int fuse_temporal_proj) {
+  if (!e) return set_err(SF_ERR_INVALID, "null handle");
+  if (compute != SF_COMPUTE_BF16 && compute != SF_COMPUTE_BF16X3) return set_err(SF_ERR_INVALID, "unknown compute mode %d", compute);
+  if (sf_missing_weights(e)) return SF_ERR_STATE;
+  if (e->cfg.add_lora_spatial && !merge_lora)
+    return set_err(SF_ERR_INVALID, "un-merged LoRA execution is a training-time path; the inference forward needs merge_lora=1");
+  HIP_TRY(hipSetDevice(e->device));
+  free_device(e);
+  e->weight_bytes = 0;
+  e->compute = compute;
+  e->fused_temporal = fuse_temporal_proj != 0;
+  const int D = e->D, I = e->I;
+  auto H = [&](const std::string& k) -> std::vector<float>& { return e->host[k].data; };
+  auto Hopt = [&](const std::string& k) -> std::vector<float>* { return e->host.count(k) ? &e->host[k].data : nullptr; };
+  int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+  TRY(upload_linear(e, H("embeddings.patch_embeddings.projection.weight"), Hopt("embeddings.patch_embeddings.projection.bias"), D, e->Kp, &e->patch));
+  TRY(dev_upload<float>(e, H("embeddings.position_embeddings"), &e->pos));
+  TRY(dev_upload<float>(e, H("embeddings.time_embeddings"), &e->time_tab));
+  e->layers.assign(e->L, DevLayer());
+  for (int i = 0; i < e->L; ++i) {
+    const std::string p = "encoder.layer." + std::to_string(i) + ".";
+    DevLayer& l = e->layers[i];
+    l.gate_tanh = std::tanh(H(p + "temporal_attention_gating")[0]);
+    TRY(upload_ln(e, p + "temporal_layernorm", &l.ln_t));
+    TRY(upload_ln(e, p + "layernorm_before", &l.ln_b));
+    TRY(upload_ln(e, p + "layernorm_after", &l.ln_a));
+    TRY(upload_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"), 3 * D, D, &l.t_qkv));
+    if (e->fused_temporal) {
+      // temporal_dense(output.dense(x)) = (W2 W1) x + (W2 b1 + b2)      (modeling:947-954)
+      const std::vector<float>& w1 = H(p + "temporal_attention.output.dense.weight");
+      const std::vector<float>& b1 = H(p + "temporal_attention.output.dense.bias");
+      const std::vector<float>& w2 = H(p + "temporal_dense.weight");
+      const std::vector<float>& b2 = H(p + "temporal_dense.bias");
+      std::vector<float> wf((size_t)D * D), bf(D);
+      std::vector<double> row(D);
+      for (int o = 0; o < D; ++o) {
+        std::fill(row.begin(), row.end(), 0.0);
+        double bb = b2[o];
+        for (int k = 0; k < D; ++k) {
+          const double a = w2[(size_t)o * D + k];
+          bb += a * b1[k];
+          const float* w1r = &w1[(size_t)k * D];
+          for (int j = 0; j < D; ++j) row[j] += a * w1r[j];
+        }
+        for (int j = 0; j < D; ++j) wf[(size_t)o * D + j] = (float)row[j];
+        bf[o] = (float)bb;
+      }
+      TRY(upload_linear(e, wf, &bf, D, D, &l.t_fused));
+    } else {
+      TRY(upload_linear(e, H(p + "temporal_attention.output.dense.weight"), Hopt(p + "temporal_attention.output.dense.bias"), D, D, &l.t_out));
+      TRY(upload_linear(e, H(p + "temporal_dense.weight"), Hopt(p + "temporal_dense.bias"), D, D, &l.t_dense));
+    }
+    std::vector<float> wq = H(p + "attention.attention.qkv.weight");
+    std::vector<float> wo = H(p + "attention.output.dense.weight");
+    if (e->cfg.add_lora_spatial) {
+      merge_lora_into(wq, H(p + "attention.attention.qkv_lora_a.weight"), H(p + "attention.attention.qkv_lora_b.weight"), 3 * D, D, kLoraRank);
+      merge_lora_into(wo, H(p + "attention.output.dense_lora_a.weight"), H(p + "attention.output.dense_lora_b.weight"), D, D, kLoraRank);
+    }
+    TRY(upload_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), 3 * D, D, &l.s_qkv));
+    TRY(upload_linear(e, wo, Hopt(p + "attention.output.dense.bias"), D, D, &l.s_out));
+    TRY(upload_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"), I, D, &l.up));
+    TRY(upload_linear(e, H(p + "output.dense.weight"), Hopt(p + "output.dense.bias"), D, I, &l.down));
+  }
+  TRY(upload_ln(e, "post_layernorm", &e->post_ln));
+  TRY(upload_ln(e, "head.layernorm", &e->head_ln));
+  {
+    // nn.MultiheadAttention packed in_proj rows are [q; k; v] (modeling:1135-1137).  The query is
+    // the learned probe only, identical for every frame: project and scale it once, in double.
+    const std::vector<float>& w = H("head.attention.in_proj_weight");
+    const std::vector<float>& b = H("head.attention.in_proj_bias");
+    const std::vector<float>& probe = H("head.probe");
+    std::vector<float> q(D);
+    const double sc = 1.0 / std::sqrt(64.0);
+    for (int o = 0; o < D; ++o) {
+      double acc = b[o];
+      for (int k = 0; k < D; ++k) acc += (double)w[(size_t)o * D + k] * probe[k];
+      q[o] = (float)(acc * sc);
+    }
+    TRY(dev_upload<float>(e, q, &e->head_q));
+    std::vector<float> wkv(w.begin() + (size_t)D * D, w.end());
+    std::vector<float> bkv(b.begin() + D, b.end());
+    TRY(upload_linear(e, wkv, &bkv, 2 * D, D, &e->head_kv));
+  }
+  TRY(upload_linear(e, H("head.attention.out_proj.weight"), Hopt("head.attention.out_proj.bias"), D, D, &e->head_out));
+  TRY(upload_linear(e, H("head.mlp.fc1.weight"), Hopt("head.mlp.fc1.bias"), I, D, &e->head_fc1));
+  TRY(upload_linear(e, H("head.mlp.fc2.weight"), Hopt("head.mlp.fc2.bias"), D, I, &e->head_fc2));
+#undef TRY
+  e->finalized = true;
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Workspace {
+  float* resid; float* te_rows;
+  bf16_t *xn_hi, *xn_lo, *ctx_hi, *ctx_lo, *tmp_hi, *tmp_lo, *mid_hi, *mid_lo;
+  void* qkv;          // spatial qkv / head kv; fast: bf16 [M,3D], accurate: fp32 [M,3D]
+  void* tqkv;         // temporal qkv of the current layer when no cache is used
+  float* attn_out;    // head: [F, D]
+  bf16_t *pc_hi, *pc_lo, *hn_hi, *hn_lo, *hm_hi, *hm_lo;
+  size_t bytes;
+};
+
+static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, bool need_tqkv) {
+  Workspace w;
+  Carver c(base);
+  const size_t M = (size_t)B * T * N, F = (size_t)B * T;
+  const size_t D = e->D, I = e->I;
+  const bool acc = e->compute == SF_COMPUTE_BF16X3;
+  const size_t wide = D > (size_t)e->Kp ? D : (size_t)e->Kp;
+  w.resid = c.take<float>(M * D);
+  w.te_rows = c.take<float>((size_t)T * D);
+  w.xn_hi = c.take<bf16_t>(M * wide);
+  w.xn_lo = acc ? c.take<bf16_t>(M * wide) : nullptr;
+  w.ctx_hi = c.take<bf16_t>(M * D);
+  w.ctx_lo = acc ? c.take<bf16_t>(M * D) : nullptr;
+  if (!e->fused_temporal) {
+    w.tmp_hi = c.take<bf16_t>(M * D);
+    w.tmp_lo = acc ? c.take<bf16_t>(M * D) : nullptr;
+  } else {
+    w.tmp_hi = w.tmp_lo = nullptr;
+  }
+  w.mid_hi = c.take<bf16_t>(M * I);
+  w.mid_lo = acc ? c.take<bf16_t>(M * I) : nullptr;
+  w.qkv = c.take<char>(M * 3 * D * (acc ? 4 : 2));
+  w.tqkv = need_tqkv ? (void*)c.take<char>(M * 3 * D * (acc ? 4 : 2)) : nullptr;
+  w.attn_out = c.take<float>(F * D);
+  w.pc_hi = c.take<bf16_t>(F * D);
+  w.pc_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
+  w.hn_hi = c.take<bf16_t>(F * D);
+  w.hn_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
+  w.hm_hi = c.take<bf16_t>(F * I);
+  w.hm_lo = acc ? c.take<bf16_t>(F * I) : nullptr;
+  w.bytes = (c.off + 255) & ~(size_t)255;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the launch schedule
+// ------------------------------------------------------------------------------------------------
+static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf16_t* a_hi, const bf16_t* a_lo,
+                             int M, int epi, hipStream_t s, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
+                             const float* resid = nullptr, float alpha = 1.f, int ldc = 0, int grp_rows = 0,
+                             int grp_stride = 0, int grp_off = 0) {
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  const bool split = e->compute == SF_COMPUTE_BF16X3;
+  g.a_hi = a_hi; g.a_lo = split ? a_lo : nullptr;
+  g.w_hi = lin.w_hi; g.w_lo = split ? lin.w_lo : nullptr;
+  g.bias = lin.bias;
+  g.M = M; g.N = lin.N; g.K = lin.K;
+  g.epi = epi; g.act = e->cfg.hidden_act; g.alpha = alpha; g.resid = resid;
+  g.out_f32 = out_f32; g.out_hi = out_hi; g.out_lo = split ? out_lo : nullptr;
+  g.ldc = ldc ? ldc : lin.N;
+  g.grp_rows = grp_rows; g.grp_stride = grp_stride; g.grp_off = grp_off;
+  return sf_launch_gemm(g, split, s);
+}
+
+static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfRowIndex* idx) {
+  const int nf = e->cfg.num_frames;
+  if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per call (got %d)", T);
+  idx->n = T;
+  if (streaming) {
+    // vqa_enc:328-369: direct rows; the reference raises past num_frames rows
+    if (t_past + T > nf)
+      return set_err(SF_ERR_CAPACITY, "streaming needs time-embedding row %d but config.num_frames is %d", t_past + T - 1, nf);
+    for (int t = 0; t < T; ++t) idx->idx[t] = t_past + t;
+  } else if (T <= nf) {
+    for (int t = 0; t < T; ++t) idx->idx[t] = t;          // modeling:436-439 slice
+  } else {
+    // F.interpolate(mode="nearest") (modeling:441-447): src = floor(dst * scale), scale = float(in)/out
+    const float scale = (float)nf / (float)T;
+    for (int t = 0; t < T; ++t) {
+      int src = (int)floorf((float)t * scale);
+      idx->idx[t] = src < nf - 1 ? src : nf - 1;
+    }
+  }
+  return SF_OK;
+}
+
+// One call of the encoder over T new frames.  tq = per-layer temporal qkv buffers ([B,cap,N,3D]).
+static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
+                       float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
+                       const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
+                       hipStream_t s) {
+  const sf_config& c = e->cfg;
+  const int P = c.patch_size, D = e->D, heads = c.num_attention_heads;
+  const int N = (H / P) * (W / P);
+  const int M = B * T * N, F = B * T;
+  const bool acc = e->compute == SF_COMPUTE_BF16X3;
+  const int qkv_epi = acc ? SF_EPI_F32 : SF_EPI_BF16;
+  const size_t esz = acc ? 4 : 2;
+  const float scale = 1.0f / sqrtf(64.0f);
+
+  SfRowIndex idx;
+  int rc = time_rows(e, t_past, T, streaming, &idx);
+  if (rc) return rc;
+  HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s));
+  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_BF16, ws.xn_hi, ws.xn_lo, F, c.num_channels, H, W, P, s));
+  {
+    SfGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a_hi = ws.xn_hi; g.a_lo = acc ? ws.xn_lo : nullptr;
+    g.w_hi = e->patch.w_hi; g.w_lo = acc ? e->patch.w_lo : nullptr;
+    g.bias = e->patch.bias;
+    g.M = M; g.N = D; g.K = e->Kp;
+    g.epi = SF_EPI_EMBED_F32;
+    g.pos = pos_dev ? pos_dev : e->pos; g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
+    g.out_f32 = ws.resid; g.ldc = D;
+    HIP_TRY(sf_launch_gemm(g, acc, s));
+  }
+  const size_t hs_stride = (size_t)M * D;
+  for (int li = 0; li < e->L; ++li) {
+    const DevLayer& l = e->layers[li];
+    if (hidden_states)
+      HIP_TRY(hipMemcpyAsync(hidden_states + li * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
+    // ---- temporal attention (modeling:937-958) ---------------------------------------------------
+    HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_t.g, l.ln_t.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    void* tq = layer_tqkv ? layer_tqkv[li] : ws.tqkv;
+    HIP_TRY(run_linear(e, l.t_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)tq, (bf16_t*)tq, nullptr, nullptr, 1.f,
+                       3 * D, T * N, cap * N, t_past * N));
+    {
+      SfAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = tq; a.k = (char*)tq + (size_t)D * esz; a.v = (char*)tq + (size_t)2 * D * esz;
+      a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.N = N; a.B = B; a.Tq = T; a.Tk = t_past + T; a.Tcap = cap; a.t_past = t_past;
+      a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = t_past;
+      a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
+      HIP_TRY(sf_launch_temporal_attention(a, acc, s));
+    }
+    if (e->fused_temporal) {
+      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, l.gate_tanh));
+    } else {
+      HIP_TRY(run_linear(e, l.t_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_BF16, s, nullptr, ws.tmp_hi, ws.tmp_lo));
+      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, l.gate_tanh));
+    }
+    // ---- spatial attention (modeling:962-996) ------------------------------------------------------
+    HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, l.s_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
+    {
+      SfAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = ws.qkv; a.k = (char*)ws.qkv + (size_t)D * esz; a.v = (char*)ws.qkv + (size_t)2 * D * esz;
+      a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
+      HIP_TRY(sf_launch_spatial_attention(a, acc, s));
+    }
+    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, 1.f));
+    // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
+    HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, l.up, ws.xn_hi, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo));
+    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, 1.f));
+  }
+  if (hidden_states)
+    HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
+  // ---- post LayerNorm + pooling head (modeling:1330-1340, 1141-1154) -------------------------------
+  HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+  if (pooler) {
+    HIP_TRY(run_linear(e, e->head_kv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
+    HIP_TRY(sf_launch_pool_attention(e->head_q, ws.qkv, acc, 2 * D, ws.pc_hi, ws.pc_lo, F, N, heads, D, s));
+    HIP_TRY(run_linear(e, e->head_out, ws.pc_hi, ws.pc_lo, F, SF_EPI_F32, s, ws.attn_out, nullptr, nullptr));
+    HIP_TRY(sf_launch_layernorm(ws.attn_out, e->head_ln.g, e->head_ln.b, nullptr, ws.hn_hi, ws.hn_lo, F, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, e->head_fc1, ws.hn_hi, ws.hn_lo, F, SF_EPI_ACT_BF16, s, nullptr, ws.hm_hi, ws.hm_lo));
+    HIP_TRY(run_linear(e, e->head_fc2, ws.hm_hi, ws.hm_lo, F, SF_EPI_RESID_F32, s, pooler, nullptr, nullptr, ws.attn_out, 1.f));
+  }
+  return SF_OK;
+}
+
+static int check_geometry(const sf_encoder* e, int B, int T, int H, int W, const float* pos_dev, int* N_out) {
+  if (!e) return set_err(SF_ERR_INVALID, "null handle");
+  const int P = e->cfg.patch_size;
+  if (B <= 0 || T <= 0 || H < P || W < P) return set_err(SF_ERR_INVALID, "bad geometry B=%d T=%d H=%d W=%d", B, T, H, W);
+  const int N = (H / P) * (W / P);
+  if (N > 224) return set_err(SF_ERR_INVALID, "%d patches per frame; the spatial attention kernel handles <= 224", N);
+  if (!pos_dev && !(N == e->N && H == W))
+    return set_err(SF_ERR_INVALID, "input %dx%d differs from image_size %d: pass a resized position table (pos_dev)", H, W, e->cfg.image_size);
+  if ((size_t)B * T * N > (size_t)1 << 30) return set_err(SF_ERR_INVALID, "too many token rows");
+  *N_out = N;
+  return SF_OK;
+}
+
+extern "C" int sf_workspace_bytes(sf_encoder* e, int B, int T, int H, int W, size_t* out) {
+  int N;
+  const float* dummy = (const float*)1;
+  int rc = check_geometry(e, B, T, H, W, dummy, &N);
+  if (rc) return rc;
+  if (!out) return set_err(SF_ERR_INVALID, "null out");
+  if (!e->finalized) return set_err(SF_ERR_STATE, "sf_finalize_weights has not run");
+  *out = carve(e, nullptr, B, T, N, true).bytes;
+  return SF_OK;
+}
+
+extern "C" int sf_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
+                          float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
+                          void* workspace, size_t workspace_bytes, sf_stream stream) {
+  int N;
+  int rc = check_geometry(e, B, T, H, W, pos_dev, &N);
+  if (rc) return rc;
+  if (!e->finalized) return set_err(SF_ERR_STATE, "sf_finalize_weights has not run");
+  if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
+  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16) return set_err(SF_ERR_INVALID, "pixels must be fp32 or bf16");
+  if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per clip");
+  Workspace ws = carve(e, workspace, B, T, N, true);
+  if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
+  return run_forward(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, pos_dev, ws, nullptr, T, 0,
+                     false, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_cache_create(sf_encoder* e, int B, int max_frames, int H, int W, sf_cache** out) {
+  int N;
+  const float* dummy = (const float*)1;
+  int rc = check_geometry(e, B, 1, H, W, dummy, &N);
+  if (rc) return rc;
+  if (!out || max_frames <= 0 || max_frames > 256) return set_err(SF_ERR_INVALID, "max_frames must be in 1..256");
+  if (!e->finalized) return set_err(SF_ERR_STATE, "sf_finalize_weights has not run");
+  HIP_TRY(hipSetDevice(e->device));
+  sf_cache* c = new sf_cache();
+  c->enc = e; c->B = B; c->cap = max_frames; c->H = H; c->W = W; c->N = N;
+  const size_t per = (size_t)B * max_frames * N * 3 * e->D * (e->compute == SF_COMPUTE_BF16X3 ? 4 : 2);
+  for (int i = 0; i < e->L; ++i) {
+    void* p = nullptr;
+    hipError_t err = hipMalloc(&p, per);
+    if (err != hipSuccess) {
+      for (void* q : c->qkv) (void)hipFree(q);
+      delete c;
+      return set_err(SF_ERR_HIP, "hipMalloc(%zu) for the KV-cache: %s", per, hipGetErrorString(err));
+    }
+    c->qkv.push_back(p);
+  }
+  c->bytes = per * e->L;
+  *out = c;
+  return SF_OK;
+}
+extern "C" int sf_cache_reset(sf_cache* c) {
+  if (!c) return set_err(SF_ERR_INVALID, "null cache");
+  c->len = 0;
+  return SF_OK;
+}
+extern "C" int sf_cache_length(const sf_cache* c) { return c ? c->len : 0; }
+extern "C" size_t sf_cache_bytes(const sf_cache* c) { return c ? c->bytes : 0; }
+extern "C" void sf_cache_destroy(sf_cache* c) {
+  if (!c) return;
+  for (void* q : c->qkv) (void)hipFree(q);
+  delete c;
+}
+extern "C" int sf_stream_workspace_bytes(sf_encoder* e, const sf_cache* c, int T_new, size_t* out) {
+  if (!e || !c || !out || T_new <= 0) return set_err(SF_ERR_INVALID, "bad argument");
+  *out = carve(e, nullptr, c->B, T_new, c->N, false).bytes;
+  return SF_OK;
+}
+extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels, int pixel_dtype, int T_new,
+                                 float* last_hidden, float* pooler, const float* pos_dev, void* workspace,
+                                 size_t workspace_bytes, sf_stream stream) {
+  if (!e || !c || c->enc != e) return set_err(SF_ERR_INVALID, "cache does not belong to this encoder");
+  int N;
+  int rc = check_geometry(e, c->B, T_new, c->H, c->W, pos_dev, &N);
+  if (rc) return rc;
+  if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
+  if (c->len + T_new > c->cap)
+    return set_err(SF_ERR_CAPACITY, "cache holds %d of %d frames; %d more do not fit", c->len, c->cap, T_new);
+  Workspace ws = carve(e, workspace, c->B, T_new, N, false);
+  if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
+  rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws,
+                   c->qkv.data(), c->cap, c->len, true, (hipStream_t)stream);
+  if (rc == SF_OK) c->len += T_new;
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single operators (parity tests)
+// ------------------------------------------------------------------------------------------------
+__global__ void sf_combine_kernel(const bf16_t* hi, const bf16_t* lo, float* out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = bf2f(hi[i]) + (lo ? bf2f(lo[i]) : 0.f);
+}
+
+extern "C" int sf_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int D,
+                               float eps, sf_stream stream) {
+  HIP_TRY(sf_launch_layernorm(x, gamma, beta, y, nullptr, nullptr, rows, D, eps, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" size_t sf_op_linear_workspace_bytes(int M, int N, int K) {
+  return ((size_t)M * K * 2 + (size_t)N * K * 2 + (size_t)M * N * 2) * 2 + 4096;
+}
+
+extern "C" int sf_op_linear(const float* x, const float* w, const float* b, const float* resid, float alpha, int gelu,
+                            float* y, int M, int N, int K, int compute, void* workspace, size_t workspace_bytes,
+                            sf_stream stream) {
+  if (workspace_bytes < sf_op_linear_workspace_bytes(M, N, K)) return set_err(SF_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const bool split = compute == SF_COMPUTE_BF16X3;
+  Carver c(workspace);
+  bf16_t* xh = c.take<bf16_t>((size_t)M * K); bf16_t* xl = c.take<bf16_t>((size_t)M * K);
+  bf16_t* wh = c.take<bf16_t>((size_t)N * K); bf16_t* wl = c.take<bf16_t>((size_t)N * K);
+  bf16_t* oh = c.take<bf16_t>((size_t)M * N); bf16_t* ol = c.take<bf16_t>((size_t)M * N);
+  HIP_TRY(sf_launch_split(x, xh, split ? xl : nullptr, (size_t)M * K, s));
+  HIP_TRY(sf_launch_split(w, wh, split ? wl : nullptr, (size_t)N * K, s));
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = xh; g.a_lo = split ? xl : nullptr; g.w_hi = wh; g.w_lo = split ? wl : nullptr; g.bias = b;
+  g.M = M; g.N = N; g.K = K; g.ldc = N; g.alpha = alpha; g.resid = resid; g.act = 0;
+  if (gelu) {
+    g.epi = SF_EPI_ACT_BF16; g.out_hi = oh; g.out_lo = split ? ol : nullptr;
+    HIP_TRY(sf_launch_gemm(g, split, s));
+    hipLaunchKernelGGL(sf_combine_kernel, dim3(1024), dim3(256), 0, s, oh, split ? ol : nullptr, y, (size_t)M * N);
+    HIP_TRY(hipGetLastError());
+  } else {
+    g.epi = resid ? SF_EPI_RESID_F32 : SF_EPI_F32; g.out_f32 = y;
+    HIP_TRY(sf_launch_gemm(g, split, s));
+  }
+  return SF_OK;
+}
+
+extern "C" size_t sf_op_attention_workspace_bytes(int groups, int L, int heads, int head_dim) {
+  const size_t rows = (size_t)groups * L, D = (size_t)heads * head_dim;
+  return rows * 3 * D * 2 + rows * D * 2 * 2 + 4096;
+}
+
+extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, int heads, int head_dim, int causal,
+                               int temporal_layout, int N_tokens, int compute, void* workspace, size_t workspace_bytes,
+                               sf_stream stream) {
+  if (head_dim != 64) return set_err(SF_ERR_INVALID, "head_dim must be 64");
+  if (workspace_bytes < sf_op_attention_workspace_bytes(groups, L, heads, head_dim)) return set_err(SF_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const bool acc = compute == SF_COMPUTE_BF16X3;
+  const int D = heads * head_dim;
+  const size_t rows = (size_t)groups * L;
+  Carver c(workspace);
+  bf16_t* qb = c.take<bf16_t>(rows * 3 * D);
+  bf16_t* ch = c.take<bf16_t>(rows * D);
+  bf16_t* cl = c.take<bf16_t>(rows * D);
+  const void* base = qkv;
+  size_t esz = 4;
+  if (!acc) {
+    HIP_TRY(sf_launch_split(qkv, qb, nullptr, rows * 3 * D, s));
+    base = qb;
+    esz = 2;
+  }
+  SfAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = base; a.k = (const char*)base + (size_t)D * esz; a.v = (const char*)base + (size_t)2 * D * esz;
+  a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 1.0f / sqrtf((float)head_dim);
+  a.ctx_hi = ch; a.ctx_lo = cl; a.D = D;
+  if (temporal_layout) {
+    // rows are [B, L, N_tokens, 3D] with groups = B * N_tokens sequences of length L
+    if (N_tokens <= 0 || groups % N_tokens) return set_err(SF_ERR_INVALID, "groups must be a multiple of N_tokens");
+    a.N = N_tokens; a.B = groups / N_tokens; a.Tq = L; a.Tk = L; a.Tcap = L; a.t_past = 0; a.causal = causal;
+    a.Tq_cap = L; a.q_t0 = 0;
+    HIP_TRY(sf_launch_temporal_attention(a, acc, s));
+  } else {
+    if (causal) return set_err(SF_ERR_INVALID, "the spatial layout has no causal variant");
+    a.N = L; a.frames = groups;
+    HIP_TRY(sf_launch_spatial_attention(a, acc, s));
+  }
+  hipLaunchKernelGGL(sf_combine_kernel, dim3(1024), dim3(256), 0, s, ch, acc ? cl : nullptr, ctx, rows * D);
+  HIP_TRY(hipGetLastError());
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss heads
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_retrieval_loss(const float* pooler, const float* text, int B, int T, int D, int Bt, int pos_offset,
+                                 float logit_scale, float logit_bias, float* loss, float* grad_pooler,
+                                 float* grad_scalars, sf_stream stream) {
+  if (!pooler || !text || !loss) return set_err(SF_ERR_INVALID, "null buffer");
+  HIP_TRY(sf_launch_retrieval_loss(pooler, text, B, T, D, Bt, pos_offset, logit_scale, logit_bias, loss, grad_pooler,
+                                   grad_scalars, (hipStream_t)stream));
+  return SF_OK;
+}
+extern "C" int sf_localization_loss(const float* pooler, const float* label_emb, const int32_t* labels, int B, int T,
+                                    int D, int L, float logit_scale, float logit_bias, float* loss, float* grad_pooler,
+                                    float* grad_scalars, sf_stream stream) {
+  if (!pooler || !label_emb || !labels || !loss) return set_err(SF_ERR_INVALID, "null buffer");
+  HIP_TRY(sf_launch_localization_loss(pooler, label_emb, labels, B, T, D, L, logit_scale, logit_bias, loss, grad_pooler,
+                                      grad_scalars, (hipStream_t)stream));
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bench hook: time the dominant GEMM with HIP events on the caller's stream
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* workspace, size_t workspace_bytes,
+                             sf_stream stream, float* mean_ms_out, double* flops_out) {
+  if (!e || !e->finalized || e->layers.empty()) return set_err(SF_ERR_STATE, "encoder not finalized");
+  if (iters <= 0 || M <= 0 || !workspace || !mean_ms_out) return set_err(SF_ERR_INVALID, "bad argument");
+  const DevLayer& l = e->layers[0];
+  const DevLinear* lin = which == 0 ? &l.up : which == 1 ? &l.down : which == 2 ? &l.s_qkv : &l.s_out;
+  const bool acc = e->compute == SF_COMPUTE_BF16X3;
+  Carver c(workspace);
+  bf16_t* ah = c.take<bf16_t>((size_t)M * lin->K);
+  bf16_t* al = c.take<bf16_t>((size_t)M * lin->K);
+  bf16_t* oh = c.take<bf16_t>((size_t)M * lin->N);
+  bf16_t* ol = c.take<bf16_t>((size_t)M * lin->N);
+  float* of = c.take<float>((size_t)M * lin->N);
+  if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
+  hipStream_t s = (hipStream_t)stream;
+  const int epi = which == 0 ? SF_EPI_ACT_BF16 : which == 2 ? (acc ? SF_EPI_F32 : SF_EPI_BF16) : SF_EPI_RESID_F32;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(run_linear(e, *lin, ah, al, M, epi, s, of, oh, ol, of, 0.f));   // warm
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIP_TRY(run_linear(e, *lin, ah, al, M, epi, s, of, oh, ol, of, 0.f));
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mean_ms_out = ms / iters;
+  if (flops_out) *flops_out = 2.0 * M * (double)lin->N * (double)lin->K;
+  return SF_OK;
+}

@@ -1,0 +1,176 @@
+// Row-wise and elementwise kernels of the encoder path: LayerNorm (reference modeling:860-865,
+// 878-880, 1251, 1138), patch extraction for the conv-as-GEMM patch embedding (modeling:329-350),
+// operand splitting for the bf16x3 mode, and time-embedding row selection (modeling:435-450).
+// All of them are HBM-bound: one wave per row, 16-byte vector accesses, wave-shuffle reductions.
+#include "sf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row lives in registers (D <= 64*4*MAXV), two-pass statistics.
+// ------------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ y_f32,
+                                                           bf16_t* __restrict__ y_hi,
+                                                           bf16_t* __restrict__ y_lo, int rows, int D,
+                                                           float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = D >> 2;                       // float4 per row
+  const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D);
+  f32x4_t v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      v[i] = xr[c];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      const f32x4_t g = reinterpret_cast<const f32x4_t*>(gamma)[c];
+      const f32x4_t b = reinterpret_cast<const f32x4_t*>(beta)[c];
+      f32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      const size_t off = (size_t)row * D + (size_t)c * 4;
+      if (y_f32) *reinterpret_cast<f32x4_t*>(y_f32 + off) = o;
+      if (y_hi) {
+        unsigned int h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_bf(o[j], h[j], l[j]);
+        *reinterpret_cast<u32x2_t*>(y_hi + off) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        if (y_lo) *reinterpret_cast<u32x2_t*>(y_lo + off) = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+      }
+    }
+  }
+}
+
+hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
+                               bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (D % 4 || D > 64 * 4 * 16) return hipErrorInvalidValue;
+  const dim3 grid((rows + 3) / 4), block(256);
+  const int nv = (D / 4 + 63) / 64;
+  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
+  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
+  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
+  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// patchify: pixels [F,C,H,W] -> A[F*N, C*P*P] (bf16 hi/lo), column = (c*P + ph)*P + pw,
+// patch n = prow*(W/P) + pcol.  One thread moves 8 consecutive pw pixels (16 B of bf16 out).
+// ------------------------------------------------------------------------------------------------
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict__ pixels,
+                                                          bf16_t* __restrict__ out_hi,
+                                                          bf16_t* __restrict__ out_lo, int F, int C, int H,
+                                                          int W, int P, int gh, int gw) {
+  const int Kp = C * P * P;
+  const int chunks_per_row = Kp >> 3;
+  const size_t total = (size_t)F * gh * gw * chunks_per_row;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % chunks_per_row);
+    const size_t prow = i / chunks_per_row;          // global patch row = f*N + n
+    const int n = (int)(prow % (gh * gw));
+    const int f = (int)(prow / (gh * gw));
+    const int col = ck << 3;
+    const int c = col / (P * P), rem = col % (P * P);
+    const int ph = rem / P, pw = rem % P;
+    const int y = (n / gw) * P + ph, x0 = (n % gw) * P + pw;
+    const size_t src = (((size_t)f * C + c) * H + y) * W + x0;
+    float v[8];
+    if (IN_BF16) {
+      const bf16_t* pp = reinterpret_cast<const bf16_t*>(pixels) + src;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = bf2f(pp[j]);
+    } else {
+      const float* pp = reinterpret_cast<const float*>(pixels) + src;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = pp[j];
+    }
+    unsigned int h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf(v[j], h[j], l[j]);
+    const size_t o = prow * Kp + col;
+    *reinterpret_cast<u32x4_t*>(out_hi + o) =
+        (u32x4_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    if (out_lo)
+      *reinterpret_cast<u32x4_t*>(out_lo + o) =
+          (u32x4_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+  }
+}
+
+hipError_t sf_launch_patchify(const void* pixels, int pixel_is_bf16, bf16_t* out_hi, bf16_t* out_lo,
+                              int F, int C, int H, int W, int P, hipStream_t s) {
+  if (P % 8) return hipErrorInvalidValue;
+  const int gh = H / P, gw = W / P;
+  const size_t total = (size_t)F * gh * gw * (C * P * P / 8);
+  if (!total) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (pixel_is_bf16)
+    hipLaunchKernelGGL(sf_patchify_kernel<true>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw);
+  else
+    hipLaunchKernelGGL(sf_patchify_kernel<false>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_split_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi,
+                                                       bf16_t* __restrict__ lo, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4_t v = reinterpret_cast<const f32x4_t*>(x)[i];
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf(v[j], h[j], l[j]);
+    reinterpret_cast<u32x2_t*>(hi)[i] = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    if (lo) reinterpret_cast<u32x2_t*>(lo)[i] = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+  }
+}
+
+hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s) {
+  if (n % 4) return hipErrorInvalidValue;
+  if (!n) return hipSuccess;
+  const size_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(sf_split_kernel, dim3(blocks), dim3(256), 0, s, x, hi, lo, n4);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_gather_rows_kernel(const float* __restrict__ table,
+                                                             float* __restrict__ out, SfRowIndex idx, int D) {
+  const int t = blockIdx.x;
+  const float* src = table + (size_t)idx.idx[t] * D;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) out[(size_t)t * D + i] = src[i];
+}
+
+hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s) {
+  if (idx.n <= 0 || idx.n > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_gather_rows_kernel, dim3(idx.n), dim3(256), 0, s, table, out, idx, D);
+  return hipGetLastError();
+}

@@ -1,0 +1,362 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's golden
+outputs.  Tolerances (max-abs), stated once:
+
+  * fp32-accurate mode (bf16x3 products): last_hidden_state <= 1e-3 (north_star bound), pooler <= 1e-3;
+    measured values are ~1e-4 and the tests also assert a 5e-4 ceiling so regressions show early.
+  * bf16 throughput mode: last_hidden_state <= 6e-2, pooler <= 3e-2 — the error floor of bf16 operands
+    the reference itself shows in pure bf16 (0.08-0.11 / 0.012); cosine >= 0.9995.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import streamformer_oracle as O
+from streamformer_amd.configuration import siglip_base
+from streamformer_amd.init_weights import make_state_dict
+from tests.helpers import frames, load_npz, maxabs, small_cfg
+
+pytestmark = pytest.mark.gpu
+
+ACC_TOL = 1e-3
+ACC_CEIL = 5e-4
+BF16_LHS, BF16_POOL = 6e-2, 3e-2
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import streamformer_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return streamformer_amd
+
+
+def build(sa, cfg, sd, mode, fuse=True):
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode, fuse_temporal_proj=fuse)
+    m.load_state_dict(sd)
+    return m.to("cuda").eval()
+
+
+def cosine(a, b):
+    a, b = a.double().flatten().cpu(), torch.as_tensor(np.asarray(b)).double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()))
+
+
+# ------------------------------------------------------------------------------------------------
+# single operators
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,D", [(1, 128), (37, 768), (1000, 768), (5, 1024), (3, 2048)])
+def test_op_layernorm(sa, rows, D):
+    nat = sa._native
+    g = torch.Generator().manual_seed(rows * 7 + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    w = torch.randn(D, generator=g) * 0.1 + 1
+    b = torch.randn(D, generator=g) * 0.1
+    want = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y = torch.empty_like(xd)
+    nat.check(nat.lib.sf_op_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, D, 1e-6,
+                                      nat.current_stream_handle(xd.device)))
+    torch.cuda.synchronize()
+    assert maxabs(y, want) <= 5e-6
+
+
+def _linear(sa, x, w, b, resid, alpha, gelu, mode):
+    nat = sa._native
+    M, K = x.shape
+    N = w.shape[0]
+    xd, wd = x.cuda(), w.cuda()
+    bd = b.cuda() if b is not None else None
+    rd = resid.cuda() if resid is not None else None
+    y = torch.empty(M, N, device="cuda")
+    nb = nat.lib.sf_op_linear_workspace_bytes(M, N, K)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    nat.check(nat.lib.sf_op_linear(xd.data_ptr(), wd.data_ptr(), nat.ptr(bd), nat.ptr(rd), alpha, int(gelu), y.data_ptr(),
+                                   M, N, K, mode, ws.data_ptr(), nb, nat.current_stream_handle(y.device)))
+    torch.cuda.synchronize()
+    return y.cpu()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1, 768, 768), (333, 2304, 768), (129, 768, 3072)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_op_linear(sa, M, N, K, mode):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5       # asymmetric, non-square: catches transposes
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 2e-5 * K ** 0.5 if mode == 1 else 2e-2
+    if mode == 0:   # compare against the same operand rounding so the bound is tight
+        ref = x.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+        tol = 1e-4
+    assert maxabs(_linear(sa, x, w, b, None, 1.0, False, mode), ref) <= tol
+    assert maxabs(_linear(sa, x, w, b, r, 0.37, False, mode), r.double() + 0.37 * ref) <= tol
+    got = _linear(sa, x, w, b, None, 1.0, True, mode)
+    want = torch.nn.functional.gelu(ref)
+    assert maxabs(got, want) <= (tol + (1e-5 if mode else 2e-2))   # bf16 output rounding in mode 0
+
+
+def _attention(sa, qkv, groups, L, heads, causal, temporal, ntok, mode):
+    nat = sa._native
+    D = heads * 64
+    q = qkv.cuda().contiguous()
+    ctx = torch.empty(groups * L, D, device="cuda")
+    nb = nat.lib.sf_op_attention_workspace_bytes(groups, L, heads, 64)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    nat.check(nat.lib.sf_op_attention(q.data_ptr(), ctx.data_ptr(), groups, L, heads, 64, int(causal), int(temporal), ntok,
+                                      mode, ws.data_ptr(), nb, nat.current_stream_handle(q.device)))
+    torch.cuda.synchronize()
+    return ctx.cpu()
+
+
+def _attn_ref(qkv, heads, mask=None):
+    D = qkv.shape[-1] // 3
+    q, k, v = qkv.double().split(D, dim=-1)
+    return O._mha(q, k, v, heads, mask)[0]
+
+
+@pytest.mark.parametrize("frames_,N,heads", [(3, 196, 12), (2, 9, 2), (1, 33, 1), (2, 224, 2), (4, 1, 2), (2, 16, 3)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_op_spatial_attention(sa, frames_, N, heads, mode):
+    g = torch.Generator().manual_seed(N * 13 + heads)
+    qkv = torch.randn(frames_, N, 3 * heads * 64, generator=g) * 1.5
+    qkv[..., 5] += 6.0                                   # a spiky column: exercises the max-subtraction
+    src = qkv if mode == 1 else qkv.bfloat16().float()
+    want = _attn_ref(src, heads).reshape(frames_ * N, -1)
+    got = _attention(sa, qkv.reshape(frames_ * N, -1), frames_, N, heads, False, False, 0, mode)
+    assert maxabs(got, want) <= (2e-4 if mode == 1 else 3e-2)
+
+
+@pytest.mark.parametrize("B,L,Nt,heads,causal", [(2, 16, 9, 2, 1), (1, 5, 4, 12, 1), (1, 1, 3, 2, 1), (1, 64, 2, 2, 1),
+                                                  (2, 16, 5, 3, 0), (1, 33, 2, 1, 1), (1, 100, 1, 2, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_op_temporal_attention(sa, B, L, Nt, heads, causal, mode):
+    g = torch.Generator().manual_seed(L * 17 + Nt)
+    D = heads * 64
+    qkv = torch.randn(B, L, Nt, 3 * D, generator=g) * 1.5          # the encoder's [B,T,N,3D] layout
+    src = qkv if mode == 1 else qkv.bfloat16().float()
+    seq = src.permute(0, 2, 1, 3).reshape(B * Nt, L, 3 * D)
+    mask = torch.tril(torch.ones(L, L, dtype=torch.bool)) if causal else None
+    want = _attn_ref(seq, heads, mask).reshape(B, Nt, L, D).permute(0, 2, 1, 3).reshape(B * L * Nt, D)
+    got = _attention(sa, qkv.reshape(B * L * Nt, 3 * D), B * Nt, L, heads, causal, True, Nt, mode)
+    assert maxabs(got, want) <= (2e-4 if mode == 1 else 3e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole forward, small config (golden F1/F5/F7 + oracle)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_forward_small_vs_golden(sa, golden_dir, mode, fuse):
+    g = load_npz(os.path.join(golden_dir, "f1_small.npz"))
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=1)
+    m = build(sa, cfg, sd, mode, fuse)
+    for T in (1, 5, 16):
+        x = frames(100 + T, (2, T, 3, 48, 48))
+        out = m(x.cuda(), output_hidden_states=True)
+        torch.cuda.synchronize()
+        lt, pt = (ACC_CEIL, ACC_CEIL) if mode == "fp32" else (BF16_LHS, BF16_POOL)
+        assert out.last_hidden_state.shape == (2, T, 9, 128) and out.pooler_output.shape == (2, T, 128)
+        assert maxabs(out.last_hidden_state, g[f"T{T}_last_hidden_state"]) <= lt
+        assert maxabs(out.pooler_output, g[f"T{T}_pooler_output"]) <= pt
+        hs = torch.stack([h.cpu() for h in out.hidden_states])            # patch-major like the reference
+        assert hs.shape == (3, 2, 9 * T, 128)
+        assert maxabs(hs, g[f"T{T}_hidden_states"]) <= (ACC_CEIL if mode == "fp32" else 0.15)
+        tup = m(x.cuda(), return_dict=False)
+        assert isinstance(tup, tuple) and torch.equal(tup[0], out.last_hidden_state)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_forward_shapes_f7(sa, golden_dir, mode):
+    g = load_npz(os.path.join(golden_dir, "f7_shapes.npz"))
+    cfg = small_cfg()
+    m = build(sa, cfg, make_state_dict(cfg, seed=1), mode)
+    lt, pt = (ACC_CEIL, ACC_CEIL) if mode == "fp32" else (BF16_LHS, BF16_POOL)
+    for T in (8, 32):
+        out = m(frames(200 + T, (1, T, 3, 48, 48)).cuda())
+        assert maxabs(out.last_hidden_state, g[f"T{T}_last_hidden_state"]) <= lt
+        assert maxabs(out.pooler_output, g[f"T{T}_pooler_output"]) <= pt
+    out = m(frames(299, (1, 4, 3, 32, 64)).cuda())                        # resized position table
+    assert maxabs(out.last_hidden_state, g["rect_last_hidden_state"]) <= lt
+    assert maxabs(out.pooler_output, g["rect_pooler_output"]) <= pt
+    cfg_bi = small_cfg(enable_causal_temporal=False)
+    m2 = build(sa, cfg_bi, make_state_dict(cfg_bi, seed=2), mode)
+    out = m2(frames(300, (2, 16, 3, 48, 48)).cuda())
+    assert maxabs(out.last_hidden_state, g["bi_last_hidden_state"]) <= lt
+    assert maxabs(out.pooler_output, g["bi_pooler_output"]) <= pt
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_forward_lora_f5(sa, golden_dir, mode):
+    g = load_npz(os.path.join(golden_dir, "f5_lora.npz"))
+    cfg = small_cfg(add_lora_spatial=True)
+    m = build(sa, cfg, make_state_dict(cfg, seed=3), mode)
+    out = m(frames(400, (2, 16, 3, 48, 48)).cuda())
+    lt, pt = (ACC_CEIL, ACC_CEIL) if mode == "fp32" else (BF16_LHS, BF16_POOL)
+    assert maxabs(out.last_hidden_state, g["last_hidden_state"]) <= lt
+    assert maxabs(out.pooler_output, g["pooler_output"]) <= pt
+
+
+def test_causal_property_hip(sa):
+    cfg = small_cfg()
+    m = build(sa, cfg, make_state_dict(cfg, seed=1), "bf16")
+    x = frames(7, (1, 16, 3, 48, 48))
+    x2 = x.clone()
+    x2[:, 9:] += 1.0
+    a = m(x.cuda()).last_hidden_state
+    b = m(x2.cuda()).last_hidden_state
+    assert torch.equal(a[:, :9], b[:, :9]), "frames < 9 must not see frames >= 9 (bit-exact)"
+    assert not torch.equal(a[:, 9:], b[:, 9:])
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming with the KV-cache (golden F4)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag,nf", [("nf16", 16), ("nf64", 64)])
+def test_streaming_f4(sa, golden_dir, mode, tag, nf):
+    g = load_npz(os.path.join(golden_dir, "f4_streaming.npz"))
+    cfg = small_cfg(num_frames=nf, add_lora_spatial=True)
+    m = build(sa, cfg, make_state_dict(cfg, seed=4), mode)
+    x = frames(500 + nf, (1, nf, 3, 48, 48)).cuda()
+    want = g[f"{tag}_last_hidden_state"]
+    lt = ACC_CEIL if mode == "fp32" else BF16_LHS
+    full = m(x).last_hidden_state
+    assert maxabs(full, want) <= lt
+    for chunks in ([nf], [nf // 2, nf // 2], [1] * nf, [3, 1, nf - 4]):
+        cache, outs, pos = None, [], 0
+        for c in chunks:
+            o = m(x[:, pos:pos + c], use_cache=True, past_key_values=cache)
+            cache = o.past_key_values
+            assert cache.get_seq_length() == pos + c
+            outs.append(o.last_hidden_state)
+            pos += c
+        got = torch.cat(outs, 1)
+        assert maxabs(got, want) <= lt
+        # streamed == full clip on the same device path, to fp32 re-ordering noise
+        assert maxabs(got, full) <= (1e-4 if mode == "fp32" else 2e-2)
+    with pytest.raises(Exception):                        # past the time-embedding rows / cache capacity
+        m(x[:, :1], use_cache=True, past_key_values=cache)
+    cache.reset()
+    o = m(x[:, :2], use_cache=True, past_key_values=cache)
+    assert maxabs(o.last_hidden_state, want[:, :2]) <= lt
+
+
+def test_vision_tower_window(sa):
+    cfg = small_cfg(num_frames=16)
+    m = build(sa, cfg, make_state_dict(cfg, seed=1), "fp32")
+    tower = sa.TimesformerVisionTower(m, context_length=6, max_frames=16)
+    x = frames(11, (1, 10, 3, 48, 48)).cuda()
+    full = m(x).last_hidden_state
+    for t in range(10):
+        feats = tower(x[:, t:t + 1])
+    assert feats.shape == (1, 6, 9, 128)
+    assert maxabs(feats, full[:, 4:10]) <= 1e-4
+    tower.clear_cache()
+    assert tower(x[:, :3]).shape == (1, 3, 9, 128)
+
+
+# ------------------------------------------------------------------------------------------------
+# SigLIP-base (golden F2) and full BASELINE size properties
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def base_models(sa):
+    cfg = siglip_base()
+    sd = make_state_dict(cfg, seed=0)
+    return {mode: build(sa, cfg, sd, mode) for mode in ("fp32", "bf16")}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["randn", "clamped"])
+def test_base_vs_golden_f2(sa, golden_dir, base_models, mode, tag):
+    g = load_npz(os.path.join(golden_dir, "f2_base.npz"))
+    torch.manual_seed(0)
+    x = torch.randn(1, 16, 3, 224, 224)
+    if tag == "clamped":
+        x = x.clamp(-1, 1)
+    out = base_models[mode](x.cuda())
+    lhs = out.last_hidden_state
+    lt, pt = (ACC_TOL, ACC_TOL) if mode == "fp32" else (BF16_LHS, BF16_POOL)
+    d_pool = maxabs(out.pooler_output, g[f"{tag}_pooler_output"])
+    d_lhs = maxabs(lhs[0][[0, 7, 15]][:, [0, 97, 195]], g[f"{tag}_lhs_slices"])
+    print(f"[{mode}/{tag}] max-abs lhs-slices {d_lhs:.3e} pooler {d_pool:.3e}")
+    assert d_pool <= pt and d_lhs <= lt
+    norms = lhs[0].double().flatten(1).norm(dim=1).cpu()
+    assert maxabs(norms, g[f"{tag}_lhs_frame_norms"]) <= (2e-2 if mode == "fp32" else 1.0)
+    assert abs(float(lhs.double().sum()) - float(g[f"{tag}_lhs_checksum"])) <= (1.0 if mode == "fp32" else 400.0)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_base_full_tensor_vs_oracle(sa, base_models, mode):
+    """Full last_hidden_state of one 16x224^2 clip against the CPU oracle (the number bench.py reports)."""
+    cfg = siglip_base()
+    sd = make_state_dict(cfg, seed=0)
+    torch.manual_seed(0)
+    x = torch.randn(1, 16, 3, 224, 224)
+    want = O.forward(sd, cfg, x)
+    out = base_models[mode](x.cuda())
+    d_lhs, d_pool = maxabs(out.last_hidden_state, want["last_hidden_state"]), maxabs(out.pooler_output, want["pooler_output"])
+    print(f"[{mode}] full-tensor max-abs lhs {d_lhs:.3e} pooler {d_pool:.3e} cosine {cosine(out.last_hidden_state, want['last_hidden_state']):.6f}")
+    if mode == "fp32":
+        assert d_lhs <= ACC_TOL and d_pool <= ACC_TOL
+    else:
+        assert d_lhs <= BF16_LHS and d_pool <= BF16_POOL
+        assert cosine(out.last_hidden_state, want["last_hidden_state"]) >= 0.9995
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_baseline_batch8_properties(sa, base_models, mode):
+    """BASELINE config #2 size (8 x 16 x 224^2): clips are independent (batch row == the clip alone,
+    bit-exact) and the causal property holds at full size."""
+    m = base_models[mode]
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(8, 16, 3, 224, 224, generator=g).cuda()
+    out = m(x)
+    assert out.last_hidden_state.shape == (8, 16, 196, 768) and out.pooler_output.shape == (8, 16, 768)
+    assert torch.isfinite(out.last_hidden_state).all() and torch.isfinite(out.pooler_output).all()
+    for i in (0, 5):
+        solo = m(x[i:i + 1])
+        assert torch.equal(solo.last_hidden_state[0], out.last_hidden_state[i])
+        assert torch.equal(solo.pooler_output[0], out.pooler_output[i])
+    x2 = x.clone()
+    x2[:, 12:] = -x2[:, 12:]
+    out2 = m(x2)
+    assert torch.equal(out2.last_hidden_state[:, :12], out.last_hidden_state[:, :12])
+    assert not torch.equal(out2.last_hidden_state[:, 12:], out.last_hidden_state[:, 12:])
+
+
+# ------------------------------------------------------------------------------------------------
+# loss heads (golden F6)
+# ------------------------------------------------------------------------------------------------
+def test_heads_f6(sa, golden_dir):
+    g = load_npz(os.path.join(golden_dir, "f6_heads.npz"))
+    pooler = torch.tensor(g["pooler"]).cuda()
+    r = sa.heads.RetrievalHead()
+    loss, gp, gs = r.loss(pooler, torch.tensor(g["text"]).cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["retrieval_loss"])) <= 2e-5
+    assert maxabs(gp, g["retrieval_grad"]) <= 1e-6
+    l = sa.heads.LocalizationHead(torch.tensor(g["label_emb"]))
+    loss, gp, gs = l.loss(pooler, torch.tensor(g["labels"]).cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["localization_loss"])) <= 2e-5
+    assert maxabs(gp, g["localization_grad"]) <= 1e-6
+    assert abs(float(gs[0]) - float(g["localization_logit_scale_grad"])) <= 2e-5
+    assert abs(float(gs[1]) - float(g["localization_logit_bias_grad"])) <= 2e-5
+
+
+def test_retrieval_multirank_negatives(sa, golden_dir):
+    """world_size 2: local block + the other rank's captions as negatives only (modeling:250-280)."""
+    g = load_npz(os.path.join(golden_dir, "f6_heads.npz"))
+    pooler, txt = torch.tensor(g["pooler"]), torch.tensor(g["text"])
+    other = torch.flip(txt, dims=[0]) * 1.3 + 0.1
+    ls, lb = torch.log(torch.tensor(10.0)), torch.tensor(-2.0)
+    for rank in (0, 1):
+        allt = torch.cat([txt, other] if rank == 0 else [other, txt], 0)
+        p = pooler.clone().requires_grad_(True)
+        want = O.retrieval_loss(p, txt, ls, lb, other_rank_text=[other])
+        want.backward()
+        loss, gp, _ = sa.heads.RetrievalHead().loss(pooler.cuda(), allt.cuda(), rank=rank)
+        assert abs(float(loss) - float(want)) <= 2e-5 and maxabs(gp, p.grad) <= 1e-6
