@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py — frames/s of the StreamFormer encoder forward on 16x224^2 clips (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+
+A "step" is one forward of the hot path over one batch of 8 synthetic clips per GPU
+(BASELINE.json configs[1]: "1xMI355X bf16 forward, batch 8x16x224^2, SigLIP-base"), inputs already
+resident in HBM.  Clips are independent, so N GPUs run N data-parallel replicas with no data-path
+collective ("scaling": "weak"); the only collectives here are the start/stop barriers and the
+max-over-ranks reduction of the elapsed time.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the dominant kernel (MLP up-projection GEMM, MFMA-bound): algorithmic FLOPs / launch
+                over its mean launch time measured with HIP events on the launch stream
+  attention     the two attention kernels against the HBM roofline ("fraction of the attention roofline")
+  accuracy      max-abs deviation of last_hidden_state / pooler_output vs the CPU oracle, both modes
+  accurate_mode frames/s of the fp32-accurate (bf16x3) mode on the same workload
+  cpu_baseline  the CPU oracle (a restatement pinned against the reference, kind "port") timed on the
+                host cores on a bounded sample: B=1 clips of the same shape
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E spec, MI355X_MICROARCH.md
+GFLOP_PER_FRAME = 49.40       # 790.48 GFLOP per 16-frame clip
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE config: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = usable host cores (affinity, cgroup quota)")
+    ap.add_argument("--profile", action="store_true", help="timed steps + roofline hooks only (for rocprofv3 runs)")
+    return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def timed_steps(model, x, steps, warmup, dist, world):
+    for _ in range(warmup):
+        model(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import streamformer_amd as sa
+    from streamformer_amd import _native as nat
+
+    cfg = sa.siglip_base()
+    sd = sa.make_state_dict(cfg, seed=0)
+    B, T = args.batch, cfg.num_frames
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, T, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
+
+    model = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+    dt = timed_steps(model, x, args.steps, args.warmup, dist, world)
+    frames = world * B * T * args.steps
+    value = frames / dt
+
+    out = {
+        "metric": "frames/s (16x224^2 clips)", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SigLIP-base StreamFormer encoder forward, {B} clips x 16 x 224^2 per GPU, "
+                               "random-init de-trivialised weights, causal temporal attention",
+                   "global_batch_clips": B * world, "frames_per_clip": T, "parallelism": f"dp{world}"},
+        "e2e_mfma_frac": round(value / world * GFLOP_PER_FRAME / 1e3 / PEAK_BF16_TFLOPS, 4),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ------
+        M = B * T * cfg.num_patches
+        ws = torch.randn(1 << 29, dtype=torch.bfloat16, device=dev).view(torch.uint8)   # 1 GiB of random bf16
+        ms, fl = nat.C.c_float(), nat.C.c_double()
+        stream = nat.current_stream_handle(dev)
+        gemms = {}
+        for which, name in ((0, "mlp_up"), (1, "mlp_down"), (2, "qkv"), (3, "out_proj")):
+            nat.check(nat.lib.sf_bench_gemm(model._handle, M, which, 20, ws.data_ptr(), ws.numel(), stream,
+                                            nat.C.byref(ms), nat.C.byref(fl)))
+            gemms[name] = {"ms": round(ms.value, 4), "tflops": round(fl.value / ms.value / 1e9, 1)}
+        up = gemms["mlp_up"]
+        out["roofline"] = {"kernel": "sf_gemm_kernel<false,SF_EPI_ACT_BF16> (MLP up-projection, M=%d N=3072 K=768)" % M,
+                           "bound": "mfma", "achieved": up["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(up["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "avg_launch_ms": up["ms"], "other_gemms": gemms}
+        by = nat.C.c_double()
+        att = {}
+        for which, name in ((0, "spatial"), (1, "temporal")):
+            nat.check(nat.lib.sf_bench_attention(model._handle, B, T, which, 20, ws.data_ptr(), ws.numel(), stream,
+                                                 nat.C.byref(ms), nat.C.byref(by), nat.C.byref(fl)))
+            gbs = by.value / ms.value / 1e6
+            att[name] = {"ms": round(ms.value, 4), "algorithmic_GB": round(by.value / 1e9, 4), "GBps": round(gbs, 1),
+                         "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "tflops": round(fl.value / ms.value / 1e9, 1)}
+        out["attention"] = att
+        del ws
+        if args.profile:
+            print(json.dumps(out), flush=True)
+            return
+
+        # ---- accuracy vs the CPU oracle + the fp32-accurate mode's throughput -------------------
+        from oracle import streamformer_oracle as O
+        torch.manual_seed(0)
+        x1 = torch.randn(1, T, 3, cfg.image_size, cfg.image_size)
+        want = O.forward(sd, cfg, x1)
+        acc = {}
+        o = model(x1.to(dev))
+        acc["bf16"] = {"last_hidden_state": float((o.last_hidden_state.cpu() - want["last_hidden_state"]).abs().max()),
+                       "pooler_output": float((o.pooler_output.cpu() - want["pooler_output"]).abs().max())}
+        del model
+        m2 = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="fp32")
+        m2.load_state_dict(sd)
+        m2.to(dev).eval()
+        o = m2(x1.to(dev))
+        acc["bf16x3"] = {"last_hidden_state": float((o.last_hidden_state.cpu() - want["last_hidden_state"]).abs().max()),
+                         "pooler_output": float((o.pooler_output.cpu() - want["pooler_output"]).abs().max())}
+        out["accuracy_max_abs_vs_cpu_oracle"] = acc
+        if world == 1:
+            dt2 = timed_steps(m2, x, max(args.steps // 2, 3), 2, None, 1)
+            out["accurate_mode"] = {"value": round(B * T * max(args.steps // 2, 3) / dt2, 1), "unit": "frames/s",
+                                    "dtype": "bf16x3 (fp32-accurate)", "max_abs_last_hidden_state": acc["bf16x3"]["last_hidden_state"]}
+        del m2
+
+        # ---- CPU baseline: the oracle on the host cores, bounded sample (N=1 only) ------------
+        if world == 1 and not args.no_cpu_baseline:
+            cores = args.cpu_threads or usable_cores()
+            torch.set_num_threads(cores)
+            t0 = time.perf_counter()
+            O.forward(sd, cfg, x1)                       # warm-up 1 (also sizes the sample)
+            t1 = time.perf_counter() - t0
+            if t1 < 4.0:
+                O.forward(sd, cfg, x1)                   # warm-up 2
+            iters = max(1, min(args.cpu_iters, int(20.0 / max(t1, 1e-3))))   # ~10-30 s of CPU work in total
+            ts = []
+            for _ in range(iters):
+                t0 = time.perf_counter()
+                O.forward(sd, cfg, x1)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            med = ts[len(ts) // 2]
+            cpu_model = ""
+            try:
+                with open("/proc/cpuinfo") as f:
+                    for line in f:
+                        if line.startswith("model name"):
+                            cpu_model = line.split(":", 1)[1].strip()
+                            break
+            except Exception:
+                pass
+            out["cpu_baseline"] = {"value": round(T / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": f"{iters} forwards of one [1,16,3,224,224] clip after warm-up "
+                                             f"(median {med:.3f}s, best {ts[0]:.3f}s), fp32 eager torch {torch.__version__}",
+                                   "cpu": cpu_model, "best": round(T / ts[0], 2)}
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1 and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,6 +154,13 @@ int sf_localization_loss(const float* pooler_dev, const float* label_emb_dev, co
 int sf_bench_gemm(sf_encoder* enc, int M, int which, int iters, void* workspace_dev,
                   size_t workspace_bytes, sf_stream stream, float* mean_ms_out, double* flops_out);
 
+/* Same for the attention kernels at the loaded model's shape: which = 0 spatial (B*T frames of N
+ * tokens), 1 temporal (B*N sequences of T frames).  bytes_out = algorithmic bytes per launch
+ * (read q,k,v once + write ctx once, in the storage type of the compute mode).                  */
+int sf_bench_attention(sf_encoder* enc, int B, int T, int which, int iters, void* workspace_dev,
+                       size_t workspace_bytes, sf_stream stream, float* mean_ms_out, double* bytes_out,
+                       double* flops_out);
+
 #ifdef __cplusplus
 }
 #endif

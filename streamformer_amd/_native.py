@@ -61,17 +61,23 @@ SIGNATURES = {
     "sf_retrieval_loss": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "sf_localization_loss": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "sf_bench_gemm": (_I, [_P, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double)]),
+    "sf_bench_attention": (_I, [_P, _I, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
 }
 
 
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m streamformer_amd.build` "
+            f"{LIB_PATH} is missing: build it with `python streamformer_amd/build.py` "
             "(hipcc --offload-arch=gfx950).  There is no non-HIP fallback.")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name} (stale build? run "
+                              "`python streamformer_amd/build.py`)") from e
         fn.restype = res
         fn.argtypes = args
     return lib

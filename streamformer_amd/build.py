@@ -1,6 +1,7 @@
 """Build the HIP shared library in-tree:  streamformer_amd/libstreamformer_hip.so
 
-    python -m streamformer_amd.build          # or __graft_entry__.build()
+    python streamformer_amd/build.py          # or __graft_entry__.build()   (not `-m`: importing the
+                                              #  package needs the library this script produces)
 
 hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box
 with the repo snapshot; nothing is JIT-built at import time.

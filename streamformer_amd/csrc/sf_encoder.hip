@@ -824,3 +824,51 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   if (flops_out) *flops_out = 2.0 * M * (double)lin->N * (double)lin->K;
   return SF_OK;
 }
+
+extern "C" int sf_bench_attention(sf_encoder* e, int B, int T, int which, int iters, void* workspace,
+                                  size_t workspace_bytes, sf_stream stream, float* mean_ms_out, double* bytes_out,
+                                  double* flops_out) {
+  if (!e || !e->finalized) return set_err(SF_ERR_STATE, "encoder not finalized");
+  if (iters <= 0 || B <= 0 || T <= 0 || !workspace || !mean_ms_out) return set_err(SF_ERR_INVALID, "bad argument");
+  const bool acc = e->compute == SF_COMPUTE_BF16X3;
+  const int D = e->D, N = e->N, heads = e->cfg.num_attention_heads;
+  const size_t M = (size_t)B * T * N, esz = acc ? 4 : 2;
+  Carver c(workspace);
+  char* qkv = c.take<char>(M * 3 * D * esz);
+  bf16_t* ch = c.take<bf16_t>(M * D);
+  bf16_t* cl = c.take<bf16_t>(M * D);
+  if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(qkv, 0x3c, M * 3 * D * esz, s));   // finite, non-trivial bit pattern
+  SfAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = qkv; a.k = qkv + (size_t)D * esz; a.v = qkv + (size_t)2 * D * esz;
+  a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 0.125f;
+  a.ctx_hi = ch; a.ctx_lo = cl; a.D = D; a.N = N;
+  if (which == 0) {
+    a.frames = B * T;
+  } else {
+    a.B = B; a.Tq = T; a.Tk = T; a.Tcap = T; a.t_past = 0; a.causal = e->cfg.enable_causal_temporal; a.Tq_cap = T; a.q_t0 = 0;
+  }
+  auto launch = [&]() { return which == 0 ? sf_launch_spatial_attention(a, acc, s) : sf_launch_temporal_attention(a, acc, s); };
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(launch());
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch());
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mean_ms_out = ms / iters;
+  if (bytes_out) *bytes_out = (double)M * 3 * D * esz + (double)M * D * 2 * (acc ? 2 : 1);
+  if (flops_out) {
+    const double L = which == 0 ? N : T;        // 2 matmuls of L x L x 64 per (sequence, head), full (not causal-halved)
+    const double seqs = which == 0 ? (double)B * T : (double)B * N;
+    *flops_out = seqs * heads * 2.0 * (2.0 * L * L * 64.0);
+  }
+  return SF_OK;
+}
