@@ -42,6 +42,23 @@ SF_DEVICE float gelu_tanh(float x) {
   const float k = 0.7978845608028654f;
   return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
 }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7) on v_rcp/v_exp: ~12 VALU instead of the
+// branchy ocml erff.  Used where the result is rounded to bf16 anyway (throughput mode).
+SF_DEVICE float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+SF_DEVICE float apply_act_fast(float x, int act) {
+  if (act == 0) return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  return act == 1 ? gelu_tanh(x) : fmaxf(x, 0.0f);
+}
 SF_DEVICE float apply_act(float x, int act) {
   return act == 0 ? gelu_erf(x) : (act == 1 ? gelu_tanh(x) : fmaxf(x, 0.0f));
 }
@@ -74,7 +91,10 @@ struct SfGemmArgs {
   // output row remap (KV-cache appends): out_row = (m / grp_rows) * grp_stride + grp_off + m % grp_rows
   int grp_rows, grp_stride, grp_off;
 };
-hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);
+hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches 128^2 / 256^2
+hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   // sf_gemm.hip
+bool sf_gemm256_supported(const SfGemmArgs& a, bool split);                      // sf_gemm256.hip
+hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // row-wise / elementwise kernels

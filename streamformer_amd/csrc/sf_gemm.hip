@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void sf_gemm_kernel(SfGemmArgs p) {
       } else {
         if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+          for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_fast(v[j], p.act);
         }
         unsigned int h[4], l[4];
 #pragma unroll
@@ -221,6 +221,11 @@ static hipError_t launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStre
 }
 
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
+  if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
+  return sf_launch_gemm128(a, split, s);
+}
+
+hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s) {
   const int bk = split ? 32 : 64;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % bk) || (a.N % 4) || (a.ldc % 4)) return hipErrorInvalidValue;
   if (split && (!a.a_lo || !a.w_lo)) return hipErrorInvalidValue;

@@ -1,0 +1,323 @@
+// 256x256x64 "8-phase" MFMA GEMM for the large projections of the encoder (qkv, MLP up/down):
+//   C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue), bf16 operands, fp32 accumulate.
+//
+// gfx950 structure (one workgroup per CU, 8 waves = 2 per SIMD, 128 KB of LDS):
+//   * wave (wm, wn) of a 2x4 grid owns a 128x64 block of C, processed as four 64x32 quadrants;
+//     one quadrant x one K-tile (BK = 64) = 16 MFMA 16x16x32 = one PHASE; 4 phases per K-tile.
+//   * a K-tile is staged as four 16 KB "pieces" in consumption order: Bp0, Ap0, Bp1, Ap1
+//     (Bp_q = the nq=q column halves of all four wave columns, Ap_q = the mq=q row halves of both
+//     wave rows), so each piece is needed one phase later than the previous one.  Every phase issues
+//     ONE piece (2 x global_load_lds_dwordx4 per lane) six pieces ahead of its use, into a 2-deep
+//     ring per piece; `s_waitcnt vmcnt(8)` (never 0 in steady state) leaves four pieces in flight
+//     across the barriers.
+//   * the two wave rows run STAGGERED by one barrier: while wm=0 issues MFMAs, wm=1 issues its
+//     ds_reads + LDS-DMA, and vice versa, so the matrix pipe of every SIMD always has one wave in a
+//     pure-MFMA segment (raised priority) next to one in a memory segment.
+//   * hazards are placed by count, not by luck: a piece is read one phase after the wait that retires
+//     it (RAW: issuing waves' vmcnt -> barrier -> ds_read) and its ring slot is re-staged >= 2 phases
+//     after its last ds_read (WAR, with the stagger).  See DESIGN.md "GEMM-256 schedule".
+//   * LDS image of a piece is [128 rows][64 k] bf16, lane-linear for the DMA, with the 16-byte slot
+//     XOR (row>>1)&7 applied to the SOURCE address and mirrored on ds_read_b128.
+#include "sf_common.h"
+
+#define G_THREADS 512
+#define PIECE_BYTES 16384
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+SF_DEVICE f32x4_t mfma16b(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+
+SF_DEVICE bf16x8_t rd_frag(const char* piece, int row, int kc) {
+  return *reinterpret_cast<const bf16x8_t*>(piece + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+}
+
+template <int N>
+SF_DEVICE void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tiles_n = p.N >> 8;
+  const int K = p.K;
+  const int nkt = K >> 6;   // even, >= 2 (checked by the launcher)
+  const int dma_lds = wave * 1024;   // wave-uniform part of the DMA destination inside a piece
+  // persistent, XCD-aware walk: in round r the 32 workgroups of XCD x take 32 consecutive tiles
+  // (consecutive tiles share the A row panel, so it is fetched into that XCD's L2 once)
+  // operands through buffer descriptors: 32-bit per-lane byte offsets + a scalar K offset, so the
+  // loop carries no 64-bit address arithmetic (each operand is < 4 GiB: checked by the launcher)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_hi, 0, (unsigned)p.M * (unsigned)K * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, (unsigned)p.N * (unsigned)K * 2u, 0x00020000);
+  const int cpx = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+
+  for (int round = 0;; ++round) {
+    const int tile = (round * 8 + xcd) * cpx + slot_in_xcd;
+    if (tile >= ntiles) break;
+    const int m0 = (tile / tiles_n) << 8, n0 = (tile % tiles_n) << 8;
+
+    // ---- per-lane DMA source offsets (elements), two 16-byte chunks per piece --------------------
+    unsigned offA[2][2], offB[2][2];
+    int tid_p = threadIdx.x;
+    asm volatile("" : "+v"(tid_p));     // recompute per tile instead of carrying (and spilling) invariants
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * G_THREADS + tid_p;
+      const int prow = c >> 3, slot = c & 7;
+      const int kc = slot ^ ((prow >> 1) & 7);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int ar = m0 + (prow >> 6) * 128 + q * 64 + (prow & 63);
+        ar = ar < p.M ? ar : p.M - 1;
+        offA[q][i] = ((unsigned)ar * (unsigned)K + kc * 8) * 2u;      // byte offsets (buffer voffset)
+        int br = n0 + (prow >> 5) * 64 + q * 32 + (prow & 31);
+        offB[q][i] = ((unsigned)br * (unsigned)K + kc * 8) * 2u;
+      }
+    }
+    // piece j of K-tile t: j = 0 Bp0, 1 Ap0, 2 Bp1, 3 Ap1 ; ring slot (t & 1) * 4 + j
+    auto issue = [&](int t, int j) {
+      char* dst = smem + ((t & 1) * 4 + j) * PIECE_BYTES + dma_lds;
+      const unsigned o0 = (j & 1) ? offA[j >> 1][0] : offB[j >> 1][0];
+      const unsigned o1 = (j & 1) ? offA[j >> 1][1] : offB[j >> 1][1];
+      const int kof = t * 128;     // bytes along K: the scalar offset of the buffer load
+      if (j & 1) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)dst, 16, o0, kof, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(dst + 8192), 16, o1, kof, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, o0, kof, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(dst + 8192), 16, o1, kof, 0, 0);
+      }
+    };
+
+    f32x4_t acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8_t af[4][2], b0[2][2], b1[2][2];
+    auto read_b = [&](bf16x8_t (&b)[2][2], int par, int nq) {
+      const char* pc = smem + (par * 4 + nq * 2) * PIECE_BYTES;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b[nt][ks] = rd_frag(pc, wn * 32 + nt * 16 + l15, ks * 4 + g);
+    };
+    auto read_a = [&](int par, int mq) {
+      const char* pc = smem + (par * 4 + mq * 2 + 1) * PIECE_BYTES;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[mt][ks] = rd_frag(pc, wm * 64 + mt * 16 + l15, ks * 4 + g);
+    };
+    auto mma = [&](int mq, int nq, bf16x8_t (&b)[2][2]) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mq][nq][mt][nt] = mfma16b(b[nt][ks], af[mt][ks], acc[mq][nq][mt][nt]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: six pieces in flight, the first two landed ------------------------------------
+    // (older epilogue stores of the previous tile may still be outstanding: a counted wait stays
+    //  correct because loads return in order among themselves -- a pending needed load implies all
+    //  later loads pending, i.e. more than N outstanding)
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1);
+    wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
+
+#define PHASE(READS, ISSUE_STMT, WAIT_STMT, MMA_STMT) \
+  do {                                               \
+    READS;                                           \
+    ISSUE_STMT;                                      \
+    WAIT_STMT;                                       \
+    __builtin_amdgcn_s_barrier();                    \
+    MMA_STMT;                                        \
+    __builtin_amdgcn_s_barrier();                    \
+  } while (0)
+
+    int t = 0;
+    for (; t + 2 < nkt; t += 2) {
+      // K-tile t (parity 0): phases issue pieces (t+1,2), (t+1,3), (t+2,0), (t+2,1)
+      PHASE((read_b(b0, 0, 0), read_a(0, 0)), issue(t + 1, 2), wait_vm<8>(), mma(0, 0, b0));
+      PHASE(read_b(b1, 0, 1), issue(t + 1, 3), wait_vm<8>(), mma(0, 1, b1));
+      PHASE(read_a(0, 1), issue(t + 2, 0), wait_vm<8>(), mma(1, 1, b1));
+      PHASE((void)0, issue(t + 2, 1), wait_vm<8>(), mma(1, 0, b0));
+      // K-tile t+1 (parity 1): pieces (t+2,2), (t+2,3), (t+3,0), (t+3,1)
+      PHASE((read_b(b0, 1, 0), read_a(1, 0)), issue(t + 2, 2), wait_vm<8>(), mma(0, 0, b0));
+      PHASE(read_b(b1, 1, 1), issue(t + 2, 3), wait_vm<8>(), mma(0, 1, b1));
+      PHASE(read_a(1, 1), issue(t + 3, 0), wait_vm<8>(), mma(1, 1, b1));
+      PHASE((void)0, issue(t + 3, 1), wait_vm<8>(), mma(1, 0, b0));
+    }
+    // ---- tail: K-tiles nkt-2 (parity 0) and nkt-1 (parity 1); only two pieces are left to issue ---
+    PHASE((read_b(b0, 0, 0), read_a(0, 0)), issue(t + 1, 2), wait_vm<8>(), mma(0, 0, b0));
+    PHASE(read_b(b1, 0, 1), issue(t + 1, 3), wait_vm<8>(), mma(0, 1, b1));
+    PHASE(read_a(0, 1), (void)0, (void)0, mma(1, 1, b1));
+    PHASE((void)0, (void)0, wait_vm<4>(), mma(1, 0, b0));
+    PHASE((read_b(b0, 1, 0), read_a(1, 0)), (void)0, wait_vm<2>(), mma(0, 0, b0));
+    PHASE(read_b(b1, 1, 1), (void)0, wait_vm<0>(), mma(0, 1, b1));
+    PHASE(read_a(1, 1), (void)0, (void)0, mma(1, 1, b1));
+    PHASE((void)0, (void)0, (void)0, mma(1, 0, b0));
+#undef PHASE
+    if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger: every ring read is retired
+
+    // ---- epilogue: stage the C tile in LDS (the ring is idle), then whole-row 16-byte stores -------
+    if (p.act == 99) {   // lab: no stores (keeps the accumulators live through an impossible branch)
+      float sacc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) sacc += acc[a][b][c][d][0] + acc[a][b][c][d][1] + acc[a][b][c][d][2] + acc[a][b][c][d][3];
+      if (sacc == 123.456f) p.out_hi[tid] = 1;
+      continue;
+    }
+    // lane-derived epilogue indices are re-materialised from an opaque copy of the thread id so the
+    // compiler does not hoist them (loop-invariant over tiles) across the register-starved K loop
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int l15 = tid_e & 15, g = (tid_e >> 4) & 3;
+    const int tid = tid_e;
+    f32x4_t bias4[2][2];
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        bias4[nq][nt] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + n0 + wn * 64 + nq * 32 + nt * 16 + g * 4)
+                               : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16) {
+      // [256 rows][32 chunks of 16 B], chunk index XOR (row & 31)
+#pragma unroll
+      for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int r = wm * 128 + mq * 64 + mt * 16 + l15;
+#pragma unroll
+          for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int nl = wn * 64 + nq * 32 + nt * 16 + g * 4;
+              f32x4_t v = acc[mq][nq][mt][nt] + bias4[nq][nt];
+              if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act_fast(v[j], 0);   // erf-GELU only (launcher checks)
+              }
+              const u32x2_t hv = {f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16)};
+              *reinterpret_cast<u32x2_t*>(smem + r * 512 + ((((nl >> 3)) ^ (r & 31)) << 4) + (nl & 4) * 2) = hv;
+            }
+        }
+      __syncthreads();
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int idx = it * G_THREADS + tid;
+        const int r = idx >> 5, c = idx & 31;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * 512 + ((c ^ (r & 31)) << 4));
+        const int m = m0 + r;
+        if (m < p.M) {
+          size_t orow = (size_t)m;
+          if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+          *reinterpret_cast<u32x4_t*>(p.out_hi + orow * (size_t)p.ldc + n0 + c * 8) = v;
+        }
+      }
+      __syncthreads();   // staging reads retired before the next tile's DMA lands in the ring
+    } else {
+      // fp32 outputs: two passes of [128 rows][64 chunks of 16 B], chunk index XOR (row & 63)
+#pragma unroll
+      for (int mq = 0; mq < 2; ++mq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int r = wm * 64 + mt * 16 + l15;
+#pragma unroll
+          for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int nl = wn * 64 + nq * 32 + nt * 16 + g * 4;
+              const f32x4_t v = acc[mq][nq][mt][nt] + bias4[nq][nt];
+              *reinterpret_cast<f32x4_t*>(smem + r * 1024 + (((nl >> 2) ^ (r & 63)) << 4)) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int idx = it * G_THREADS + tid;
+          const int r = idx >> 6, c = idx & 63;
+          f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + ((c ^ (r & 63)) << 4));
+          const int m = m0 + (r >> 6) * 128 + mq * 64 + (r & 63);
+          if (m < p.M) {
+            size_t orow = (size_t)m;
+            if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+            const size_t o = orow * (size_t)p.ldc + n0 + c * 4;
+            if (EPI == SF_EPI_RESID_F32) v = *reinterpret_cast<const f32x4_t*>(p.resid + o) + p.alpha * v;
+            *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
+  if (split) return false;
+  if (a.epi == SF_EPI_EMBED_F32) return false;
+  if (a.epi == SF_EPI_ACT_BF16 && a.act != 0 && a.act != 99) return false;   // other activations: 128^2 kernel
+  if (a.K % 128 || a.K < 128) return false;
+  if (a.N % 256 || a.N < 1024) return false;    // N = 768: 294 tiles on 256 CUs -> the 128^2 kernel wins
+  if (a.M < 2048 || (size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return false;                 // small problems: the 128x128 kernel fills the chip better
+  if (a.out_lo) return false;
+  return true;
+}
+
+static int g256_grid() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus < 8) cus = 256;
+    cus &= ~7;      // the XCD-aware walk wants a multiple of 8
+  }
+  return cus;
+}
+
+hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
+  const int tiles = ((a.M + 255) / 256) * (a.N / 256);
+  const size_t lds = 8 * PIECE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define SF_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SF_ATTR(SF_EPI_F32) SF_ATTR(SF_EPI_BF16) SF_ATTR(SF_EPI_ACT_BF16) SF_ATTR(SF_EPI_RESID_F32)
+#undef SF_ATTR
+    attr_set = true;
+  }
+  const dim3 grid(g256_grid()), block(G_THREADS);
+  switch (a.epi) {
+    case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_BF16: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_ACT_BF16: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_RESID_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_RESID_F32>), grid, block, lds, s, a, tiles); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
