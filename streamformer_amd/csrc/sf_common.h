@@ -95,6 +95,8 @@ hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      
 hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   // sf_gemm.hip
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split);                      // sf_gemm256.hip
 hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s);
+bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip
+hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // row-wise / elementwise kernels

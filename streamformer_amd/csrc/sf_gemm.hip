@@ -221,6 +221,7 @@ static hipError_t launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStre
 }
 
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
+  if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
   return sf_launch_gemm128(a, split, s);
 }

@@ -1,0 +1,213 @@
+// "Panel" MFMA GEMM for the N = 768 projections with a residual epilogue (attention output
+// projections and MLP down-projection):   out = resid + alpha * (A[M,K] * W[N,K]^T + bias)
+//
+// Why a third GEMM kernel: with N = 768 a 256x256 tiling gives 98 x 3 = 294 tiles on 256 CUs (two
+// rounds, the second 15 % full) and 128x128 tiles run the 2-barrier schedule.  Here the tile is
+// (rows/128) x 384: for the BASELINE shape M = 25088 that is 196 x 384 -> exactly 128 x 2 = 256 tiles,
+// one per CU, one round, with fewer operand bytes per FLOP than a 256^2 tile.
+//
+// gfx950 structure: 8 waves = 1(M) x 8(N); a wave owns all 13 m-tiles x 3 n-tiles (208 x 48) = 39
+// MFMA 16x16x32 per 32-deep K-tile.  A K-tile is one A piece (256 rows x 64 B, rows past the tile are
+// clamped re-reads) + one W piece (384 x 64 B) = 40 KB, in a 4-slot LDS ring (160 KB: the whole CU).
+// One phase per K-tile: ds_reads -> vmcnt(5) -> barrier -> issue the K-tile three ahead -> 39 MFMA
+// -> barrier, with the two halves of the workgroup staggered by one barrier (one half in its MFMA
+// segment while the other reads).  Hazards by count: a slot is re-staged in the MFMA segment of the
+// phase after its last read (>= the retiring lgkmcnt + one barrier for both halves), and read one
+// phase after the vmcnt that retires it.
+#include "sf_common.h"
+
+#define P_THREADS 512
+#define P_MT 13
+#define P_NT 3
+#define P_SLOT_BYTES 40960
+#define P_A_BYTES 16384
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+SF_DEVICE f32x4_t mfma16p(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+template <int N>
+SF_DEVICE void wait_vmp() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
+  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
+}
+
+__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int K = p.K;
+  const int nkt = K >> 5;
+  // tile = (row panel, column half); the two halves of a row panel sit on the same XCD (b, b+8)
+  const int bid = blockIdx.x;
+  const int panel = (bid >> 4) * 8 + (bid & 7), nh = (bid >> 3) & 1;
+  const int m0 = panel * rows_per_tile;
+  const int m_end = min(m0 + rows_per_tile, p.M);
+  const int n0 = nh * 384;
+  if (m0 >= p.M) return;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_hi, 0, (unsigned)p.M * (unsigned)K * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, (unsigned)p.N * (unsigned)K * 2u, 0x00020000);
+  unsigned offA[2], offW[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * P_THREADS + tid;
+    const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
+    if (i < 2) {
+      int ar = m0 + row;
+      ar = ar < m_end ? ar : m_end - 1;
+      offA[i] = ((unsigned)ar * (unsigned)K + kc * 8) * 2u;
+    }
+    offW[i] = ((unsigned)(n0 + row) * (unsigned)K + kc * 8) * 2u;
+  }
+  const int dma_lds = wave * 1024;
+  auto issue = [&](int t) {
+    char* dst = smem + (t & 3) * P_SLOT_BYTES + dma_lds;
+    const int kof = t * 64;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)dst, 16, offA[0], kof, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(dst + 8192), 16, offA[1], kof, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(dst + P_A_BYTES), 16, offW[0], kof, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(dst + P_A_BYTES + 8192), 16, offW[1], kof, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(dst + P_A_BYTES + 16384), 16, offW[2], kof, 0, 0);
+  };
+
+  f32x4_t acc[P_MT][P_NT];
+#pragma unroll
+  for (int i = 0; i < P_MT; ++i)
+#pragma unroll
+    for (int j = 0; j < P_NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[P_MT], wf[P_NT];
+
+  auto reads = [&](int t) {
+    const char* pa = smem + (t & 3) * P_SLOT_BYTES;
+    const char* pw = pa + P_A_BYTES;
+#pragma unroll
+    for (int nt = 0; nt < P_NT; ++nt) wf[nt] = rd32(pw, wave * 48 + nt * 16 + l15, g);
+#pragma unroll
+    for (int mt = 0; mt < P_MT; ++mt) af[mt] = rd32(pa, mt * 16 + l15, g);
+  };
+  auto mma = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < P_MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < P_NT; ++nt) acc[mt][nt] = mfma16p(wf[nt], af[mt], acc[mt][nt]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: K-tiles 0,1,2 in flight, K-tile 0 landed -----------------------------------------
+  issue(0);
+  issue(1);
+  issue(2);
+  wait_vmp<10>();
+  __builtin_amdgcn_s_barrier();
+  if (half == 1) __builtin_amdgcn_s_barrier();
+
+  int t = 0;
+  for (; t + 3 < nkt; ++t) {
+    reads(t);
+    wait_vmp<5>();                      // K-tile t+1 landed (only K-tile t+2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    issue(t + 3);                       // into the slot read in phase t-1
+    mma();
+    __builtin_amdgcn_s_barrier();
+  }
+  // tail: phases nkt-3, nkt-2, nkt-1 (nothing left to issue)
+  reads(t); wait_vmp<5>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
+  reads(t); wait_vmp<0>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
+  reads(t); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier();
+  if (half == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: stage 64-row groups in LDS as fp32 rows of 384, then whole-row 16-byte I/O --------
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int el15 = tid_e & 15, eg = (tid_e >> 4) & 3;
+  f32x4_t bias4[P_NT];
+#pragma unroll
+  for (int nt = 0; nt < P_NT; ++nt)
+    bias4[nt] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + n0 + wave * 48 + nt * 16 + eg * 4)
+                       : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // staging image: [64 rows][96 chunks of 16 B], chunk XOR (row & 31) inside its 32-chunk group
+#pragma unroll
+  for (int grp = 0; grp < 4; ++grp) {
+    constexpr int kIters = 12;                       // 64 rows x 96 chunks / 512 threads
+    const int iters = grp < 3 ? kIters : 3;          // the last group holds one m-tile (16 rows)
+    // residual rows of this group: all loads in flight before the staging pass (latency overlap)
+    f32x4_t res[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int idx = it * P_THREADS + tid_e;
+      const int r = idx / 96, c = idx % 96;
+      const int m = m0 + grp * 64 + r;
+      res[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (it < iters && m < m_end) res[it] = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * (size_t)p.ldc + n0 + c * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mt = grp * 4 + q;
+      if (mt < P_MT) {
+        const int r = q * 16 + el15;
+#pragma unroll
+        for (int nt = 0; nt < P_NT; ++nt) {
+          const int chunk = wave * 12 + nt * 4 + eg;
+          const f32x4_t v = acc[mt][nt] + bias4[nt];
+          *reinterpret_cast<f32x4_t*>(smem + r * 1536 + (((chunk & ~31) | ((chunk ^ r) & 31)) << 4)) = v;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int idx = it * P_THREADS + tid_e;
+      const int r = idx / 96, c = idx % 96;
+      const int m = m0 + grp * 64 + r;
+      if (it < iters && m < m_end) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1536 + (((c & ~31) | ((c ^ r) & 31)) << 4));
+        *reinterpret_cast<f32x4_t*>(p.out_f32 + (size_t)m * (size_t)p.ldc + n0 + c * 4) = res[it] + p.alpha * v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int panel_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus < 16) cus = 256;
+    cus &= ~15;
+  }
+  return cus;
+}
+
+bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split) {
+  if (split || a.epi != SF_EPI_RESID_F32 || a.N != 768 || a.grp_rows > 0) return false;
+  if (a.K % 32 || a.K < 128) return false;
+  if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32)) return false;
+  const int panels = panel_cus() / 2;
+  const int rows = (a.M + panels - 1) / panels;
+  // one round of (rows x 384) tiles; worthwhile only when the 208-row MFMA tile is mostly real rows
+  return rows <= 16 * P_MT && rows > 16 * (P_MT - 3);
+}
+
+hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s) {
+  const int cus = panel_cus();
+  const int panels = cus / 2;
+  const int rows = (a.M + panels - 1) / panels;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P_SLOT_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sf_gemm_panel_kernel, dim3(cus), dim3(P_THREADS), 4 * P_SLOT_BYTES, s, a, rows);
+  return hipGetLastError();
+}

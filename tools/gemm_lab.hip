@@ -17,8 +17,8 @@ int main(int argc, char** argv) {
     {25088, 3072, 768, SF_EPI_ACT_BF16, "mlp_up"}, {25088, 768, 3072, SF_EPI_RESID_F32, "mlp_down"},
     {25088, 2304, 768, SF_EPI_BF16, "qkv"}, {25088, 768, 768, SF_EPI_RESID_F32, "out_proj"},
     {25088, 1536, 768, SF_EPI_BF16, "head_kv"}, {4000, 768, 256, SF_EPI_F32, "ragged"},
-    {8192, 8192, 8192, SF_EPI_BF16, "sq8k"}, {4096, 4096, 4096, SF_EPI_BF16, "sq4k"}, {25088, 3072, 768, SF_EPI_BF16, "up_nogelu"},
-    {25088, 3072, 3072, SF_EPI_BF16, "up_K3072"}, {25088, 3072, 768, -SF_EPI_BF16, "up_nostore"},
+    {8192, 8192, 8192, SF_EPI_BF16, "sq8k"},
+    {12544, 768, 768, SF_EPI_RESID_F32, "out_B4"}, {23000, 768, 3072, SF_EPI_RESID_F32, "down_ragged"},
   };
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
   for (auto& sh : shapes) {
@@ -45,11 +45,12 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) CK(sf_launch_gemm128(g, false, 0)); CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms1, e0, e1));
     double maxd = -1;
-    if (sf_gemm256_supported(g, false)) {
+    const bool use_panel = sf_gemm_panel_supported(g, false);
+    if (use_panel || sf_gemm256_supported(g, false)) {
       g.out_f32 = of2; g.out_hi = oh2;
-      CK(sf_launch_gemm256(g, 0));
+      CK(use_panel ? sf_launch_gemm_panel(g, 0) : sf_launch_gemm256(g, 0));
       CK(hipDeviceSynchronize());
-      CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) CK(sf_launch_gemm256(g, 0)); CK(hipEventRecord(e1, 0));
+      CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) CK(use_panel ? sf_launch_gemm_panel(g, 0) : sf_launch_gemm256(g, 0)); CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms2, e0, e1));
       const bool f32out = sh.epi == SF_EPI_F32 || sh.epi == SF_EPI_RESID_F32;
       maxd = 0;
