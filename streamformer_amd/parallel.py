@@ -1,0 +1,57 @@
+"""Data-parallel plumbing (one process per GPU, torch.distributed over RCCL; gloo on CPU in tests).
+
+The encoder forward shards by clips with NO data-path collective (clips are independent: reference
+inference shards by video list, scripts/downstream_extract_oad_feature.sh:29-50).  Collectives exist
+only around it: the retrieval head needs every rank's caption features once per step (the reference
+ring-exchanges them with batch_isend_irecv, modeling:244-295; one all_gather delivers the same
+negatives), and a training step all-reduces the gradient buffer (DDP in the reference,
+run_finetuning_multi_task.py:421-423).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) shard of n_items for this rank (first n % world ranks get one more)."""
+    q, r = divmod(n_items, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """[B, D] per rank -> [world*B, D] in rank order (same B on every rank)."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    out = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(out, t.contiguous())
+    return torch.cat(out, dim=0)
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    rank, ws = world()
+    if ws == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_mean_(buckets: List[torch.Tensor]) -> None:
+    """In-place mean all-reduce of a few large flat gradient buckets (one collective each)."""
+    rank, ws = world()
+    if ws == 1:
+        return
+    for b in buckets:
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        b.div_(ws)

@@ -1,0 +1,115 @@
+"""CPU: host-side mirror of the reference module — config, checkpoint formats, key handling, output
+objects, and the loud failure without a GPU."""
+import json
+import os
+
+import pytest
+import torch
+
+import streamformer_amd as sa
+from streamformer_amd.configuration import StreamformerConfig
+from streamformer_amd.modeling import ModelOutput, expected_keys, normalize_checkpoint_keys
+from streamformer_amd.parallel import shard_range
+from tests.helpers import small_cfg
+
+
+def test_config_defaults_and_roundtrip(tmp_path):
+    c = StreamformerConfig()
+    assert (c.image_size, c.patch_size, c.num_frames, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+            c.intermediate_size, c.hidden_act, c.layer_norm_eps, c.qkv_bias, c.attention_type) == \
+        (224, 16, 16, 768, 12, 12, 3072, "gelu", 1e-6, True, "divided_space_time")
+    assert c.enable_causal_temporal is False and c.add_lora_spatial is False and c.model_type == "timesformer"
+    c2 = StreamformerConfig(enable_causal_temporal=True, architectures=["X"], torch_dtype="float32")
+    c2.save_pretrained(tmp_path)
+    d = json.load(open(tmp_path / "config.json"))
+    assert d["model_type"] == "timesformer" and d["architectures"] == ["X"]
+    c3 = StreamformerConfig.from_pretrained(str(tmp_path))
+    assert c3.to_dict() == c2.to_dict()
+    with pytest.raises(ValueError):
+        StreamformerConfig(attention_type="bogus")
+
+
+def test_state_dict_keys_match_reference_layout():
+    cfg = sa.siglip_base()
+    sd = sa.make_state_dict(cfg, seed=0)
+    exp = expected_keys(cfg)
+    extra = set(sd) - set(exp)
+    assert all(k.endswith("temporal_attention.attention.mask") for k in extra) and len(extra) == 12
+    assert set(exp) <= set(sd)
+    for k, shape in exp.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+    assert m.num_parameters() == 128350476              # reference count
+    cfg_l = sa.siglip_base(add_lora_spatial=True)
+    n_l = sa.TimesformerMultiTaskingModelSigLIP(cfg_l).num_parameters()
+    assert n_l - 128350476 == 12 * 32 * (768 + 2304 + 768 + 768)
+
+
+@pytest.mark.parametrize("safe", [True, False])
+def test_save_and_from_pretrained_roundtrip(tmp_path, safe):
+    cfg = small_cfg(add_lora_spatial=True)
+    sd = sa.make_state_dict(cfg, seed=9)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+    m.load_state_dict(sd)
+    m.save_pretrained(str(tmp_path), safe_serialization=safe)
+    m2 = sa.TimesformerMultiTaskingModelSigLIP.from_pretrained(str(tmp_path), device="cpu")
+    assert m2.config.add_lora_spatial and m2.config.hidden_size == 128
+    a, b = m.state_dict(), m2.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_wrapper_checkpoint_keys_are_normalised():
+    cfg = small_cfg()
+    sd = sa.make_state_dict(cfg, seed=2)
+    wrapped = {"timesformer." + k: v for k, v in sd.items()}
+    wrapped["task_heads.retrieval.logit_scale"] = torch.tensor(1.0)
+    wrapped["logit_bias"] = torch.tensor(-2.0)
+    clean = normalize_checkpoint_keys(wrapped)
+    assert set(clean) == set(sd)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+    m.load_state_dict(wrapped)                           # strict: nothing missing / unexpected
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in sd.items() if "probe" not in k})
+    bad = dict(sd)
+    bad["head.probe"] = torch.zeros(1, 1, 7)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+
+
+def test_lora_surface():
+    m = sa.TimesformerMultiTaskingModelSigLIP(small_cfg())
+    n0 = len(m.state_dict())
+    m.add_lora_spatial()
+    sd = m.state_dict()
+    assert len(sd) == n0 + 4 * 2
+    assert all(float(v.abs().max()) == 0 for k, v in sd.items() if "_lora_b" in k)    # B = 0 (modeling:534)
+    assert "encoder.layer.0.attention.attention.qkv.weight" not in m.trainable_parameter_names()
+    assert "encoder.layer.0.attention.attention.qkv_lora_a.weight" in m.trainable_parameter_names()
+
+
+def test_model_output_protocol():
+    o = ModelOutput(last_hidden_state=1, pooler_output=2, hidden_states=None, attentions=None)
+    assert o.last_hidden_state == 1 and o["pooler_output"] == 2 and o[0] == 1 and o[1] == 2
+    assert o.to_tuple() == (1, 2)
+    with pytest.raises(AttributeError):
+        o.nope
+
+
+def test_forward_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = sa.TimesformerMultiTaskingModelSigLIP(small_cfg())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 2, 3, 48, 48))
+    with pytest.raises(NotImplementedError):
+        sa.TimesformerMultiTaskingModelSigLIP(small_cfg(attention_type="joint_space_time"))
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
