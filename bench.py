@@ -154,9 +154,18 @@ def main():
                                             nat.C.byref(ms), nat.C.byref(fl)))
             gemms[name] = {"ms": round(ms.value, 4), "tflops": round(fl.value / ms.value / 1e9, 1)}
         up = gemms["mlp_up"]
-        out["roofline"] = {"kernel": "sf_gemm_kernel<false,SF_EPI_ACT_BF16> (MLP up-projection, M=%d N=3072 K=768)" % M,
+        traffic = None
+        try:   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+            traffic = next(v["traffic_bytes_corrected"] for k, v in pmc.items() if k.startswith("void sf_gemm256_kernel<2>"))
+        except Exception:
+            pass
+        out["roofline"] = {"kernel": "sf_gemm256_kernel<SF_EPI_ACT_BF16> (MLP up-projection + erf-GELU, M=%d N=3072 K=768)" % M,
                            "bound": "mfma", "achieved": up["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(up["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "frac": round(up["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                           "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (profiles/r01_pmc_traffic.json, separate --pmc passes; "
+                                           "FETCH includes Infinity-Cache hits); algorithmic bytes/launch = 197e6 (A 38.5 + W 4.7 + C 154 MB)",
                            "avg_launch_ms": up["ms"], "other_gemms": gemms}
         by = nat.C.c_double()
         att = {}

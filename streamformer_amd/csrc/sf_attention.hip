@@ -27,6 +27,9 @@ SF_DEVICE f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
 // the slot XOR must separate (r>>1, a): 8 values.
 SF_DEVICE int kswz(int key) { return ((key >> 1) & 1) | (((key >> 3) & 3) << 1); }
 
+// V^T LDS swizzle of the spatial kernel (4 bits: rows are padded to a multiple of 16 chunks)
+SF_DEVICE int vswz(int d) { return ((d ^ (d >> 3)) & 7) | (((d >> 3) & 1) << 3); }
+
 // load 8 consecutive elements (bf16 or fp32 storage) as floats
 template <bool F32>
 SF_DEVICE void load8(const void* base, size_t elem_off, float (&out)[8]) {
@@ -85,10 +88,16 @@ SF_DEVICE void store_ctx(bf16_t* ctx_hi, bf16_t* ctx_lo, size_t off, const f32x4
 }
 
 // ================================================================================================
-// spatial attention: block = (frame, head), 4 waves; K and V^T of the head live in LDS
+// spatial attention: block = (frame, head), 8 waves; K and V^T of the head live in LDS.
+// Latency plan: every wave first issues the Q-fragment loads of its (up to two) query tiles, then
+// the block stages K / V^T, so the Q latency hides under the staging; the context rows of a query
+// tile are staged through a per-wave LDS patch and leave as whole 128-byte rows.
 // ================================================================================================
+#define SP_WAVES 8
+#define SP_QT 2     // query tiles per wave: 16 * SP_WAVES * SP_QT = 256 >= 224 queries
+
 template <bool ACC, int MAXNT2>
-__global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int vpitch) {
+__global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnArgs p, int vpitch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -100,10 +109,23 @@ __global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int 
   char* k_lo = k_hi + (ACC ? nkp * 128 : 0);
   char* v_hi = k_lo + nkp * 128;
   char* v_lo = v_hi + (ACC ? HD * vpitch : 0);
+  char* o_st = v_lo + HD * vpitch + wave * (ACC ? 4096 : 2048);   // per-wave [16 rows][128 B] (hi [, lo])
   const size_t row0 = (size_t)frame * N;
+  const int nqt = (N + 15) >> 4;
+
+  // ---- Q fragments of this wave's query tiles (in flight during the staging below) ----------------
+  bf16x8_t qh[SP_QT][2], ql[SP_QT][2];
+#pragma unroll
+  for (int u = 0; u < SP_QT; ++u) {
+    int qi = (wave + u * SP_WAVES) * 16 + l15;
+    qi = qi < N ? qi : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      load_frag<ACC>(p.q, (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[u][ks], ql[u][ks]);
+  }
 
   // ---- stage K (swizzled rows) -------------------------------------------------------------------
-  for (int i = tid; i < nkp * 8; i += 256) {
+  for (int i = tid; i < nkp * 8; i += SP_WAVES * 64) {
     const int key = i >> 3, c = i & 7;
     u32x4_t hv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
     if (key < N) {
@@ -116,8 +138,9 @@ __global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int 
     *reinterpret_cast<u32x4_t*>(k_hi + off) = hv;
     if (ACC) *reinterpret_cast<u32x4_t*>(k_lo + off) = lv;
   }
-  // ---- stage V^T: item = (key pair, 8-wide d chunk) -> 8 dword writes {V[2kp][d], V[2kp+1][d]} -----
-  for (int i = tid; i < (nkp >> 1) * 8; i += 256) {
+  // ---- stage V^T: item = (key pair, 8-wide d chunk) -> 8 dword writes {V[2kp][d], V[2kp+1][d]};
+  //      (bank-swizzled, see below) ------------------------------------------------------------------
+  for (int i = tid; i < (nkp >> 1) * 8; i += SP_WAVES * 64) {
     const int kp = i >> 3, c = i & 7;
     float v0[8], v1[8];
 #pragma unroll
@@ -129,22 +152,20 @@ __global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int 
       unsigned int h0, l0, h1, l1;
       split_bf(v0[j], h0, l0);
       split_bf(v1[j], h1, l1);
-      const int off = (c * 8 + j) * vpitch + kp * 4;
+      // V^T row d = c*8+j, 16-byte key chunks XOR-swizzled by vswz(d): distinct for the 8 rows a wave
+      // writes together (d = 8c+j, c = 0..7) AND for the 16 rows one ds_read_b128 group reads
+      const int d = c * 8 + j;
+      const int off = d * vpitch + ((((kp >> 2) ^ vswz(d)) << 2) + (kp & 3)) * 4;
       *reinterpret_cast<unsigned int*>(v_hi + off) = h0 | (h1 << 16);
       if (ACC) *reinterpret_cast<unsigned int*>(v_lo + off) = l0 | (l1 << 16);
     }
   }
   __syncthreads();
 
-  const int nqt = (N + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    int qi = qt * 16 + l15;
-    const bool qvalid = qi < N;
-    if (!qvalid) qi = N - 1;
-    bf16x8_t qh[2], ql[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      load_frag<ACC>(p.q, (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
+  for (int u = 0; u < SP_QT; ++u) {
+    const int qt = wave + u * SP_WAVES;
+    if (qt >= nqt) break;
 
     // ---- S^T = K Q^T ---------------------------------------------------------------------------
     f32x4_t s[MAXNT2][2];
@@ -162,10 +183,10 @@ __global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int 
             const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(k_hi + off);
             if (ACC) {
               const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(k_lo + off);
-              acc = mfma16(kl, qh[ks], acc);
-              acc = mfma16(kh, ql[ks], acc);
+              acc = mfma16(kl, qh[u][ks], acc);
+              acc = mfma16(kh, ql[u][ks], acc);
             }
-            acc = mfma16(kh, qh[ks], acc);
+            acc = mfma16(kh, qh[u][ks], acc);
           }
         }
         s[kt2][hh] = acc;
@@ -212,7 +233,8 @@ __global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int 
         pack_p<ACC>(s[kt2][0], s[kt2][1], ph, pl);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const int off = (dt * 16 + l15) * vpitch + (kt2 * 32 + g * 8) * 2;
+          const int d = dt * 16 + l15;
+          const int off = d * vpitch + (((kt2 * 4 + g) ^ vswz(d)) << 4);
           const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(v_hi + off);
           if (ACC) {
             const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(v_lo + off);
@@ -223,11 +245,33 @@ __global__ __launch_bounds__(256) void sf_spatial_attn_kernel(SfAttnArgs p, int 
         }
       }
     }
-    if (qvalid) {
+    // ---- context rows: lane holds d = dt*16 + g*4 .. +4 of query l15 -> per-wave LDS patch -> rows --
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        store_ctx<ACC>(p.ctx_hi, p.ctx_lo, (row0 + qi) * p.D + h * HD + dt * 16 + g * 4, o[dt], inv);
+    for (int dt = 0; dt < 4; ++dt) {
+      unsigned int hb[4], lb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf(o[dt][j] * inv, hb[j], lb[j]);
+      const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
+      *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+      if (ACC) *reinterpret_cast<u32x2_t*>(o_st + 2048 + off) = (u32x2_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = it * 64 + lane;           // 128 chunks: 16 rows x 8 chunks of 16 B
+      const int r = idx >> 3, c = idx & 7;
+      const int qi = qt * 16 + r;
+      const int off = r * 128 + ((c ^ (r & 7)) << 4);
+      if (qi < N) {
+        const size_t o_off = (row0 + qi) * p.D + h * HD + c * 8;
+        *reinterpret_cast<u32x4_t*>(p.ctx_hi + o_off) = *reinterpret_cast<const u32x4_t*>(o_st + off);
+        if (ACC) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = *reinterpret_cast<const u32x4_t*>(o_st + 2048 + off);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -245,9 +289,9 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
   const int nkp = (a.N + 31) & ~31;
   if (nkp > 32 * 7) return hipErrorInvalidValue;   // N <= 224 patches (16x16 patches of <= 224 px)
-  const int vp = vt_pitch(nkp);
-  const size_t lds = (size_t)(nkp * 128 + HD * vp) * (accurate ? 2 : 1);
-  const dim3 grid(a.frames * a.heads), block(256);
+  const int vp = (2 * nkp + 255) & ~255;          // V^T row pitch: whole groups of 16 chunks (vswz is 4-bit)
+  const size_t lds = (size_t)(nkp * 128 + HD * vp + SP_WAVES * 2048) * (accurate ? 2 : 1);
+  const dim3 grid(a.frames * a.heads), block(SP_WAVES * 64);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
