@@ -12,14 +12,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define SF_DEVICE __device__ __forceinline__
 
-// round-to-nearest-even fp32 -> bf16 (inputs on this path are finite)
+// round-to-nearest-even fp32 -> bf16: the casts lower to gfx950's v_cvt_pk_bf16_f32 (one VALU op per
+// pair instead of the 4-op integer sequence)
 SF_DEVICE unsigned int f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+  const __bf16 b = (__bf16)f;
+  return (unsigned int)__builtin_bit_cast(unsigned short, b);
 }
 SF_DEVICE float bf2f(unsigned int b) { return __uint_as_float(b << 16); }
-SF_DEVICE unsigned int pack_bf2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+SF_DEVICE unsigned int pack_bf2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the operand split of SF_COMPUTE_BF16X3
 SF_DEVICE void split_bf(float x, unsigned int& hi, unsigned int& lo) {
   hi = f2bf(x);
@@ -55,8 +60,20 @@ SF_DEVICE float erf_fast(float x) {
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
+// erf-GELU with the constants folded: gelu(x) = x * Phi(x), Phi(x) = x >= 0 ? 1 - h : h,
+// h = 0.5 * poly(t) * exp(-x^2/2), t = 1 / (1 + p/sqrt(2) * |x|)   (same A&S 7.1.26 approximation)
+SF_DEVICE float gelu_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, ax, 1.0f));           // 0.3275911 / sqrt(2)
+  float poly = fmaf(t, 0.5307027145f, -0.7265760135f);                            // 0.5 * a5, 0.5 * a4
+  poly = fmaf(poly, t, 0.7107068705f);
+  poly = fmaf(poly, t, -0.142248368f);
+  poly = fmaf(poly, t, 0.127414796f);
+  const float h = poly * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044f);     // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+  return x * (x >= 0.f ? 1.0f - h : h);
+}
 SF_DEVICE float apply_act_fast(float x, int act) {
-  if (act == 0) return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  if (act == 0) return gelu_fast(x);
   return act == 1 ? gelu_tanh(x) : fmaxf(x, 0.0f);
 }
 SF_DEVICE float apply_act(float x, int act) {

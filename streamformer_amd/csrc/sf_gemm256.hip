@@ -223,7 +223,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = apply_act_fast(v[j], 0);   // erf-GELU only (launcher checks)
               }
-              const u32x2_t hv = {f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16)};
+              const u32x2_t hv = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
               *reinterpret_cast<u32x2_t*>(smem + r * 512 + ((((nl >> 3)) ^ (r & 31)) << 4) + (nl & 4) * 2) = hv;
             }
         }
