@@ -304,143 +304,188 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
 }
 
 // ================================================================================================
-// temporal attention: block = (b, n); wave w takes heads w, w+4, ...; K/Q fragments come straight
-// from global memory (one 128-byte line per frame and head), V^T goes through a per-wave LDS patch.
+// temporal attention: ONE WAVE per (b, patch, head) task, four consecutive tasks (adjacent heads =
+// adjacent 128-byte lines) per workgroup, no workgroup barrier.  Every global load of the task
+// (Q, K fragments, V rows) is issued up front so a task costs one memory latency; V^T goes through
+// a wave-private LDS patch, the context rows leave as whole 128-byte segments.
 // Row addressing: see SfAttnArgs.
 // ================================================================================================
 template <bool ACC, int MAXNT2>
-__global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int vpitch) {
+__global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int vpitch, int ntasks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr bool PRELOAD_K = MAXNT2 <= 2;          // K fragments of the whole key range live in registers
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / p.N, n = blockIdx.x % p.N;
+  const int task = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (task >= ntasks) return;
+  const int h = task % p.heads, bn = task / p.heads;
+  const int b = bn / p.N, n = bn % p.N;
   const int Tk = p.Tk, Tq = p.Tq;
   const int tkp = (Tk + 31) & ~31;
   const int nt2 = tkp >> 5;
-  char* v_hi = smem + (size_t)wave * HD * vpitch * (ACC ? 2 : 1);
-  char* v_lo = v_hi + HD * vpitch;
-  const int hiters = (p.heads + 3) >> 2;
+  const int patch = HD * vpitch * (ACC ? 2 : 1) + (ACC ? 4096 : 2048);
+  char* v_hi = smem + (size_t)wave * patch;
+  char* v_lo = v_hi + (ACC ? HD * vpitch : 0);
+  char* o_st = v_lo + HD * vpitch;
 
-  for (int it = 0; it < hiters; ++it) {
-    const int h = it * 4 + wave;
-    const bool hvalid = h < p.heads;
-    __syncthreads();   // previous head's V^T reads are done
-    if (hvalid) {
-      for (int i = lane; i < (tkp >> 1) * 8; i += 64) {
-        const int kp = i >> 3, c = i & 7;
-        float v0[8], v1[8];
+  // ---- issue every load of the task ------------------------------------------------------------------
+  bf16x8_t qh[2], ql[2];
+  {
+    int t = l15 < Tq ? l15 : Tq - 1;
+    const size_t qrow = ((size_t)b * p.Tq_cap + p.q_t0 + t) * p.N + n;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v0[j] = 0.f; v1[j] = 0.f; }
-        if (2 * kp < Tk) load8<ACC>(p.v, (((size_t)b * p.Tcap + 2 * kp) * p.N + n) * p.row_pitch_kv + h * HD + c * 8, v0);
-        if (2 * kp + 1 < Tk) load8<ACC>(p.v, (((size_t)b * p.Tcap + 2 * kp + 1) * p.N + n) * p.row_pitch_kv + h * HD + c * 8, v1);
+    for (int ks = 0; ks < 2; ++ks) load_frag<ACC>(p.q, qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
+  }
+  bf16x8_t kfh[PRELOAD_K ? MAXNT2 : 1][2][2], kfl[PRELOAD_K ? MAXNT2 : 1][2][2];
+  if (PRELOAD_K) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          unsigned int h0, l0, h1, l1;
-          split_bf(v0[j], h0, l0);
-          split_bf(v1[j], h1, l1);
-          const int off = (c * 8 + j) * vpitch + kp * 4;
-          *reinterpret_cast<unsigned int*>(v_hi + off) = h0 | (h1 << 16);
-          if (ACC) *reinterpret_cast<unsigned int*>(v_lo + off) = l0 | (l1 << 16);
-        }
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
+        key = key < Tk ? key : Tk - 1;                     // clamped rows are masked below
+        const size_t krow = ((size_t)b * p.Tcap + key) * p.N + n;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          load_frag<ACC>(p.k, krow * p.row_pitch_kv + h * HD + ks * 32 + g * 8, kfh[kt2][hh][ks], kfl[kt2][hh][ks]);
       }
+  }
+  // V rows -> V^T patch: item = (key pair, 8-wide d chunk)
+  for (int i = lane; i < (tkp >> 1) * 8; i += 64) {
+    const int kp = i >> 3, c = i & 7;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v0[j] = 0.f; v1[j] = 0.f; }
+    if (2 * kp < Tk) load8<ACC>(p.v, (((size_t)b * p.Tcap + 2 * kp) * p.N + n) * p.row_pitch_kv + h * HD + c * 8, v0);
+    if (2 * kp + 1 < Tk) load8<ACC>(p.v, (((size_t)b * p.Tcap + 2 * kp + 1) * p.N + n) * p.row_pitch_kv + h * HD + c * 8, v1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned int h0, l0, h1, l1;
+      split_bf(v0[j], h0, l0);
+      split_bf(v1[j], h1, l1);
+      const int off = (c * 8 + j) * vpitch + kp * 4;
+      *reinterpret_cast<unsigned int*>(v_hi + off) = h0 | (h1 << 16);
+      if (ACC) *reinterpret_cast<unsigned int*>(v_lo + off) = l0 | (l1 << 16);
     }
-    __syncthreads();
-    if (!hvalid) continue;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const int nqt = (Tq + 15) >> 4;
-    for (int qt = 0; qt < nqt; ++qt) {
-      int t = qt * 16 + l15;
-      const bool qvalid = t < Tq;
-      if (!qvalid) t = Tq - 1;
+  const int nqt = (Tq + 15) >> 4;
+  for (int qt = 0; qt < nqt; ++qt) {
+    int t = qt * 16 + l15;
+    const bool qvalid = t < Tq;
+    if (!qvalid) t = Tq - 1;
+    if (qt > 0) {      // further query tiles (T_new > 16): reload Q
       const size_t qrow = ((size_t)b * p.Tq_cap + p.q_t0 + t) * p.N + n;
-      bf16x8_t qh[2], ql[2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        load_frag<ACC>(p.q, qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
-
-      f32x4_t s[MAXNT2][2];
+      for (int ks = 0; ks < 2; ++ks) load_frag<ACC>(p.q, qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
+    }
+    f32x4_t s[MAXNT2][2];
 #pragma unroll
-      for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-          if (kt2 < nt2) {
-            int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
-            key = key < Tk ? key : Tk - 1;                 // clamped rows are masked below
-            const size_t krow = ((size_t)b * p.Tcap + key) * p.N + n;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              bf16x8_t kh, kl;
-              load_frag<ACC>(p.k, krow * p.row_pitch_kv + h * HD + ks * 32 + g * 8, kh, kl);
-              if (ACC) {
-                acc = mfma16(kl, qh[ks], acc);
-                acc = mfma16(kh, ql[ks], acc);
-              }
-              acc = mfma16(kh, qh[ks], acc);
-            }
-          }
-          s[kt2][hh] = acc;
-        }
-      }
-      const int qpos = p.t_past + t;   // absolute frame index of this lane's query
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kt2 * 32 + g * 8 + hh * 4 + r;
-            const bool keep = kt2 < nt2 && key < Tk && (!p.causal || key <= qpos);
-            const float v = keep ? s[kt2][hh][r] * p.scale : -INFINITY;
-            s[kt2][hh][r] = v;
-            mx = fmaxf(mx, v);
-          }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = ACC ? expf(s[kt2][hh][r] - mx) : __expf(s[kt2][hh][r] - mx);
-            s[kt2][hh][r] = e;
-            sum += e;
-          }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-
-      f32x4_t o[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         if (kt2 < nt2) {
-          bf16x8_t ph, pl;
-          pack_p<ACC>(s[kt2][0], s[kt2][1], ph, pl);
+          int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
+          key = key < Tk ? key : Tk - 1;
+          const size_t krow = ((size_t)b * p.Tcap + key) * p.N + n;
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const int off = (dt * 16 + l15) * vpitch + (kt2 * 32 + g * 8) * 2;
-            const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(v_hi + off);
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t kh, kl;
+            if (PRELOAD_K) { kh = kfh[kt2][hh][ks]; kl = kfl[kt2][hh][ks]; }
+            else load_frag<ACC>(p.k, krow * p.row_pitch_kv + h * HD + ks * 32 + g * 8, kh, kl);
             if (ACC) {
-              const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(v_lo + off);
-              o[dt] = mfma16(vl, ph, o[dt]);
-              o[dt] = mfma16(vh, pl, o[dt]);
+              acc = mfma16(kl, qh[ks], acc);
+              acc = mfma16(kh, ql[ks], acc);
             }
-            o[dt] = mfma16(vh, ph, o[dt]);
+            acc = mfma16(kh, qh[ks], acc);
           }
         }
-      }
-      if (qvalid) {
-        const size_t orow = ((size_t)b * Tq + t) * p.N + n;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          store_ctx<ACC>(p.ctx_hi, p.ctx_lo, orow * p.D + h * HD + dt * 16 + g * 4, o[dt], inv);
+        s[kt2][hh] = acc;
       }
     }
+    const int qpos = p.t_past + t;   // absolute frame index of this lane's query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt2 * 32 + g * 8 + hh * 4 + r;
+          const bool keep = kt2 < nt2 && key < Tk && (!p.causal || key <= qpos);
+          const float v = keep ? s[kt2][hh][r] * p.scale : -INFINITY;
+          s[kt2][hh][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = ACC ? expf(s[kt2][hh][r] - mx) : __expf(s[kt2][hh][r] - mx);
+          s[kt2][hh][r] = e;
+          sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+      if (kt2 < nt2) {
+        bf16x8_t ph, pl;
+        pack_p<ACC>(s[kt2][0], s[kt2][1], ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int off = (dt * 16 + l15) * vpitch + (kt2 * 32 + g * 8) * 2;
+          const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(v_hi + off);
+          if (ACC) {
+            const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(v_lo + off);
+            o[dt] = mfma16(vl, ph, o[dt]);
+            o[dt] = mfma16(vh, pl, o[dt]);
+          }
+          o[dt] = mfma16(vh, ph, o[dt]);
+        }
+      }
+    }
+    // ---- context: lane holds d = dt*16 + g*4..+4 of query l15 -> wave patch -> 128-byte row segments
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      unsigned int hb[4], lb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf(o[dt][j] * inv, hb[j], lb[j]);
+      const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
+      *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+      if (ACC) *reinterpret_cast<u32x2_t*>(o_st + 2048 + off) = (u32x2_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = it * 64 + lane;
+      const int r = idx >> 3, c = idx & 7;
+      const int tq = qt * 16 + r;
+      if (tq < Tq) {
+        const size_t o_off = (((size_t)b * Tq + tq) * p.N + n) * p.D + h * HD + c * 8;
+        const int off = r * 128 + ((c ^ (r & 7)) << 4);
+        *reinterpret_cast<u32x4_t*>(p.ctx_hi + o_off) = *reinterpret_cast<const u32x4_t*>(o_st + off);
+        if (ACC) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = *reinterpret_cast<const u32x4_t*>(o_st + 2048 + off);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -449,13 +494,21 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
   const int tkp = (a.Tk + 31) & ~31;
   if (tkp > 32 * 8) return hipErrorInvalidValue;   // <= 256 cached frames per stream
   const int vp = vt_pitch(tkp);
-  const size_t lds = (size_t)4 * HD * vp * (accurate ? 2 : 1);
-  const dim3 grid(a.B * a.N), block(256);
+  const size_t patch = (size_t)HD * vp * (accurate ? 2 : 1) + (accurate ? 4096 : 2048);
+  int waves = 4;
+  while (waves > 1 && patch * waves > 150 * 1024) waves >>= 1;
+  const size_t lds = patch * waves;
+  const int ntasks = a.B * a.N * a.heads;
+  const dim3 grid((ntasks + waves - 1) / waves), block(waves * 64);
 #define SF_TL(ACCV, NT)                                                                              \
   do {                                                                                               \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_kernel<ACCV, NT>),     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
-    hipLaunchKernelGGL((sf_temporal_attn_kernel<ACCV, NT>), grid, block, lds, s, a, vp);               \
+    static bool attr = false;                                                                        \
+    if (!attr) {                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_kernel<ACCV, NT>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+      attr = true;                                                                                   \
+    }                                                                                                \
+    hipLaunchKernelGGL((sf_temporal_attn_kernel<ACCV, NT>), grid, block, lds, s, a, vp, ntasks);     \
   } while (0)
   const int nt2 = tkp >> 5;
   if (accurate) {
