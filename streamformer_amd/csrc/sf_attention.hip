@@ -78,6 +78,53 @@ SF_DEVICE void pack_p(const f32x4_t& a, const f32x4_t& b, bf16x8_t& hi, bf16x8_t
   }
 }
 
+
+// Softmax numerator over the score tiles of one query column, in place.  `valid(kt2, key)` says whether
+// a key takes part.  The scale (> 0) is folded into the exponent: p = 2^((s - max s) * scale * log2 e),
+// one FMA + v_exp_f32 per element; tiles known to be fully valid skip the mask.  Returns sum(p).
+template <bool ACC, int MAXNT2, typename Valid>
+SF_DEVICE float softmax_tiles(f32x4_t (&s)[MAXNT2][2], int nt2, int g, float scale, int first_masked_tile, Valid valid) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+    if (kt2 < nt2) {
+      if (kt2 >= first_masked_tile) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!valid(kt2, kt2 * 32 + g * 8 + hh * 4 + r)) s[kt2][hh][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        mx = fmaxf(mx, fmaxf(fmaxf(s[kt2][hh][0], s[kt2][hh][1]), fmaxf(s[kt2][hh][2], s[kt2][hh][3])));
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float c = scale * 1.44269504088896340736f;
+  const float mc = mx * c;
+  float sum = 0.f;
+#pragma unroll
+  for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = 0.f;
+        if (kt2 < nt2) {
+          const float a = fmaf(s[kt2][hh][r], c, -mc);
+          e = ACC ? exp2f(a) : __builtin_amdgcn_exp2f(a);
+        }
+        s[kt2][hh][r] = e;
+        sum += e;
+      }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  return sum;
+}
+
 template <bool ACC>
 SF_DEVICE void store_ctx(bf16_t* ctx_hi, bf16_t* ctx_lo, size_t off, const f32x4_t& o, float inv) {
   unsigned int h[4], l[4];
@@ -193,33 +240,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
       }
     }
     // ---- softmax over keys (lane: query l15; keys 32*kt2 + 8*g + 4*hh + r) ------------------------
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt2 * 32 + g * 8 + hh * 4 + r;
-          const float v = (kt2 < nt2 && key < N) ? s[kt2][hh][r] * p.scale : -INFINITY;
-          s[kt2][hh][r] = v;
-          mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = ACC ? expf(s[kt2][hh][r] - mx) : __expf(s[kt2][hh][r] - mx);
-          s[kt2][hh][r] = e;
-          sum += e;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    const float sum = softmax_tiles<ACC, MAXNT2>(s, nt2, g, p.scale, N >> 5, [&](int, int key) { return key < N; });
     const float inv = 1.0f / sum;
 
     // ---- O^T = V^T P^T ----------------------------------------------------------------------------
@@ -408,34 +429,9 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int
       }
     }
     const int qpos = p.t_past + t;   // absolute frame index of this lane's query
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt2 * 32 + g * 8 + hh * 4 + r;
-          const bool keep = kt2 < nt2 && key < Tk && (!p.causal || key <= qpos);
-          const float v = keep ? s[kt2][hh][r] * p.scale : -INFINITY;
-          s[kt2][hh][r] = v;
-          mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = ACC ? expf(s[kt2][hh][r] - mx) : __expf(s[kt2][hh][r] - mx);
-          s[kt2][hh][r] = e;
-          sum += e;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    const int causal = p.causal;
+    const float sum = softmax_tiles<ACC, MAXNT2>(s, nt2, g, p.scale, 0,
+                                                 [&](int, int key) { return key < Tk && (!causal || key <= qpos); });
     const float inv = 1.0f / sum;
 
     f32x4_t o[4];
