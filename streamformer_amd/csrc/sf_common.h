@@ -107,6 +107,11 @@ struct SfGemmArgs {
   int ldc;                                  // output row pitch in elements
   // output row remap (KV-cache appends): out_row = (m / grp_rows) * grp_stride + grp_off + m % grp_rows
   int grp_rows, grp_stride, grp_off;
+  // LayerNorm folded into the NEXT Linear (bf16 mode): a residual producer also emits bf16(x) in out_hi
+  // and per-row partial sums {sum x, sum x^2} per 384-column half in ln_stats_out [M][4]; the consumer
+  // (A = bf16(x), W' = W * gamma) finishes y = rstd * (acc - mean * ln_s[n]) + bias' in its epilogue.
+  float* ln_stats_out;
+  const float* ln_stats; const float* ln_s; float ln_eps;
 };
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches 128^2 / 256^2
 hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   // sf_gemm.hip
@@ -126,6 +131,8 @@ hipError_t sf_launch_patchify(const void* pixels, int pixel_is_bf16, bf16_t* out
                               int F, int C, int H, int W, int P, hipStream_t s);
 // fp32 [n] -> bf16 hi (+lo)
 hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
+// fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s);
 // gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)
 struct SfRowIndex { int n; int idx[256]; };
 hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s);

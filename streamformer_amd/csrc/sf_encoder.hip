@@ -58,12 +58,14 @@ struct DevLinear {          // y = x W^T + b ; W [N,K]
   bf16_t* w_hi = nullptr;
   bf16_t* w_lo = nullptr;
   float* bias = nullptr;
+  float* ln_s = nullptr;    // LN-folded variants only: s_n = sum_k bf16(W'[n,k])
   int N = 0, K = 0;
 };
 struct DevLN { float* g = nullptr; float* b = nullptr; };
 struct DevLayer {
   DevLN ln_t, ln_b, ln_a;
   DevLinear t_qkv, t_out, t_dense, t_fused, s_qkv, s_out, up, down;
+  DevLinear t_qkv_f, s_qkv_f, up_f;   // bf16 mode: the preceding LayerNorm folded in (W' = W*gamma, b' = b + W beta)
   float gate_tanh = 0.f;
 };
 
@@ -273,6 +275,29 @@ static int upload_linear(sf_encoder* e, const std::vector<float>& w, const std::
   return SF_OK;
 }
 
+// LayerNorm(gamma, beta) followed by Linear(W, b)  ==  rstd * (x W'^T - mean * s) + b'
+// with W' = W * gamma (per input column), b' = b + W beta, s_n = sum_k W'[n,k] (of the ROUNDED W').
+static int upload_folded_linear(sf_encoder* e, const std::vector<float>& w, const std::vector<float>* bias,
+                                const std::vector<float>& gamma, const std::vector<float>& beta, int N, int K,
+                                DevLinear* out) {
+  std::vector<float> wf(w.size()), bf(N), sn(N);
+  for (int n = 0; n < N; ++n) {
+    double bb = bias ? (double)(*bias)[n] : 0.0, ss = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const float wv = w[(size_t)n * K + k];
+      const float wg = (float)((double)wv * (double)gamma[k]);
+      wf[(size_t)n * K + k] = wg;
+      ss += (double)h_bf2f(h_f2bf(wg));
+      bb += (double)wv * (double)beta[k];
+    }
+    bf[n] = (float)bb;
+    sn[n] = (float)ss;
+  }
+  int rc = upload_linear(e, wf, &bf, N, K, out);
+  if (rc) return rc;
+  return dev_upload<float>(e, sn, &out->ln_s);
+}
+
 static int upload_ln(sf_encoder* e, const std::string& p, DevLN* out) {
   int rc = dev_upload<float>(e, e->host[p + ".weight"].data, &out->g);
   if (rc) return rc;
@@ -318,6 +343,9 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     TRY(upload_ln(e, p + "layernorm_before", &l.ln_b));
     TRY(upload_ln(e, p + "layernorm_after", &l.ln_a));
     TRY(upload_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"), 3 * D, D, &l.t_qkv));
+    if (compute == SF_COMPUTE_BF16)
+      TRY(upload_folded_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"),
+                               H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_f));
     if (e->fused_temporal) {
       // temporal_dense(output.dense(x)) = (W2 W1) x + (W2 b1 + b2)      (modeling:947-954)
       const std::vector<float>& w1 = H(p + "temporal_attention.output.dense.weight");
@@ -350,6 +378,12 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
       merge_lora_into(wo, H(p + "attention.output.dense_lora_a.weight"), H(p + "attention.output.dense_lora_b.weight"), D, D, kLoraRank);
     }
     TRY(upload_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), 3 * D, D, &l.s_qkv));
+    if (compute == SF_COMPUTE_BF16) {
+      TRY(upload_folded_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), H(p + "layernorm_before.weight"),
+                               H(p + "layernorm_before.bias"), 3 * D, D, &l.s_qkv_f));
+      TRY(upload_folded_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"),
+                               H(p + "layernorm_after.weight"), H(p + "layernorm_after.bias"), I, D, &l.up_f));
+    }
     TRY(upload_linear(e, wo, Hopt(p + "attention.output.dense.bias"), D, D, &l.s_out));
     TRY(upload_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"), I, D, &l.up));
     TRY(upload_linear(e, H(p + "output.dense.weight"), Hopt(p + "output.dense.bias"), D, I, &l.down));
@@ -399,7 +433,7 @@ struct Carver {
 };
 
 struct Workspace {
-  float* resid; float* te_rows;
+  float* resid; float* te_rows; float* ln_stats;
   bf16_t *xn_hi, *xn_lo, *ctx_hi, *ctx_lo, *tmp_hi, *tmp_lo, *mid_hi, *mid_lo;
   void* qkv;          // spatial qkv / head kv; fast: bf16 [M,3D], accurate: fp32 [M,3D]
   void* tqkv;         // temporal qkv of the current layer when no cache is used
@@ -417,6 +451,7 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   const size_t wide = D > (size_t)e->Kp ? D : (size_t)e->Kp;
   w.resid = c.take<float>(M * D);
   w.te_rows = c.take<float>((size_t)T * D);
+  w.ln_stats = c.take<float>(M * 4);
   w.xn_hi = c.take<bf16_t>(M * wide);
   w.xn_lo = acc ? c.take<bf16_t>(M * wide) : nullptr;
   w.ctx_hi = c.take<bf16_t>(M * D);
@@ -448,7 +483,8 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
 static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf16_t* a_hi, const bf16_t* a_lo,
                              int M, int epi, hipStream_t s, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
                              const float* resid = nullptr, float alpha = 1.f, int ldc = 0, int grp_rows = 0,
-                             int grp_stride = 0, int grp_off = 0) {
+                             int grp_stride = 0, int grp_off = 0, const float* ln_stats = nullptr,
+                             float* ln_stats_out = nullptr) {
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   const bool split = e->compute == SF_COMPUTE_BF16X3;
@@ -460,7 +496,27 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   g.out_f32 = out_f32; g.out_hi = out_hi; g.out_lo = split ? out_lo : nullptr;
   g.ldc = ldc ? ldc : lin.N;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride; g.grp_off = grp_off;
+  g.ln_stats = ln_stats; g.ln_s = ln_stats ? lin.ln_s : nullptr; g.ln_eps = e->cfg.layer_norm_eps;
+  g.ln_stats_out = ln_stats_out;
+  if (epi == SF_EPI_RESID_F32) g.out_hi = out_hi;     // LN-fold producer: bf16 copy of the new residual rows
   return sf_launch_gemm(g, split, s);
+}
+
+// LayerNorm folding needs the panel kernel as every residual producer (it emits the row statistics)
+// and the 256^2 kernel as every consumer (it applies them): true for the BASELINE shape.
+static bool ln_fold_ok(const sf_encoder* e, int M) {
+  if (e->compute != SF_COMPUTE_BF16) return false;
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = e->D; g.epi = SF_EPI_RESID_F32;
+  g.K = e->D;
+  if (!sf_gemm_panel_supported(g, false)) return false;
+  g.K = e->I;
+  if (!sf_gemm_panel_supported(g, false)) return false;
+  g.epi = SF_EPI_BF16; g.K = e->D; g.N = 3 * e->D;
+  if (!sf_gemm256_supported(g, false)) return false;
+  g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
+  return sf_gemm256_supported(g, false);
 }
 
 static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfRowIndex* idx) {
@@ -517,15 +573,21 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     HIP_TRY(sf_launch_gemm(g, acc, s));
   }
   const size_t hs_stride = (size_t)M * D;
+  // LN folding (bf16 mode, BASELINE-sized M): xn_hi holds bf16(residual), ln_stats the row sums; the
+  // three per-layer LayerNorm launches disappear into the neighbouring GEMM epilogues.
+  const bool fold = ln_fold_ok(e, M) && !streaming;
+  bf16_t* fold_hi = fold ? ws.xn_hi : nullptr;
+  float* fold_st = fold ? ws.ln_stats : nullptr;
+  if (fold) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
   for (int li = 0; li < e->L; ++li) {
     const DevLayer& l = e->layers[li];
     if (hidden_states)
       HIP_TRY(hipMemcpyAsync(hidden_states + li * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
     // ---- temporal attention (modeling:937-958) ---------------------------------------------------
-    HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_t.g, l.ln_t.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    if (!fold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_t.g, l.ln_t.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
     void* tq = layer_tqkv ? layer_tqkv[li] : ws.tqkv;
-    HIP_TRY(run_linear(e, l.t_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)tq, (bf16_t*)tq, nullptr, nullptr, 1.f,
-                       3 * D, T * N, cap * N, t_past * N));
+    HIP_TRY(run_linear(e, fold ? l.t_qkv_f : l.t_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)tq, (bf16_t*)tq, nullptr, nullptr, 1.f,
+                       3 * D, T * N, cap * N, t_past * N, fold_st));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
@@ -537,14 +599,17 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       HIP_TRY(sf_launch_temporal_attention(a, acc, s));
     }
     if (e->fused_temporal) {
-      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, l.gate_tanh));
+      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, l.gate_tanh,
+                         0, 0, 0, 0, nullptr, fold_st));
     } else {
       HIP_TRY(run_linear(e, l.t_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_BF16, s, nullptr, ws.tmp_hi, ws.tmp_lo));
-      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, l.gate_tanh));
+      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, l.gate_tanh,
+                         0, 0, 0, 0, nullptr, fold_st));
     }
     // ---- spatial attention (modeling:962-996) ------------------------------------------------------
-    HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, l.s_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
+    if (!fold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, fold ? l.s_qkv_f : l.s_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr,
+                       nullptr, 1.f, 0, 0, 0, 0, fold_st));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
@@ -553,11 +618,14 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
       HIP_TRY(sf_launch_spatial_attention(a, acc, s));
     }
-    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, 1.f));
+    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
+                       0, 0, 0, 0, nullptr, fold_st));
     // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
-    HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, l.up, ws.xn_hi, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo));
-    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, ws.resid, nullptr, nullptr, ws.resid, 1.f));
+    if (!fold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, fold ? l.up_f : l.up, ws.xn_hi, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
+                       0, 0, 0, 0, fold_st));
+    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
+                       0, 0, 0, 0, nullptr, fold_st));
   }
   if (hidden_states)
     HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));

@@ -40,7 +40,7 @@ SF_DEVICE void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI>
+template <int EPI, bool LNF>
 __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -206,6 +206,15 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
       for (int nt = 0; nt < 2; ++nt)
         bias4[nq][nt] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + n0 + wn * 64 + nq * 32 + nt * 16 + g * 4)
                                : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // LayerNorm folded into this Linear: s_n = sum_k W'[n,k] per output column
+    f32x4_t lns4[2][2];
+    constexpr bool ln_fold = LNF;
+    if (ln_fold) {
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) lns4[nq][nt] = *reinterpret_cast<const f32x4_t*>(p.ln_s + n0 + wn * 64 + nq * 32 + nt * 16 + g * 4);
+    }
     if (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16) {
       // [256 rows][32 chunks of 16 B], chunk index XOR (row & 31)
 #pragma unroll
@@ -213,12 +222,22 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int r = wm * 128 + mq * 64 + mt * 16 + l15;
+          float ln_mu = 0.f, ln_r = 1.f;
+          if (ln_fold) {
+            const int mrow = min(m0 + r, p.M - 1);
+            const f32x4_t st = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 4);
+            const float invd = 1.0f / (float)K;
+            ln_mu = (st[0] + st[2]) * invd;
+            ln_r = rsqrtf((st[1] + st[3]) * invd - ln_mu * ln_mu + p.ln_eps);
+          }
 #pragma unroll
           for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               const int nl = wn * 64 + nq * 32 + nt * 16 + g * 4;
-              f32x4_t v = acc[mq][nq][mt][nt] + bias4[nq][nt];
+              f32x4_t v = acc[mq][nq][mt][nt];
+              if (ln_fold) v = ln_r * (v - ln_mu * lns4[nq][nt]);
+              v += bias4[nq][nt];
               if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = apply_act_fast(v[j], 0);   // erf-GELU only (launcher checks)
@@ -306,17 +325,26 @@ hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
   const size_t lds = 8 * PIECE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-#define SF_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SF_ATTR(SF_EPI_F32) SF_ATTR(SF_EPI_BF16) SF_ATTR(SF_EPI_ACT_BF16) SF_ATTR(SF_EPI_RESID_F32)
+#define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
+    SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true)
 #undef SF_ATTR
     attr_set = true;
   }
   const dim3 grid(g256_grid()), block(G_THREADS);
+  const bool lnf = a.ln_stats != nullptr;
+  if (lnf && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return hipErrorInvalidValue;
   switch (a.epi) {
-    case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32>), grid, block, lds, s, a, tiles); break;
-    case SF_EPI_BF16: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16>), grid, block, lds, s, a, tiles); break;
-    case SF_EPI_ACT_BF16: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16>), grid, block, lds, s, a, tiles); break;
-    case SF_EPI_RESID_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_RESID_F32>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32, false>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_BF16:
+      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, true>), grid, block, lds, s, a, tiles);
+      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, false>), grid, block, lds, s, a, tiles);
+      break;
+    case SF_EPI_ACT_BF16:
+      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, true>), grid, block, lds, s, a, tiles);
+      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, false>), grid, block, lds, s, a, tiles);
+      break;
+    case SF_EPI_RESID_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_RESID_F32, false>), grid, block, lds, s, a, tiles); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -134,20 +134,24 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
   for (int nt = 0; nt < P_NT; ++nt)
     bias4[nt] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + n0 + wave * 48 + nt * 16 + eg * 4)
                        : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // staging image: [64 rows][96 chunks of 16 B], chunk XOR (row & 31) inside its 32-chunk group
+  // staging image: [64 rows][96 chunks of 16 B], chunk XOR (row & 31) inside its 32-chunk group.
+  // Copy-out: wave w owns rows w, w+8, ... of the group; a row is 96 chunks = lanes 0..63 + lanes 0..31,
+  // so the LayerNorm partial statistics of the row half (sum x, sum x^2 over these 384 columns) are
+  // two deterministic wave reductions.
+  const int elane = tid_e & 63;
 #pragma unroll
   for (int grp = 0; grp < 4; ++grp) {
-    constexpr int kIters = 12;                       // 64 rows x 96 chunks / 512 threads
-    const int iters = grp < 3 ? kIters : 3;          // the last group holds one m-tile (16 rows)
+    constexpr int kRows = 8;                         // rows per wave in a 64-row group
+    const int rows_w = grp < 3 ? kRows : 2;          // the last group holds one m-tile (16 rows)
     // residual rows of this group: all loads in flight before the staging pass (latency overlap)
-    f32x4_t res[kIters];
+    f32x4_t res[kRows][2];
 #pragma unroll
-    for (int it = 0; it < kIters; ++it) {
-      const int idx = it * P_THREADS + tid_e;
-      const int r = idx / 96, c = idx % 96;
-      const int m = m0 + grp * 64 + r;
-      res[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      if (it < iters && m < m_end) res[it] = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m * (size_t)p.ldc + n0 + c * 4);
+    for (int j = 0; j < kRows; ++j) {
+      const int m = m0 + grp * 64 + wave + 8 * j;
+      const bool ok = j < rows_w && m < m_end;
+      const float* rp = p.resid + (size_t)m * (size_t)p.ldc + n0;
+      res[j][0] = ok ? *reinterpret_cast<const f32x4_t*>(rp + elane * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      res[j][1] = (ok && elane < 32) ? *reinterpret_cast<const f32x4_t*>(rp + 256 + elane * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -164,13 +168,34 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < kIters; ++it) {
-      const int idx = it * P_THREADS + tid_e;
-      const int r = idx / 96, c = idx % 96;
+    for (int j = 0; j < kRows; ++j) {
+      const int r = wave + 8 * j;
       const int m = m0 + grp * 64 + r;
-      if (it < iters && m < m_end) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1536 + (((c & ~31) | ((c ^ r) & 31)) << 4));
-        *reinterpret_cast<f32x4_t*>(p.out_f32 + (size_t)m * (size_t)p.ldc + n0 + c * 4) = res[it] + p.alpha * v;
+      if (j < rows_w && m < m_end) {                 // wave-uniform
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+          const int c = hp * 64 + elane;
+          if (hp == 0 || elane < 32) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1536 + (((c & ~31) | ((c ^ r) & 31)) << 4));
+            const f32x4_t x = res[j][hp] + p.alpha * v;
+            const size_t o = (size_t)m * (size_t)p.ldc + n0 + c * 4;
+            *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = x;
+            if (p.out_hi) {
+              *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+              s1 += (x[0] + x[1]) + (x[2] + x[3]);
+              s2 += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+            }
+          }
+        }
+        if (p.ln_stats_out) {
+          s1 = wave_sum(s1);
+          s2 = wave_sum(s2);
+          if (elane == 0) {
+            p.ln_stats_out[(size_t)m * 4 + nh * 2 + 0] = s1;
+            p.ln_stats_out[(size_t)m * 4 + nh * 2 + 1] = s2;
+          }
+        }
       }
     }
     __syncthreads();

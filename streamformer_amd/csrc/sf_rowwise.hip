@@ -162,6 +162,33 @@ hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hip
 }
 
 // ------------------------------------------------------------------------------------------------
+// LN-fold entry: bf16 copy of the rows + {sum x, sum x^2} (used once per forward, on the embeddings)
+__global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
+                                                               float* __restrict__ stats, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = D >> 2;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < nv; c += 64) {
+    const f32x4_t v = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D)[c];
+    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    *reinterpret_cast<u32x2_t*>(xb + (size_t)row * D + (size_t)c * 4) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) *reinterpret_cast<f32x4_t*>(stats + (size_t)row * 4) = (f32x4_t){s1, s2, 0.f, 0.f};
+}
+
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (D % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, stats, rows, D);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sf_gather_rows_kernel(const float* __restrict__ table,
                                                              float* __restrict__ out, SfRowIndex idx, int D) {
   const int t = blockIdx.x;

@@ -308,18 +308,36 @@ def test_base_full_tensor_vs_oracle(sa, base_models, mode):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_baseline_batch8_properties(sa, base_models, mode):
-    """BASELINE config #2 size (8 x 16 x 224^2): clips are independent (batch row == the clip alone,
-    bit-exact) and the causal property holds at full size."""
+    """BASELINE config #2 size (8 x 16 x 224^2).  At this size the bf16 mode runs the LayerNorm-folded
+    schedule (panel + 256^2 GEMMs), so it is checked against the oracle directly, plus the properties
+    the domain offers: a clip's output does not depend on the other clips of the batch (bit-exact),
+    equals the clip run alone up to kernel-schedule rounding, and obeys causality at full size."""
     m = base_models[mode]
+    cfg = siglip_base()
+    sd = make_state_dict(cfg, seed=0)
     g = torch.Generator().manual_seed(123)
-    x = torch.randn(8, 16, 3, 224, 224, generator=g).cuda()
+    xc = torch.randn(8, 16, 3, 224, 224, generator=g)
+    x = xc.cuda()
     out = m(x)
     assert out.last_hidden_state.shape == (8, 16, 196, 768) and out.pooler_output.shape == (8, 16, 768)
     assert torch.isfinite(out.last_hidden_state).all() and torch.isfinite(out.pooler_output).all()
+    lt, pt = (ACC_TOL, ACC_TOL) if mode == "fp32" else (BF16_LHS, BF16_POOL)
     for i in (0, 5):
+        want = O.forward(sd, cfg, xc[i:i + 1])
+        d1 = maxabs(out.last_hidden_state[i], want["last_hidden_state"][0])
+        d2 = maxabs(out.pooler_output[i], want["pooler_output"][0])
+        print(f"[{mode}] B=8 clip {i}: max-abs lhs {d1:.3e} pooler {d2:.3e}")
+        assert d1 <= lt and d2 <= pt
         solo = m(x[i:i + 1])
-        assert torch.equal(solo.last_hidden_state[0], out.last_hidden_state[i])
-        assert torch.equal(solo.pooler_output[0], out.pooler_output[i])
+        assert maxabs(solo.last_hidden_state[0], out.last_hidden_state[i]) <= (1e-4 if mode == "fp32" else 4e-2)
+    # other clips' content does not leak into clip 3 (same batch shape => same schedule => bit-exact)
+    x3 = x.clone()
+    x3[:3] = 0.5 * x3[:3] + 1.0
+    x3[4:] = -x3[4:]
+    out3 = m(x3)
+    assert torch.equal(out3.last_hidden_state[3], out.last_hidden_state[3])
+    assert torch.equal(out3.pooler_output[3], out.pooler_output[3])
+    assert torch.equal(m(x).last_hidden_state, out.last_hidden_state)          # deterministic
     x2 = x.clone()
     x2[:, 12:] = -x2[:, 12:]
     out2 = m(x2)
