@@ -36,6 +36,22 @@ SF_DEVICE float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Same sum on the DPP path (six VALU adds with row_shr / row_bcast modifiers + one v_readlane instead
+// of six dependent ds_bpermute round trips).  All 64 lanes must be active; the result is wave-uniform.
+template <int CTRL, int ROW_MASK>
+SF_DEVICE float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+SF_DEVICE float wave_sum_dpp(float v) {
+  v = dpp_add<0x111, 0xf>(v);   // row_shr:1   inclusive scan inside each row of 16 lanes
+  v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);   // row_shr:8   lane 15 of each row = row total
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 = wave total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 SF_DEVICE float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -506,6 +507,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
 // and the 256^2 kernel as every consumer (it applies them): true for the BASELINE shape.
 static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16) return false;
+  if (getenv("SF_DISABLE_LN_FOLD")) return false;        // A/B switch for measurements
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = e->D; g.epi = SF_EPI_RESID_F32;

@@ -189,8 +189,8 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
           }
         }
         if (p.ln_stats_out) {
-          s1 = wave_sum(s1);
-          s2 = wave_sum(s2);
+          s1 = wave_sum_dpp(s1);
+          s2 = wave_sum_dpp(s2);
           if (elane == 0) {
             p.ln_stats_out[(size_t)m * 4 + nh * 2 + 0] = s1;
             p.ln_stats_out[(size_t)m * 4 + nh * 2 + 1] = s2;

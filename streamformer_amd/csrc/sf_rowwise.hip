@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
       v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  const float mean = wave_sum(s) / (float)D;
+  const float mean = wave_sum_dpp(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = rsqrtf(wave_sum_dpp(q) / (float)D + eps);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __re
     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     *reinterpret_cast<u32x2_t*>(xb + (size_t)row * D + (size_t)c * 4) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
+  s1 = wave_sum_dpp(s1);
+  s2 = wave_sum_dpp(s2);
   if (lane == 0) *reinterpret_cast<f32x4_t*>(stats + (size_t)row * 4) = (f32x4_t){s1, s2, 0.f, 0.f};
 }
 
