@@ -497,6 +497,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   g.out_f32 = out_f32; g.out_hi = out_hi; g.out_lo = split ? out_lo : nullptr;
   g.ldc = ldc ? ldc : lin.N;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride; g.grp_off = grp_off;
+  if (grp_rows > 0 && grp_stride == grp_rows && grp_off == 0) g.grp_rows = 0;   // identity remap (full clip)
   g.ln_stats = ln_stats; g.ln_s = ln_stats ? lin.ln_s : nullptr; g.ln_eps = e->cfg.layer_norm_eps;
   g.ln_stats_out = ln_stats_out;
   if (epi == SF_EPI_RESID_F32) g.out_hi = out_hi;     // LN-fold producer: bf16 copy of the new residual rows

@@ -337,7 +337,10 @@ def test_baseline_batch8_properties(sa, base_models, mode):
     out3 = m(x3)
     assert torch.equal(out3.last_hidden_state[3], out.last_hidden_state[3])
     assert torch.equal(out3.pooler_output[3], out.pooler_output[3])
-    assert torch.equal(m(x).last_hidden_state, out.last_hidden_state)          # deterministic
+    for _ in range(10):      # race screen for the count-placed LDS hand-offs: every repeat bit-identical
+        again = m(x)
+        assert torch.equal(again.last_hidden_state, out.last_hidden_state)
+        assert torch.equal(again.pooler_output, out.pooler_output)
     x2 = x.clone()
     x2[:, 12:] = -x2[:, 12:]
     out2 = m(x2)
