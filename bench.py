@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = usable host cores (affinity, cgroup quota)")
     ap.add_argument("--profile", action="store_true", help="timed steps + roofline hooks only (for rocprofv3 runs)")
+    ap.add_argument("--streams", type=int, default=1, help="batches in flight: consecutive steps alternate over this many HIP streams")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run of the N>1 path with every rank on cuda:0")
     return ap.parse_args()
@@ -77,16 +78,26 @@ def usable_cores() -> int:
     return n
 
 
-def timed_steps(model, x, steps, warmup, dist, world):
-    for _ in range(warmup):
-        model(x)
+def timed_steps(model, x, steps, warmup, dist, world, nstreams=1):
+    """K forwards over batches of clips.  With nstreams > 1, consecutive (independent) steps are issued
+    round-robin on separate HIP streams, each with its own workspace: the HBM-bound phases of one batch
+    overlap the MFMA-bound phases of the other.  Still K steps of the same batch size."""
+    streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream()]
+    def step(i):
+        if nstreams > 1:
+            with torch.cuda.stream(streams[i % nstreams]):
+                model(x)
+        else:
+            model(x)
+    for i in range(max(warmup, nstreams)):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        model(x)
+    for i in range(steps):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -134,7 +145,7 @@ def main():
     model = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
     model.load_state_dict(sd)
     model.to(dev).eval()
-    dt = timed_steps(model, x, args.steps, args.warmup, dist, world)
+    dt = timed_steps(model, x, args.steps, args.warmup, dist, world, args.streams)
     frames = world * B * T * args.steps
     value = frames / dt
 
@@ -145,9 +156,14 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SigLIP-base StreamFormer encoder forward, {B} clips x 16 x 224^2 per GPU, "
                                "random-init de-trivialised weights, causal temporal attention",
-                   "global_batch_clips": B * world, "frames_per_clip": T, "parallelism": f"dp{world}"},
+                   "global_batch_clips": B * world, "frames_per_clip": T, "parallelism": f"dp{world}",
+                   "steps_in_flight": args.streams},
         "e2e_mfma_frac": round(value / world * GFLOP_PER_FRAME / 1e3 / PEAK_BF16_TFLOPS, 4),
+        "streams_in_flight": args.streams,
     }
+    if args.streams > 1:
+        dt1 = timed_steps(model, x, args.steps, 2, dist, world, 1)
+        out["single_stream"] = {"value": round(frames / dt1, 1), "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ------

@@ -476,6 +476,7 @@ class TimesformerMultiTaskingModelSigLIP:
         streaming = bool(use_cache) or past_key_values is not None
         with torch.cuda.device(dev):
             stream = nat.current_stream_handle(dev)
+            skey = int(stream or 0)          # one workspace per HIP stream: concurrent forwards never share scratch
             lhs = torch.empty(B, T, N, D, dtype=torch.float32, device=dev)
             pool = torch.empty(B, T, D, dtype=torch.float32, device=dev)
             nbytes = nat.C.c_size_t()
@@ -490,7 +491,7 @@ class TimesformerMultiTaskingModelSigLIP:
                 if (cache.batch, cache.H, cache.W) != (B, H, W):
                     raise ValueError("past_key_values was created for a different batch size / resolution")
                 nat.check(nat.lib.sf_stream_workspace_bytes(self._handle, cache._h, T, nat.C.byref(nbytes)))
-                ws = self._workspace(("s", B, T, H, W), nbytes.value)
+                ws = self._workspace(("s", B, T, H, W, skey), nbytes.value)
                 nat.check(nat.lib.sf_forward_stream(self._handle, cache._h, x.data_ptr(), _TORCH2SF[x.dtype], T,
                                                     lhs.data_ptr(), pool.data_ptr(), nat.ptr(pos), ws.data_ptr(),
                                                     ws.numel(), stream))
@@ -499,7 +500,7 @@ class TimesformerMultiTaskingModelSigLIP:
                 return BaseModelOutputWithPast(lhs, past_key_values=cache, pooler_output=pool)
             hs = torch.empty(L + 1, B, T, N, D, dtype=torch.float32, device=dev) if output_hidden_states else None
             nat.check(nat.lib.sf_workspace_bytes(self._handle, B, T, H, W, nat.C.byref(nbytes)))
-            ws = self._workspace(("f", B, T, H, W), nbytes.value)
+            ws = self._workspace(("f", B, T, H, W, skey), nbytes.value)
             nat.check(nat.lib.sf_forward(self._handle, x.data_ptr(), _TORCH2SF[x.dtype], B, T, H, W, lhs.data_ptr(),
                                          pool.data_ptr(), nat.ptr(hs), nat.ptr(pos), ws.data_ptr(), ws.numel(), stream))
         hidden = None
