@@ -17,7 +17,6 @@
 #include "sf_common.h"
 
 #define P_THREADS 512
-#define P_MT 13
 #define P_NT 3
 #define P_SLOT_BYTES 40960
 #define P_A_BYTES 16384
@@ -36,7 +35,8 @@ SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
   return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
 }
 
-__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile) {
+template <int P_MT>
+__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
   const int K = p.K;
   const int nkt = K >> 5;
   // tile = (row panel, column half); the two halves of a row panel sit on the same XCD (b, b+8)
-  const int bid = blockIdx.x;
+  for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
   const int panel = (bid >> 4) * 8 + (bid & 7), nh = (bid >> 3) & 1;
   const int m0 = panel * rows_per_tile;
   const int m_end = min(m0 + rows_per_tile, p.M);
   const int n0 = nh * 384;
-  if (m0 >= p.M) return;
+  if (m0 >= p.M) continue;
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_hi, 0, (unsigned)p.M * (unsigned)K * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, (unsigned)p.N * (unsigned)K * 2u, 0x00020000);
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
   // two deterministic wave reductions.
   const int elane = tid_e & 63;
 #pragma unroll
-  for (int grp = 0; grp < 4; ++grp) {
+  for (int grp = 0; grp < (P_MT + 3) / 4; ++grp) {
     constexpr int kRows = 8;                         // rows per wave in a 64-row group
-    const int rows_w = grp < 3 ? kRows : 2;          // the last group holds one m-tile (16 rows)
+    const int rows_w = (grp + 1) * 4 <= P_MT ? kRows : 2 * (P_MT - grp * 4);   // a partial last group: 16 rows per m-tile
     // residual rows of this group: all loads in flight before the staging pass (latency overlap)
     f32x4_t res[kRows][2];
 #pragma unroll
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     }
     __syncthreads();
   }
+  }   // tiles
 }
 
 static int panel_cus() {
@@ -214,25 +215,49 @@ static int panel_cus() {
   return cus;
 }
 
+// Tiling plan: P row panels (a multiple of CUs/2, so that the 2P tiles fill whole rounds), rows = ceil(M/P)
+// per panel, MT = the smallest instantiated m-tile count covering `rows`.
+struct PanelPlan { int panels, rows, mt, ok; };
+static PanelPlan panel_plan(int M) {
+  PanelPlan pl = {0, 0, 0, 0};
+  const int half = panel_cus() / 2;
+  int panels = ((M + 207) / 208 + half - 1) / half * half;
+  if (panels <= 0) return pl;
+  const int rows = (M + panels - 1) / panels;
+  static const int kMt[4] = {2, 4, 7, 13};
+  for (int i = 0; i < 4; ++i)
+    if (rows <= 16 * kMt[i]) { pl.mt = kMt[i]; break; }
+  if (!pl.mt) return pl;
+  pl.panels = panels; pl.rows = rows; pl.ok = rows * 4 >= pl.mt * 16 * 3;   // >= 75 % of the MFMA rows are real
+  return pl;
+}
+
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split) {
   if (split || a.epi != SF_EPI_RESID_F32 || a.N != 768 || a.grp_rows > 0) return false;
   if (a.K % 32 || a.K < 128) return false;
   if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32)) return false;
-  const int panels = panel_cus() / 2;
-  const int rows = (a.M + panels - 1) / panels;
-  // one round of (rows x 384) tiles; worthwhile only when the 208-row MFMA tile is mostly real rows
-  return rows <= 16 * P_MT && rows > 16 * (P_MT - 3);
+  return panel_plan(a.M).ok != 0;
 }
 
 hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s) {
+  const PanelPlan pl = panel_plan(a.M);
+  if (!pl.ok) return hipErrorInvalidValue;
   const int cus = panel_cus();
-  const int panels = cus / 2;
-  const int rows = (a.M + panels - 1) / panels;
+  const int ntiles = pl.panels * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P_SLOT_BYTES);
+#define SF_PATTR(MT) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_panel_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P_SLOT_BYTES);
+    SF_PATTR(2) SF_PATTR(4) SF_PATTR(7) SF_PATTR(13)
+#undef SF_PATTR
     attr_set = true;
   }
-  hipLaunchKernelGGL(sf_gemm_panel_kernel, dim3(cus), dim3(P_THREADS), 4 * P_SLOT_BYTES, s, a, rows);
+  const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
+  const size_t lds = 4 * P_SLOT_BYTES;
+  switch (pl.mt) {
+    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles); break;
+    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles); break;
+    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles); break;
+    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles); break;
+  }
   return hipGetLastError();
 }
