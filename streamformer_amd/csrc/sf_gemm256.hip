@@ -19,6 +19,7 @@
 //   * LDS image of a piece is [128 rows][64 k] bf16, lane-linear for the DMA, with the 16-byte slot
 //     XOR (row>>1)&7 applied to the SOURCE address and mirrored on ds_read_b128.
 #include "sf_common.h"
+#include <cstdlib>
 
 #define G_THREADS 512
 #define PIECE_BYTES 16384
@@ -40,8 +41,13 @@ SF_DEVICE void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, bool LNF>
+// BM = 256, or 224 when that tiles M with fewer idle tile slots (M = 25088 = 112 x 224: the qkv GEMM runs
+// 4 full rounds of 224-row tiles instead of 3.45 -> 4 rounds of 256-row ones).  With BM = 224 a wave row
+// owns 112 rows: quadrant mq = 0 has 4 m-tiles, mq = 1 has 3 (its A piece is padded with clamped rows).
+template <int EPI, bool LNF, int BM>
 __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles) {
+  constexpr int HR = BM / 2;                 // rows per wave row
+  constexpr int MT1 = (BM == 256) ? 4 : 3;   // m-tiles of the second row quadrant
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
   for (int round = 0;; ++round) {
     const int tile = (round * 8 + xcd) * cpx + slot_in_xcd;
     if (tile >= ntiles) break;
-    const int m0 = (tile / tiles_n) << 8, n0 = (tile % tiles_n) << 8;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
 
     // ---- per-lane DMA source offsets (elements), two 16-byte chunks per piece --------------------
     unsigned offA[2][2], offB[2][2];
@@ -77,7 +83,9 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
       const int kc = slot ^ ((prow >> 1) & 7);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        int ar = m0 + (prow >> 6) * 128 + q * 64 + (prow & 63);
+        int rr = prow & 63;
+        if (q == 1 && rr >= MT1 * 16) rr = MT1 * 16 - 1;            // padding rows of the short quadrant
+        int ar = m0 + (prow >> 6) * HR + q * 64 + rr;
         ar = ar < p.M ? ar : p.M - 1;
         offA[q][i] = ((unsigned)ar * (unsigned)K + kc * 8) * 2u;      // byte offsets (buffer voffset)
         int br = n0 + (prow >> 5) * 64 + q * 32 + (prow & 31);
@@ -122,7 +130,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[mt][ks] = rd_frag(pc, wm * 64 + mt * 16 + l15, ks * 4 + g);
+        for (int ks = 0; ks < 2; ++ks)
+          if (mt < (mq ? MT1 : 4)) af[mt][ks] = rd_frag(pc, wm * 64 + mt * 16 + l15, ks * 4 + g);
     };
     auto mma = [&](int mq, int nq, bf16x8_t (&b)[2][2]) {
       __builtin_amdgcn_s_setprio(1);
@@ -131,7 +140,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mq][nq][mt][nt] = mfma16b(b[nt][ks], af[mt][ks], acc[mq][nq][mt][nt]);
+          for (int nt = 0; nt < 2; ++nt)
+            if (mt < (mq ? MT1 : 4)) acc[mq][nq][mt][nt] = mfma16b(b[nt][ks], af[mt][ks], acc[mq][nq][mt][nt]);
       __builtin_amdgcn_s_setprio(0);
     };
 
@@ -220,8 +230,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int r = wm * 128 + mq * 64 + mt * 16 + l15;
+        for (int mt = 0; mt < (mq ? MT1 : 4); ++mt) {
+          const int r = wm * HR + mq * 64 + mt * 16 + l15;
           float ln_mu = 0.f, ln_r = 1.f;
           if (ln_fold) {
             const int mrow = min(m0 + r, p.M - 1);
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
         }
       __syncthreads();
 #pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
+      for (int it = 0; it < BM / 16; ++it) {
         const int idx = it * G_THREADS + tid;
         const int r = idx >> 5, c = idx & 31;
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * 512 + ((c ^ (r & 31)) << 4));
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < (mq ? MT1 : 4); ++mt) {
           const int r = wm * 64 + mt * 16 + l15;
 #pragma unroll
           for (int nq = 0; nq < 2; ++nq)
@@ -282,8 +292,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
           const int idx = it * G_THREADS + tid;
           const int r = idx >> 6, c = idx & 63;
           f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + ((c ^ (r & 63)) << 4));
-          const int m = m0 + (r >> 6) * 128 + mq * 64 + (r & 63);
-          if (m < p.M) {
+          const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
+          if (m < p.M && (r & 63) < (mq ? MT1 : 4) * 16) {
             size_t orow = (size_t)m;
             if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
             const size_t o = orow * (size_t)p.ldc + n0 + c * 4;
@@ -320,12 +330,13 @@ static int g256_grid() {
   return cus;
 }
 
-hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
-  const int tiles = ((a.M + 255) / 256) * (a.N / 256);
+template <int BM>
+static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
+  const int tiles = ((a.M + BM - 1) / BM) * (a.N / 256);
   const size_t lds = 8 * PIECE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-#define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
     SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true)
 #undef SF_ATTR
@@ -335,17 +346,25 @@ hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
   const bool lnf = a.ln_stats != nullptr;
   if (lnf && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return hipErrorInvalidValue;
   switch (a.epi) {
-    case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32, false>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32, false, BM>), grid, block, lds, s, a, tiles); break;
     case SF_EPI_BF16:
-      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, true>), grid, block, lds, s, a, tiles);
-      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, false>), grid, block, lds, s, a, tiles);
+      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, true, BM>), grid, block, lds, s, a, tiles);
+      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, false, BM>), grid, block, lds, s, a, tiles);
       break;
     case SF_EPI_ACT_BF16:
-      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, true>), grid, block, lds, s, a, tiles);
-      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, false>), grid, block, lds, s, a, tiles);
+      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, true, BM>), grid, block, lds, s, a, tiles);
+      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, false, BM>), grid, block, lds, s, a, tiles);
       break;
-    case SF_EPI_RESID_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_RESID_F32, false>), grid, block, lds, s, a, tiles); break;
+    case SF_EPI_RESID_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_RESID_F32, false, BM>), grid, block, lds, s, a, tiles); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
+  // pick the row-tile height that wastes fewer tile slots of the persistent grid
+  const int g = g256_grid(), nt = a.N / 256;
+  auto cost = [&](int bm) { const int tiles = ((a.M + bm - 1) / bm) * nt; return (long)((tiles + g - 1) / g) * bm; };
+  if (cost(224) < cost(256) && !getenv("SF_G256_NO_BM224")) return launch_bm<224>(a, s);   // env: A/B switch
+  return launch_bm<256>(a, s);
 }
