@@ -181,7 +181,7 @@ def main():
         try:   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pmc = json.load(f)["kernels"]
-            traffic = next(v["traffic_bytes_corrected"] for k, v in pmc.items() if k.startswith("void sf_gemm256_kernel<2, true>"))
+            traffic = next(v["traffic_bytes_corrected"] for k, v in pmc.items() if k.startswith("void sf_gemm256_kernel<2, true"))
         except Exception:
             pass
         out["roofline"] = {"kernel": "sf_gemm256_kernel<SF_EPI_ACT_BF16, LN-folded> (LayerNorm + MLP up-projection + erf-GELU, M=%d N=3072 K=768)" % M,
