@@ -148,6 +148,74 @@ int sf_localization_loss(const float* pooler_dev, const float* label_emb_dev, co
                          float* loss_dev, float* grad_pooler_dev, float* grad_scalars_dev,
                          sf_stream stream);
 
+/* ---- training step (BASELINE configs #3 / #4) ------------------------------
+ * Replaces, for one micro-batch: the autograd graph of TimesformerMultiTaskingModelSigLIP.forward
+ * (modeling:1299-1354) as driven by train_one_epoch_multi_task (tools/finetune_tools.py:395-573:
+ * forward -> task-head loss -> loss/update_freq -> backward -> optimizer step every update_freq
+ * micro-steps) and torch.optim.AdamW as optim_factory.py:59-104 configures it (no weight decay for
+ * 1-D parameters and "*.bias"; frozen parameters skipped).
+ *
+ * State layout: ALL parameters live in ONE caller-owned flat fp32 device buffer (so the gradient
+ * buffer of the same layout can be all-reduced by RCCL in a few large slices); each
+ * segment starts on a multiple of 64 floats.  Trainable parameters come first, in model order
+ * (embeddings, layers 0..L-1, post_layernorm, head, extra scalars), frozen ones (the spatial
+ * qkv / output.dense base weights when freeze_spatial=1, modeling:1284-1297) after them.
+ * Names are the reference state_dict keys; `extra.<i>` are caller-defined trainable
+ * scalars (task heads' logit_scale / logit_bias, modeling:1363-1364).
+ * Compute mode is SF_COMPUTE_BF16 (bf16 MFMA operands, fp32 accumulation, fp32 master weights,
+ * fp32 residual stream and its gradient).                                                        */
+typedef struct sf_trainer sf_trainer;
+int sf_trainer_create(const sf_config* cfg, int device, int freeze_spatial, int n_extra, sf_trainer** out);
+void sf_trainer_destroy(sf_trainer* tr);
+int sf_trainer_num_params(const sf_trainer* tr);
+/* shape_out: up to 4 dims; trainable/decay: the optim_factory.py:70-77 grouping                 */
+int sf_trainer_param_info(const sf_trainer* tr, int index, char* name_out, int name_cap, int64_t* offset_out,
+                          int64_t* numel_out, int64_t* shape_out, int* ndim_out, int* trainable_out,
+                          int* decay_out);
+/* total floats of the flat buffer, and the length of its trainable prefix                        */
+int sf_trainer_total_floats(const sf_trainer* tr, int64_t* total_out, int64_t* trainable_out);
+/* backward runs in stages so the caller can all-reduce finished gradient slices while earlier
+ * layers are still being differentiated: stage 0 = pooling head + post_layernorm,
+ * stage 1+k = layer L-1-k, stage L+1 = embeddings.  The slice [offset, offset+numel) of the
+ * gradient buffer is final when the stage returns.                                              */
+int sf_trainer_num_stages(const sf_trainer* tr);
+int sf_trainer_stage_range(const sf_trainer* tr, int stage, int64_t* offset_out, int64_t* numel_out);
+/* fp32 master -> bf16 working weights (row-major and transposed copies, LoRA merged as
+ * W + B A (modeling:541-545), temporal_dense scaled by tanh(gate) (modeling:954-958)).  Call after
+ * every optimizer step; params_dev must stay valid until the next call.                          */
+int sf_trainer_sync_weights(sf_trainer* tr, const float* params_dev, sf_stream stream);
+int sf_trainer_workspace_bytes(const sf_trainer* tr, int B, int T, size_t* out);
+/* forward with every activation the backward needs kept in the workspace                         */
+int sf_trainer_forward(sf_trainer* tr, const void* pixels_dev, int pixel_dtype, int B, int T,
+                       float* last_hidden_dev, float* pooler_dev, void* workspace_dev,
+                       size_t workspace_bytes, sf_stream stream);
+/* grads_dev += d loss / d params for stages [stage_first, stage_last]; d_pooler_dev fp32 [B,T,D],
+ * d_last_hidden_dev fp32 [B,T,N,D] or NULL.  Must follow sf_trainer_forward on the same workspace. */
+int sf_trainer_backward(sf_trainer* tr, const float* d_pooler_dev, const float* d_last_hidden_dev,
+                        float* grads_dev, int stage_first, int stage_last, void* workspace_dev,
+                        size_t workspace_bytes, sf_stream stream);
+/* torch.optim.AdamW update of the trainable prefix; `step` counts from 1; grad_scale multiplies
+ * the gradient first (1/world for averaging, clip coefficient, ...).                             */
+int sf_trainer_adamw_step(sf_trainer* tr, float* params_dev, const float* grads_dev, float* exp_avg_dev,
+                          float* exp_avg_sq_dev, int step, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, float grad_scale, sf_stream stream);
+/* out_dev[0] = sum of squares of the trainable gradient prefix (for clip_grad_norm_)             */
+int sf_trainer_grad_sumsq(sf_trainer* tr, const float* grads_dev, float* out_dev, sf_stream stream);
+
+/* single backward operators (parity tests).  bf16 tensors are raw uint16 device buffers.         */
+/* C[N1,N2] = alpha * dY^T X  (+ C) : dy [M,ldy], x [M,ldx] bf16; out fp32 [N1,ldo]               */
+int sf_op_wgrad(const void* dy_dev, int ldy, const void* x_dev, int ldx, int M, int N1, int N2, float alpha,
+                int accumulate, float* out_dev, int ldo, sf_stream stream);
+/* attention backward; layout 0 = spatial (nseq sequences of L consecutive token rows),
+ * 1 = temporal (token row of (b, t, n) = (b*L + t)*seq_rows + n, nseq = B*seq_rows).
+ * qkv/d_qkv bf16 [rows, 3D], o/d_o bf16 [rows, D].                                               */
+int sf_op_attention_bwd(const void* qkv_dev, const void* o_dev, const void* d_o_dev, void* d_qkv_dev, int layout,
+                        int nseq, int L, int seq_rows, int heads, int causal, sf_stream stream);
+/* LayerNorm backward: dx = g_in + dLN(x; dy), d_gamma/d_beta accumulated                          */
+int sf_op_layernorm_bwd(const float* x_dev, const float* dy_dev, const float* gamma_dev, const float* g_in_dev,
+                        float* dx_dev, float* d_gamma_dev, float* d_beta_dev, int rows, int D, float eps,
+                        sf_stream stream);
+
 /* ---- introspection for bench/roofline ------------------------------------------------------- */
 /* Enqueue `iters` back-to-back launches of the dominant GEMM (the MLP up-projection shape of the
  * loaded model at M rows) between two HIP events on `stream` and return the mean launch time.   */

@@ -245,6 +245,12 @@ def to_patch_major(h: Tensor) -> Tensor:
 @torch.no_grad()
 def forward(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
             collect: Optional[dict] = None, cache: Optional[List[dict]] = None) -> Dict[str, Tensor]:
+    """Inference entry: :func:`forward_graph` under ``torch.no_grad()``."""
+    return forward_graph(sd, cfg, pixels, output_hidden_states, collect, cache)
+
+
+def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
+                  collect: Optional[dict] = None, cache: Optional[List[dict]] = None) -> Dict[str, Tensor]:
     """Full-clip forward (``cache is None``) or one streaming call (``cache`` = list of per-layer dicts).
 
     Returns ``last_hidden_state [B,T,N,D]``, ``pooler_output [B,T,D]`` and, on request,

@@ -60,6 +60,23 @@ SIGNATURES = {
     "sf_op_attention_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sf_retrieval_loss": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "sf_localization_loss": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "sf_trainer_create": (_I, [C.POINTER(SfConfig), _I, _I, _I, C.POINTER(_P)]),
+    "sf_trainer_destroy": (None, [_P]),
+    "sf_trainer_num_params": (_I, [_P]),
+    "sf_trainer_param_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "sf_trainer_total_floats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sf_trainer_num_stages": (_I, [_P]),
+    "sf_trainer_stage_range": (_I, [_P, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sf_trainer_sync_weights": (_I, [_P, _P, _P]),
+    "sf_trainer_workspace_bytes": (_I, [_P, _I, _I, C.POINTER(_SZ)]),
+    "sf_trainer_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "sf_trainer_backward": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
+    "sf_trainer_adamw_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P]),
+    "sf_trainer_grad_sumsq": (_I, [_P, _P, _P, _P]),
+    "sf_op_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "sf_op_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sf_op_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "sf_bench_gemm": (_I, [_P, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double)]),
     "sf_bench_attention": (_I, [_P, _I, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),

@@ -1,0 +1,565 @@
+// Attention backward for the training step (torch autograd through modeling_timesformer_siglip.py:590-612
+// temporal causal attention, :703-714 spatial attention, :1145-1149 pooling-head attention).
+//
+//   S = scale * Q K^T (+ causal mask),  P = softmax_row(S),  O = P V
+//   dV = P^T dO,  dP = dO V^T,  Delta_i = sum_e dO_ie O_ie,  dS = P o (dP - Delta) * scale
+//   dQ = dS K,  dK = dS^T Q
+//
+// gfx950 design: the four row-major [tokens][64] bf16 images (Q, K, V, dO) of one (sequence, head)
+// problem live in LDS (XOR-swizzled 16-byte chunks).  Products that contract over the head dim read
+// row fragments (ds_read_b128); products that contract over tokens (dV, dK, dQ) need a token-major
+// B operand, which ds_read_b64_tr_b16 delivers straight from the same row-major images — no
+// transposed copies.  The probabilities never touch LDS: the 16x16 MFMA result layout (lane = one
+// column, 4 consecutive rows) of two neighbouring tiles is exactly the 8-value A operand of the next
+// product, in a k order that the transposed reads reproduce.
+//   phase A: row statistics (log-sum-exp in base 2) and Delta             — waves own query tiles
+//   phase B: dK, dV                                                        — waves own 32-key blocks
+//   phase C: dQ (scores recomputed in the swapped orientation)             — waves own 32-query blocks
+// No atomics: every output element has one owner, results are bit-reproducible.
+// Spatial: one 8-wave workgroup per (frame, head), L <= 224.  Temporal: one WAVE per (batch, patch,
+// head) sequence with wave-private images, L <= 32.
+#include "sf_train.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+#define LOG2E 1.4426950408889634f
+#define NEG_BIG (-1.0e30f)
+
+SF_DEVICE f32x4_t ab_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+// chunk swizzle: bijective in row bits 1..3 (row fragments of 16 rows conflict-free), and its upper
+// two bits bijective in row bits 1..2 (the 8 rows of a half-wave transposed read conflict-free)
+SF_DEVICE int bswz(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
+SF_DEVICE int img_off(int row, int chunk) { return row * 128 + ((chunk ^ bswz(row)) << 4); }
+
+SF_DEVICE bf16x8_t row_frag(const char* img, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8_t*>(img + img_off(row, chunk));
+}
+// token-major fragment: lane (l15 = column e of tile et, g) gets rows {r0+4g..+3} and {r0+16+4g..+3}
+template <bool TWO>
+SF_DEVICE bf16x8_t tr_frag(const char* img, int r0, int et, int lane) {
+  const int t16 = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * g + (t16 >> 2);
+  const int off = img_off(row, 2 * et + ((t16 & 3) >> 1)) + ((t16 & 1) << 3);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + off));
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  if (TWO) {
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + off + 16 * 128));
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  } else {
+    f[4] = f[5] = f[6] = f[7] = 0;
+  }
+  return f;
+}
+SF_DEVICE bf16x8_t pack_a(const f32x4_t lo, const f32x4_t hi) {
+  u32x4_t u = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+struct BwdView {
+  const char *q, *k, *v, *d_o;     // LDS images
+  float* lse2;                     // [rows] base-2 log-sum-exp of the scaled scores
+  float* delta;                    // [rows]
+  char* patch;                     // wave-private [32][64] bf16 output staging
+  int L;
+  int causal;
+  float sl2;                       // scale * log2(e)
+  float scale;
+};
+
+// ---- phase A: statistics of query tile `it` (16 queries), swapped scores: lane = query l15 ----------
+template <bool TWO>
+SF_DEVICE void phase_a_tile(const BwdView& w, int it, int nt, int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+  const int qi = it * 16 + l15;
+  bf16x8_t qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = row_frag(w.q, it * 16 + l15, ks * 4 + g);
+  float m = NEG_BIG, l = 0.f;
+  for (int jt = 0; jt < nt; ++jt) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) acc = ab_mfma(row_frag(w.k, jt * 16 + l15, ks * 4 + g), qf[ks], acc);
+    float s[4];
+    float tm = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kj = jt * 16 + 4 * g + r;
+      const bool ok = kj < w.L && !(w.causal && kj > qi);
+      s[r] = ok ? acc[r] * w.sl2 : NEG_BIG;
+      tm = fmaxf(tm, s[r]);
+    }
+    const float mn = fmaxf(m, tm);
+    float add = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) add += s[r] > 0.5f * NEG_BIG ? __builtin_amdgcn_exp2f(s[r] - mn) : 0.f;
+    l = l * __builtin_amdgcn_exp2f(m - mn) + add;
+    m = mn;
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, m2);
+    l = l * __builtin_amdgcn_exp2f(m - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
+    m = mn;
+  }
+  if (g == 0) w.lse2[qi] = (qi < w.L && l > 0.f) ? m + __log2f(l) : -NEG_BIG;   // padding queries: p = 0
+}
+
+SF_DEVICE void store_patch(char* patch, int row, int col, float v) {
+  *reinterpret_cast<bf16_t*>(patch + img_off(row, col >> 3) + ((col & 7) << 1)) = (bf16_t)f2bf(v);
+}
+
+// copy the wave's 32-row patch to global rows tok0 + r (r < nrows valid), 64 columns at `dst_col`
+SF_DEVICE void patch_to_global(const char* patch, bf16_t* dst, size_t ld, long row_base, long row_step, int tok0, int L,
+                               int rows, int lane) {
+  for (int c = lane; c < rows * 8; c += 64) {
+    const int r = c >> 3, ch = c & 7;
+    const int tok = tok0 + r;
+    if (tok < L) {
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + img_off(r, ch));
+      *reinterpret_cast<u32x4_t*>(dst + (size_t)(row_base + tok * row_step) * ld + ch * 8) = v;
+    }
+  }
+}
+
+// ---- phase B: dK, dV of key block jb (32 keys) -----------------------------------------------------
+template <bool TWO>
+SF_DEVICE void phase_b_block(const BwdView& w, int jb, int nb, f32x4_t (&dk)[2][4], f32x4_t (&dv)[2][4], int lane) {
+  constexpr int NT2 = TWO ? 2 : 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16x8_t kf[2][2], vf[2][2];
+#pragma unroll
+  for (int jt2 = 0; jt2 < NT2; ++jt2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[jt2][ks] = row_frag(w.k, jb * 32 + jt2 * 16 + l15, ks * 4 + g);
+      vf[jt2][ks] = row_frag(w.v, jb * 32 + jt2 * 16 + l15, ks * 4 + g);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dk[a][b] = dv[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int ib0 = w.causal ? jb : 0;       // queries before the key block see none of its keys
+  for (int ib = ib0; ib < nb; ++ib) {
+    f32x4_t p[2][2], ds[2][2];             // [query tile][key tile]
+#pragma unroll
+    for (int it2 = 0; it2 < 2; ++it2) {
+      if (it2 < NT2) {
+        const int q0 = ib * 32 + it2 * 16;
+        bf16x8_t qf[2], gf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[ks] = row_frag(w.q, q0 + l15, ks * 4 + g);
+          gf[ks] = row_frag(w.d_o, q0 + l15, ks * 4 + g);
+        }
+        const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(w.lse2 + q0 + 4 * g);
+        const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(w.delta + q0 + 4 * g);
+#pragma unroll
+        for (int jt2 = 0; jt2 < 2; ++jt2) {
+          if (jt2 < NT2) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              s = ab_mfma(qf[ks], kf[jt2][ks], s);
+              dp = ab_mfma(gf[ks], vf[jt2][ks], dp);
+            }
+            const int kj = jb * 32 + jt2 * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qi = q0 + 4 * g + r;
+              const bool ok = kj < w.L && !(w.causal && kj > qi);
+              const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * w.sl2 - lse[r]) : 0.f;
+              p[it2][jt2][r] = pv;
+              ds[it2][jt2][r] = pv * (dp[r] - dl[r]) * w.scale;
+            }
+          } else {
+            p[it2][jt2] = ds[it2][jt2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      } else {
+        p[it2][0] = p[it2][1] = ds[it2][0] = ds[it2][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      const bf16x8_t gt = tr_frag<TWO>(w.d_o, ib * 32, et, lane);
+      const bf16x8_t qt = tr_frag<TWO>(w.q, ib * 32, et, lane);
+#pragma unroll
+      for (int jt2 = 0; jt2 < NT2; ++jt2) {
+        dv[jt2][et] = ab_mfma(pack_a(p[0][jt2], p[1][jt2]), gt, dv[jt2][et]);
+        dk[jt2][et] = ab_mfma(pack_a(ds[0][jt2], ds[1][jt2]), qt, dk[jt2][et]);
+      }
+    }
+  }
+}
+
+// ---- phase C: dQ of query block ib (32 queries), swapped scores --------------------------------------
+template <bool TWO>
+SF_DEVICE void phase_c_block(const BwdView& w, int ib, int nb, f32x4_t (&dq)[2][4], int lane) {
+  constexpr int NT2 = TWO ? 2 : 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16x8_t qf[2][2], gf[2][2];
+  float lse[2], dl[2];
+#pragma unroll
+  for (int it2 = 0; it2 < NT2; ++it2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[it2][ks] = row_frag(w.q, ib * 32 + it2 * 16 + l15, ks * 4 + g);
+      gf[it2][ks] = row_frag(w.d_o, ib * 32 + it2 * 16 + l15, ks * 4 + g);
+    }
+    lse[it2] = w.lse2[ib * 32 + it2 * 16 + l15];
+    dl[it2] = w.delta[ib * 32 + it2 * 16 + l15];
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dq[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int jb1 = w.causal ? ib + 1 : nb;    // keys after the query block are masked for all its queries
+  for (int jb = 0; jb < jb1; ++jb) {
+    f32x4_t ds[2][2];                         // [key tile][query tile]
+#pragma unroll
+    for (int jt2 = 0; jt2 < 2; ++jt2) {
+      if (jt2 < NT2) {
+        const int k0 = jb * 32 + jt2 * 16;
+        bf16x8_t kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          kf[ks] = row_frag(w.k, k0 + l15, ks * 4 + g);
+          vf[ks] = row_frag(w.v, k0 + l15, ks * 4 + g);
+        }
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2) {
+          if (it2 < NT2) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              s = ab_mfma(kf[ks], qf[it2][ks], s);
+              dp = ab_mfma(vf[ks], gf[it2][ks], dp);
+            }
+            const int qi = ib * 32 + it2 * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kj = k0 + 4 * g + r;
+              const bool ok = kj < w.L && !(w.causal && kj > qi);
+              const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * w.sl2 - lse[it2]) : 0.f;
+              ds[jt2][it2][r] = pv * (dp[r] - dl[it2]) * w.scale;
+            }
+          } else {
+            ds[jt2][it2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      } else {
+        ds[jt2][0] = ds[jt2][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      const bf16x8_t kt = tr_frag<TWO>(w.k, jb * 32, et, lane);
+#pragma unroll
+      for (int it2 = 0; it2 < NT2; ++it2) dq[it2][et] = ab_mfma(pack_a(ds[0][it2], ds[1][it2]), kt, dq[it2][et]);
+    }
+  }
+}
+
+template <bool TWO>
+SF_DEVICE void tiles_to_patch(char* patch, const f32x4_t (&t)[2][4], int lane) {
+  constexpr int NT2 = TWO ? 2 : 1;
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < NT2; ++a)
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) store_patch(patch, a * 16 + 4 * g + r, et * 16 + l15, t[a][et][r]);
+}
+
+// stage rows [0, rows_pad) of one image: token t < L from global, zeros beyond; `nthreads` cooperate
+SF_DEVICE void stage_image(char* img, const bf16_t* src, size_t ld, long row_base, long row_step, int L, int rows_pad,
+                           int tid, int nthreads) {
+  for (int c = tid; c < rows_pad * 8; c += nthreads) {
+    const int r = c >> 3, ch = c & 7;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (r < L) v = *reinterpret_cast<const u32x4_t*>(src + (size_t)(row_base + r * row_step) * ld + ch * 8);
+    *reinterpret_cast<u32x4_t*>(img + img_off(r, ch)) = v;
+  }
+}
+// dO image + Delta_i = sum_e dO_ie * O_ie (8 lanes per row, xor-shuffle reduce)
+SF_DEVICE void stage_do_delta(char* img, float* delta, const bf16_t* d_o, const bf16_t* o, size_t ld, long row_base,
+                              long row_step, int L, int rows_pad, int tid, int nthreads) {
+  for (int c0 = 0; c0 < rows_pad * 8; c0 += nthreads) {
+    const int c = c0 + tid;
+    const int r = c >> 3, ch = c & 7;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    float dot = 0.f;
+    if (c < rows_pad * 8) {
+      if (r < L) {
+        const size_t off = (size_t)(row_base + r * row_step) * ld + ch * 8;
+        v = *reinterpret_cast<const u32x4_t*>(d_o + off);
+        const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(o + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dot += bf2f(v[i] & 0xffffu) * bf2f(ov[i] & 0xffffu);
+          dot += bf2f(v[i] >> 16) * bf2f(ov[i] >> 16);
+        }
+      }
+      *reinterpret_cast<u32x4_t*>(img + img_off(r, ch)) = v;
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (c < rows_pad * 8 && ch == 0) delta[r] = dot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// spatial: one workgroup (8 waves) per (frame, head)
+// ------------------------------------------------------------------------------------------------
+#define SB_THREADS 512
+#define SB_ROWS 224
+#define SB_IMG (SB_ROWS * 128)
+
+__global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+  const int L = a.L;
+  const int nt = (L + 15) >> 4, nb = (L + 31) >> 5;
+  const int rows_pad = nb * 32;
+  char* iq = smem;
+  char* ik = smem + SB_IMG;
+  char* iv = smem + 2 * SB_IMG;
+  char* ig = smem + 3 * SB_IMG;
+  float* lse2 = reinterpret_cast<float*>(smem + 4 * SB_IMG);
+  float* delta = lse2 + SB_ROWS;
+  char* patch = smem + 4 * SB_IMG + 2 * SB_ROWS * 4 + wave * 4096;
+
+  const long row_base = (long)f * L;
+  const bf16_t* qkv = a.qkv + h * 64;
+  stage_image(iq, qkv, a.ld_qkv, row_base, 1, L, rows_pad, tid, SB_THREADS);
+  stage_image(ik, qkv + a.D, a.ld_qkv, row_base, 1, L, rows_pad, tid, SB_THREADS);
+  stage_image(iv, qkv + 2 * a.D, a.ld_qkv, row_base, 1, L, rows_pad, tid, SB_THREADS);
+  stage_do_delta(ig, delta, a.d_o + h * 64, a.o + h * 64, a.ld_o, row_base, 1, L, rows_pad, tid, SB_THREADS);
+  __syncthreads();
+
+  BwdView w;
+  w.q = iq; w.k = ik; w.v = iv; w.d_o = ig; w.lse2 = lse2; w.delta = delta; w.patch = patch;
+  w.L = L; w.causal = a.causal; w.scale = a.scale; w.sl2 = a.scale * LOG2E;
+
+  for (int it = wave; it < 2 * nb; it += 8) phase_a_tile<true>(w, it, nt, lane);
+  __syncthreads();
+
+  bf16_t* dqkv = a.d_qkv + h * 64;
+  for (int jb = wave; jb < nb; jb += 8) {
+    f32x4_t dk[2][4], dv[2][4];
+    phase_b_block<true>(w, jb, nb, dk, dv, lane);
+    tiles_to_patch<true>(patch, dk, lane);
+    patch_to_global(patch, dqkv + a.D, a.ld_qkv, row_base, 1, jb * 32, L, 32, lane);
+    tiles_to_patch<true>(patch, dv, lane);
+    patch_to_global(patch, dqkv + 2 * a.D, a.ld_qkv, row_base, 1, jb * 32, L, 32, lane);
+  }
+  for (int ib = wave; ib < nb; ib += 8) {
+    f32x4_t dq[2][4];
+    phase_c_block<true>(w, ib, nb, dq, lane);
+    tiles_to_patch<true>(patch, dq, lane);
+    patch_to_global(patch, dqkv, a.ld_qkv, row_base, 1, ib * 32, L, 32, lane);
+  }
+}
+
+hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s) {
+  if (a.L <= 0 || a.L > SB_ROWS || a.nseq <= 0 || a.D != a.heads * 64) return hipErrorInvalidValue;
+  if ((a.ld_qkv % 8) || (a.ld_o % 8)) return hipErrorInvalidValue;
+  const size_t lds = 4 * SB_IMG + 2 * SB_ROWS * 4 + 8 * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// temporal: one wave per (batch, patch, head) sequence; wave-private images of NP rows
+// ------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void sf_temporal_attn_bwd_kernel(SfAttnBwdArgs a, int nprob) {
+  constexpr bool TWO = NP > 16;
+  constexpr int IMG = NP * 128;
+  constexpr int PER_WAVE = 4 * IMG + 2 * NP * 4 + IMG;      // images, lse2/delta, patch
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int prob = blockIdx.x * 4 + wave;
+  if (prob >= nprob) return;
+  const int h = prob % a.heads;
+  const int bn = prob / a.heads;
+  const int n = bn % a.seq_rows, b = bn / a.seq_rows;
+  const int L = a.L;
+  char* base = smem + wave * PER_WAVE;
+  char* iq = base;
+  char* ik = base + IMG;
+  char* iv = base + 2 * IMG;
+  char* ig = base + 3 * IMG;
+  float* lse2 = reinterpret_cast<float*>(base + 4 * IMG);
+  float* delta = lse2 + NP;
+  char* patch = base + 4 * IMG + 2 * NP * 4;
+
+  const long row_base = (long)b * L * a.seq_rows + n, row_step = a.seq_rows;
+  const bf16_t* qkv = a.qkv + h * 64;
+  stage_image(iq, qkv, a.ld_qkv, row_base, row_step, L, NP, lane, 64);
+  stage_image(ik, qkv + a.D, a.ld_qkv, row_base, row_step, L, NP, lane, 64);
+  stage_image(iv, qkv + 2 * a.D, a.ld_qkv, row_base, row_step, L, NP, lane, 64);
+  stage_do_delta(ig, delta, a.d_o + h * 64, a.o + h * 64, a.ld_o, row_base, row_step, L, NP, lane, 64);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  BwdView w;
+  w.q = iq; w.k = ik; w.v = iv; w.d_o = ig; w.lse2 = lse2; w.delta = delta; w.patch = patch;
+  w.L = L; w.causal = a.causal; w.scale = a.scale; w.sl2 = a.scale * LOG2E;
+  constexpr int NT = NP / 16;
+  for (int it = 0; it < NT; ++it) phase_a_tile<TWO>(w, it, NT, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  bf16_t* dqkv = a.d_qkv + h * 64;
+  {
+    f32x4_t dk[2][4], dv[2][4];
+    phase_b_block<TWO>(w, 0, 1, dk, dv, lane);
+    tiles_to_patch<TWO>(patch, dk, lane);
+    patch_to_global(patch, dqkv + a.D, a.ld_qkv, row_base, row_step, 0, L, NP, lane);
+    tiles_to_patch<TWO>(patch, dv, lane);
+    patch_to_global(patch, dqkv + 2 * a.D, a.ld_qkv, row_base, row_step, 0, L, NP, lane);
+  }
+  {
+    f32x4_t dq[2][4];
+    phase_c_block<TWO>(w, 0, 1, dq, lane);
+    tiles_to_patch<TWO>(patch, dq, lane);
+    patch_to_global(patch, dqkv, a.ld_qkv, row_base, row_step, 0, L, NP, lane);
+  }
+}
+
+hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s) {
+  if (a.L <= 0 || a.L > 32 || a.nseq <= 0 || a.seq_rows <= 0 || a.D != a.heads * 64) return hipErrorInvalidValue;
+  if ((a.ld_qkv % 8) || (a.ld_o % 8)) return hipErrorInvalidValue;
+  const int nprob = a.nseq * a.heads;
+  const dim3 grid((nprob + 3) / 4), block(256);
+  if (a.L <= 16) {
+    const size_t lds = 4 * (size_t)(5 * 16 * 128 + 2 * 16 * 4);
+    hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<16>, grid, block, lds, s, a, nprob);
+  } else {
+    const size_t lds = 4 * (size_t)(5 * 32 * 128 + 2 * 32 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<32>, grid, block, lds, s, a, nprob);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling head: one query per (frame, head); one wave per problem, lanes over keys
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_pool_attn_bwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                               const float* __restrict__ d_ctx, bf16_t* __restrict__ d_kv,
+                                                               float* __restrict__ dq_frames, int frames, int N, int heads,
+                                                               int D) {
+  __shared__ float sq[4][64], sg[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int prob = blockIdx.x * 4 + wave;
+  if (prob >= frames * heads) return;
+  const int f = prob / heads, h = prob % heads;
+  sq[wave][lane] = q[h * 64 + lane];
+  sg[wave][lane] = d_ctx[(size_t)f * D + h * 64 + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int ld = 2 * D;
+  const int per = (N + 63) / 64;             // keys per lane (<= 4 for N <= 256)
+  float s[4], dp[4];
+  float m = NEG_BIG;
+  for (int i = 0; i < 4; ++i) {
+    s[i] = NEG_BIG; dp[i] = 0.f;
+    const int n = i * 64 + lane;
+    if (i < per && n < N) {
+      const bf16_t* kr = kv + ((size_t)f * N + n) * ld + h * 64;
+      const bf16_t* vr = kr + D;
+      float a = 0.f, b = 0.f;
+      for (int c = 0; c < 8; ++c) {
+        const u32x4_t kk = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
+        const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vr + c * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a += bf2f(kk[j] & 0xffffu) * sq[wave][c * 8 + 2 * j] + bf2f(kk[j] >> 16) * sq[wave][c * 8 + 2 * j + 1];
+          b += bf2f(vv[j] & 0xffffu) * sg[wave][c * 8 + 2 * j] + bf2f(vv[j] >> 16) * sg[wave][c * 8 + 2 * j + 1];
+        }
+      }
+      s[i] = a; dp[i] = b;
+      m = fmaxf(m, a);
+    }
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    s[i] = s[i] > 0.5f * NEG_BIG ? __expf(s[i] - m) : 0.f;
+    l += s[i];
+  }
+  l = wave_sum(l);
+  const float inv = 1.0f / l;
+  float pd = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    s[i] *= inv;                              // p
+    pd += s[i] * dp[i];
+  }
+  pd = wave_sum(pd);
+  float dq[64];
+#pragma unroll
+  for (int e = 0; e < 64; ++e) dq[e] = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int n = i * 64 + lane;
+    if (i < per && n < N) {
+      const float p = s[i];
+      const float ds = p * (dp[i] - pd);
+      const size_t row = ((size_t)f * N + n) * ld + h * 64;
+      const bf16_t* kr = kv + row;
+      for (int c = 0; c < 8; ++c) {
+        const u32x4_t kk = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
+        u32x4_t ok, ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = c * 8 + 2 * j;
+          dq[e] += ds * bf2f(kk[j] & 0xffffu);
+          dq[e + 1] += ds * bf2f(kk[j] >> 16);
+          ok[j] = pack_bf2(ds * sq[wave][e], ds * sq[wave][e + 1]);
+          ov[j] = pack_bf2(p * sg[wave][e], p * sg[wave][e + 1]);
+        }
+        *reinterpret_cast<u32x4_t*>(d_kv + row + c * 8) = ok;
+        *reinterpret_cast<u32x4_t*>(d_kv + row + D + c * 8) = ov;
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int e = 0; e < 64; ++e) {
+    const float t = wave_sum(dq[e]);
+    if (lane == e) mine = t;
+  }
+  dq_frames[(size_t)f * D + h * 64 + lane] = mine;
+}
+
+hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const float* d_ctx, bf16_t* d_kv,
+                                        float* dq_frames, int frames, int N, int heads, int D, hipStream_t s) {
+  if (N <= 0 || N > 256 || D != heads * 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_pool_attn_bwd_kernel, dim3((frames * heads + 3) / 4), dim3(256), 0, s, q, kv, d_ctx, d_kv, dq_frames,
+                     frames, N, heads, D);
+  return hipGetLastError();
+}

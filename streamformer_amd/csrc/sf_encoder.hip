@@ -1,7 +1,7 @@
 // C-ABI implementation: handle, weight packing, and the launch schedule of the encoder forward
 // (reference TimesformerMultiTaskingModelSigLIP.forward, modeling:1299-1354; layer body :934-1004;
 // streaming copy vqa_enc:1316-1392).  See include/streamformer_hip.h for the contract.
-#include "../../include/streamformer_hip.h"
+#include "sf_internal.h"
 #include "sf_common.h"
 
 #include <cmath>
@@ -20,18 +20,14 @@ static const int kLoraRank = 32;  // modeling:1280-1281
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
-static int set_err(int code, const char* fmt, ...) {
+int sf_set_err(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess) return set_err(SF_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
+#define set_err sf_set_err
 
 // ------------------------------------------------------------------------------------------------
 // host-side helpers

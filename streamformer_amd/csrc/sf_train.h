@@ -1,0 +1,109 @@
+// Kernel launchers of the training step (backward pass + optimizer) — SURVEY.md §8 f-1.
+// Reference semantics: torch autograd through modeling_timesformer_siglip.py:934-1004 (layer),
+// :1141-1154 (pooling head), :413-457 (embeddings); AdamW as run_finetuning_multi_task.py:429-433 /
+// optim_factory.py:59-104 configure it.
+#pragma once
+#include "sf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient GEMM ("TN"):  C[N1,N2] (+)= sum_m dY[m,N1] * X[m,N2]
+// Both operands are token-major bf16 exactly as the forward/backward kernels leave them; the
+// contraction runs over token rows, fragments come out of row-major LDS tiles through
+// ds_read_b64_tr_b16.  Split over M with fp32 partials + a deterministic reduction.
+// ------------------------------------------------------------------------------------------------
+struct SfWgradArgs {
+  const bf16_t* dy; int ldy;       // [M, ldy], columns [0, N1)
+  const bf16_t* x; int ldx;        // [M, ldx], columns [0, N2)
+  int M, N1, N2;
+  float* out; int ldo;             // [N1, ldo] fp32
+  int accumulate;                  // out += result (else out = result)
+  float alpha;                     // result scaled by alpha
+  float* partial;                  // scratch, >= sf_wgrad_partial_floats(...) floats
+};
+size_t sf_wgrad_partial_floats(int M, int N1, int N2);
+hipError_t sf_launch_wgrad(const SfWgradArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// attention backward (softmax(QK^T * scale [+ causal mask]) V), bf16 storage, fp32 math
+// ------------------------------------------------------------------------------------------------
+struct SfAttnBwdArgs {
+  const bf16_t* qkv; int ld_qkv;   // token rows [rows, 3D]: q | k | v column blocks
+  const bf16_t* o;  int ld_o;      // forward context [rows, D]
+  const bf16_t* d_o;               // gradient wrt context [rows, D]   (same pitch as o)
+  bf16_t* d_qkv;                   // [rows, 3D] (same pitch as qkv)
+  int heads, D;
+  float scale;
+  int L;                           // sequence length (spatial: patches per frame; temporal: frames)
+  int nseq;                        // spatial: frames; temporal: B * N sequences
+  int seq_rows;                    // temporal only: N (token row of (b, t, n) = (b*L + t)*N + n)
+  int causal;
+};
+hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);    // L <= 224
+hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);   // L <= 32
+// pooling head: q fp32 [D] (projected, scaled), kv bf16 [F*N, 2D], d_ctx fp32 [F, D]
+//   -> d_kv bf16 [F*N, 2D], dq_frames fp32 [F, D] (gradient wrt the scaled q, per frame)
+hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const float* d_ctx, bf16_t* d_kv,
+                                        float* dq_frames, int frames, int N, int heads, int D, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// row-wise / elementwise
+// ------------------------------------------------------------------------------------------------
+// act = gelu(pre)   (erf form, modeling:819-824)
+hipError_t sf_launch_gelu_fwd(const bf16_t* pre, bf16_t* act, size_t n, hipStream_t s);
+// d = d * gelu'(pre)   in place
+hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_t s);
+// LayerNorm backward over rows of x (statistics recomputed): g_out = (g_in ? g_in : 0) + dL/dx;
+// d_gamma += sum_rows dy * xhat, d_beta += sum_rows dy.   partial: >= sf_ln_bwd_partial_floats(D)
+size_t sf_ln_bwd_partial_floats(int D);
+hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* g_out,
+                            float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
+                            hipStream_t s);
+// out[c] += alpha * sum_r x[r, c]   (bias gradients); partial >= sf_colsum_partial_floats(cols)
+size_t sf_colsum_partial_floats(int cols);
+hipError_t sf_launch_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float alpha, float* out,
+                                 int accumulate, float* partial, hipStream_t s);
+// out[o, :] (+)= sum_{r < R} in[(o % n_a) * stride_a + (o / n_a) * stride_b + r * stride_r, :]  (fp32 rows of D)
+hipError_t sf_launch_sum_rows(const float* in, float* out, int n_out, int n_a, long stride_a, long stride_b,
+                              int R, long stride_r, int D, int accumulate, hipStream_t s);
+// scatter-add rows: out[idx[t], :] += in[t, :]
+hipError_t sf_launch_scatter_add_rows(const float* in, float* out, const SfRowIndex& idx, int D, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// weights: fp32 master -> bf16 working copies
+// ------------------------------------------------------------------------------------------------
+// w_eff = scale * (w + lora_b * lora_a)  [N,K]  ->  w_bf [N,K] and wT_bf [K,N] (either may be null);
+// scale = tanh(*gate) when gate != nullptr.  bias_out = scale * bias (optional).
+hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const float* lora_b, int rank,
+                                 const float* gate, bf16_t* w_bf, bf16_t* wT_bf, const float* bias,
+                                 float* bias_out, int N, int K, hipStream_t s);
+// pooling-head query: q[D] = (probe * Wq^T + bq) * scale     (modeling:1145-1149 with nn.MultiheadAttention)
+hipError_t sf_launch_head_query(const float* probe, const float* wq, const float* bq, float scale, float* q, int D,
+                                hipStream_t s);
+// ... and its backward: dWq += scale * dq (x) probe, dbq += scale * dq, dprobe += scale * Wq^T dq
+hipError_t sf_launch_head_query_bwd(const float* dq, const float* probe, const float* wq, float scale, float* d_wq,
+                                    float* d_bq, float* d_probe, int D, hipStream_t s);
+// LoRA factors from the gradient of the merged weight: dA += B^T dW, dB += dW A^T   (W_eff = W + B A)
+hipError_t sf_launch_lora_grad(const float* dW, const float* A, const float* Bm, float* dA, float* dB, int N, int K,
+                               int rank, hipStream_t s);
+// temporal gate: h1 = h + tanh(g) * (t_out W^T + b).  G = unscaled dW, cs = unscaled db (colsum of dL/dh1):
+//   dW += tanh(g) G, db += tanh(g) cs, dgate += (1 - tanh(g)^2) * (<G, W> + <cs, b>)
+hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, const float* b, const float* gate,
+                               float* d_w, float* d_b, float* d_gate, int N, int K, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// optimizer
+// ------------------------------------------------------------------------------------------------
+struct SfAdamWArgs {
+  float* p; const float* g; float* m; float* v;   // flat fp32 [n]
+  size_t n;
+  const int* seg_end;        // device: exclusive end offset of each segment (ascending), nseg entries
+  const unsigned char* seg_decay;   // device: 1 = weight decay applies
+  const unsigned char* seg_train;   // device: 1 = trainable (others untouched)
+  int nseg;
+  float lr, beta1, beta2, eps, weight_decay;
+  float bias_correction1, bias_correction2;   // 1 - beta^t
+  float grad_scale;                            // g is multiplied by this first (clipping / averaging)
+};
+hipError_t sf_launch_adamw(const SfAdamWArgs& a, hipStream_t s);
+// out[0] = sum g^2 (deterministic two-stage); partial >= 1024 floats
+hipError_t sf_launch_sumsq(const float* g, size_t n, float* out, float* partial, hipStream_t s);

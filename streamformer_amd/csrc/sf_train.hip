@@ -1,0 +1,777 @@
+// C-ABI implementation of the training step (include/streamformer_hip.h, "training step" section):
+// flat fp32 parameter layout, bf16 working weights, forward with saved activations, staged backward,
+// fused AdamW.  Reference: autograd through TimesformerMultiTaskingModelSigLIP.forward
+// (modeling:1299-1354; layer :934-1004; head :1141-1154; embeddings :413-457) under the step
+// semantics of tools/finetune_tools.py:395-573 and the optimizer grouping of optim_factory.py:59-104.
+#include "sf_internal.h"
+#include "sf_common.h"
+#include "sf_train.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static const int kRank = 32;   // modeling:1280-1281
+
+struct TParam {
+  std::string name;
+  int64_t shape[4];
+  int ndim;
+  size_t numel, off;
+  bool trainable, decay;
+};
+
+struct TLin {                    // y = x W^T + b over the flat buffer
+  int N = 0, K = 0;
+  int pw = -1; size_t pw_off = 0;   // weight: param index + float offset inside it
+  int pb = -1; size_t pb_off = 0;   // bias (pb < 0: none)
+  int pla = -1, plb = -1;           // LoRA factors (spatial qkv / output.dense)
+  int pgate = -1;                   // temporal_dense: forward weight = tanh(gate) * W
+  bf16_t* w = nullptr;              // [N,K] working copy
+  bf16_t* wT = nullptr;             // [K,N] for the input-gradient GEMM
+  float* bias_scaled = nullptr;     // tanh(gate) * b
+  bool need_wT = true;
+};
+
+struct TLayer {
+  int gate, ln_t_g, ln_t_b, ln_b_g, ln_b_b, ln_a_g, ln_a_b;
+  TLin t_qkv, t_out, t_dense, s_qkv, s_out, up, down;
+  size_t seg_off, seg_end;
+};
+
+struct sf_trainer {
+  sf_config cfg;
+  int device;
+  int D, I, L, heads, N, Kp, C, P;
+  bool lora, freeze;
+  std::vector<TParam> params;
+  size_t total = 0, n_train = 0;
+  int p_pos, p_time, p_probe, p_inw, p_inb, post_g, post_b, hln_g, hln_b;
+  TLin patch, head_kv, head_out, fc1, fc2;
+  std::vector<TLayer> layers;
+  size_t emb_off, emb_end, tail_off, tail_end;
+  // device state
+  int* seg_end = nullptr;
+  unsigned char* seg_decay = nullptr;
+  unsigned char* seg_train = nullptr;
+  int nseg = 0;
+  bf16_t* arena = nullptr;
+  float* farena = nullptr;          // scaled biases, head query, reduction scratch
+  float* head_q = nullptr;
+  float* red_partial = nullptr;
+  const float* params_dev = nullptr;
+  int fB = 0, fT = 0;               // geometry of the last forward (0 = none)
+};
+
+static int add_param(sf_trainer* t, const std::string& name, std::initializer_list<int64_t> shape, bool trainable) {
+  TParam p;
+  p.name = name;
+  p.ndim = (int)shape.size();
+  p.numel = 1;
+  int i = 0;
+  for (int64_t d : shape) { p.shape[i++] = d; p.numel *= (size_t)d; }
+  for (; i < 4; ++i) p.shape[i] = 1;
+  p.off = 0;
+  p.trainable = trainable;
+  // optim_factory.py:72-77: 1-D parameters and "*.bias" are not decayed; everything else (incl. 0-dim) is
+  const bool is_bias = name.size() >= 5 && name.compare(name.size() - 5, 5, ".bias") == 0;
+  p.decay = !(p.ndim == 1 || is_bias);
+  t->params.push_back(p);
+  return (int)t->params.size() - 1;
+}
+
+static void lin_params(sf_trainer* t, TLin* l, const std::string& prefix, int N, int K, bool bias, bool trainable) {
+  l->N = N; l->K = K;
+  l->pw = add_param(t, prefix + ".weight", {N, K}, trainable);
+  l->pb = bias ? add_param(t, prefix + ".bias", {N}, trainable) : -1;
+}
+
+static void free_trainer_device(sf_trainer* t) {
+  if (t->seg_end) (void)hipFree(t->seg_end);
+  if (t->seg_decay) (void)hipFree(t->seg_decay);
+  if (t->seg_train) (void)hipFree(t->seg_train);
+  if (t->arena) (void)hipFree(t->arena);
+  if (t->farena) (void)hipFree(t->farena);
+}
+
+extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_spatial, int n_extra, sf_trainer** out) {
+  if (!cfg || !out) return sf_set_err(SF_ERR_INVALID, "sf_trainer_create: null argument");
+  const sf_config& c = *cfg;
+  if (c.hidden_size % c.num_attention_heads || c.hidden_size / c.num_attention_heads != 64)
+    return sf_set_err(SF_ERR_INVALID, "head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_attention_heads);
+  if (c.hidden_act != 0) return sf_set_err(SF_ERR_INVALID, "training supports hidden_act=gelu only");
+  if (c.image_size % c.patch_size) return sf_set_err(SF_ERR_INVALID, "image_size %% patch_size != 0");
+  if (n_extra < 0 || n_extra > 64) return sf_set_err(SF_ERR_INVALID, "n_extra out of range");
+  if (hipSetDevice(device) != hipSuccess) return sf_set_err(SF_ERR_HIP, "hipSetDevice(%d) failed", device);
+  sf_trainer* t = new sf_trainer();
+  t->cfg = c; t->device = device;
+  t->D = c.hidden_size; t->I = c.intermediate_size; t->L = c.num_hidden_layers; t->heads = c.num_attention_heads;
+  t->C = c.num_channels; t->P = c.patch_size;
+  t->N = (c.image_size / c.patch_size) * (c.image_size / c.patch_size);
+  t->Kp = t->C * t->P * t->P;
+  t->lora = c.add_lora_spatial != 0;
+  t->freeze = freeze_spatial != 0;
+  const int D = t->D, I = t->I;
+  if (t->N > 224) { delete t; return sf_set_err(SF_ERR_INVALID, "%d patches per frame; kernels handle <= 224", t->N); }
+  if ((D % 64) || (I % 64) || (t->Kp % 64)) { delete t; return sf_set_err(SF_ERR_INVALID, "hidden/intermediate/patch sizes must be multiples of 64"); }
+
+  // ---- parameter list in model order (names = reference state_dict keys) -----------
+  t->p_pos = add_param(t, "embeddings.position_embeddings", {1, t->N, D}, true);
+  t->p_time = add_param(t, "embeddings.time_embeddings", {1, c.num_frames, D}, true);
+  t->patch.N = D; t->patch.K = t->Kp; t->patch.need_wT = false;
+  t->patch.pw = add_param(t, "embeddings.patch_embeddings.projection.weight", {D, t->C, t->P, t->P}, true);
+  t->patch.pb = add_param(t, "embeddings.patch_embeddings.projection.bias", {D}, true);
+  t->layers.resize(t->L);
+  for (int i = 0; i < t->L; ++i) {
+    TLayer& l = t->layers[i];
+    const std::string p = "encoder.layer." + std::to_string(i) + ".";
+    const bool sp_train = !t->freeze;
+    l.gate = add_param(t, p + "temporal_attention_gating", {}, true);
+    l.ln_t_g = add_param(t, p + "temporal_layernorm.weight", {D}, true);
+    l.ln_t_b = add_param(t, p + "temporal_layernorm.bias", {D}, true);
+    lin_params(t, &l.t_qkv, p + "temporal_attention.attention.qkv", 3 * D, D, c.qkv_bias != 0, true);
+    lin_params(t, &l.t_out, p + "temporal_attention.output.dense", D, D, true, true);
+    lin_params(t, &l.t_dense, p + "temporal_dense", D, D, true, true);
+    l.t_dense.pgate = l.gate;
+    l.ln_b_g = add_param(t, p + "layernorm_before.weight", {D}, true);
+    l.ln_b_b = add_param(t, p + "layernorm_before.bias", {D}, true);
+    lin_params(t, &l.s_qkv, p + "attention.attention.qkv", 3 * D, D, c.qkv_bias != 0, sp_train);
+    if (t->lora) {
+      l.s_qkv.pla = add_param(t, p + "attention.attention.qkv_lora_a.weight", {kRank, D}, true);
+      l.s_qkv.plb = add_param(t, p + "attention.attention.qkv_lora_b.weight", {3 * D, kRank}, true);
+    }
+    lin_params(t, &l.s_out, p + "attention.output.dense", D, D, true, sp_train);
+    if (t->lora) {
+      l.s_out.pla = add_param(t, p + "attention.output.dense_lora_a.weight", {kRank, D}, true);
+      l.s_out.plb = add_param(t, p + "attention.output.dense_lora_b.weight", {D, kRank}, true);
+    }
+    l.ln_a_g = add_param(t, p + "layernorm_after.weight", {D}, true);
+    l.ln_a_b = add_param(t, p + "layernorm_after.bias", {D}, true);
+    lin_params(t, &l.up, p + "intermediate.dense", I, D, true, true);
+    lin_params(t, &l.down, p + "output.dense", D, I, true, true);
+  }
+  t->post_g = add_param(t, "post_layernorm.weight", {D}, true);
+  t->post_b = add_param(t, "post_layernorm.bias", {D}, true);
+  t->p_probe = add_param(t, "head.probe", {1, 1, D}, true);
+  t->p_inw = add_param(t, "head.attention.in_proj_weight", {3 * D, D}, true);
+  t->p_inb = add_param(t, "head.attention.in_proj_bias", {3 * D}, true);
+  t->head_kv.N = 2 * D; t->head_kv.K = D;
+  t->head_kv.pw = t->p_inw; t->head_kv.pw_off = (size_t)D * D;
+  t->head_kv.pb = t->p_inb; t->head_kv.pb_off = (size_t)D;
+  lin_params(t, &t->head_out, "head.attention.out_proj", D, D, true, true);
+  t->hln_g = add_param(t, "head.layernorm.weight", {D}, true);
+  t->hln_b = add_param(t, "head.layernorm.bias", {D}, true);
+  lin_params(t, &t->fc1, "head.mlp.fc1", I, D, true, true);
+  lin_params(t, &t->fc2, "head.mlp.fc2", D, I, true, true);
+  for (int i = 0; i < n_extra; ++i) add_param(t, "extra." + std::to_string(i), {}, true);
+
+  // ---- offsets: trainable prefix in model order, frozen tail; 64-float alignment ---------------------
+  size_t off = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (TParam& p : t->params) {
+      if (p.trainable != (pass == 0)) continue;
+      p.off = off;
+      off += (p.numel + 63) & ~(size_t)63;
+    }
+    if (pass == 0) t->n_train = off;
+  }
+  t->total = off;
+  auto seg_end_of = [&](int idx) { const TParam& p = t->params[idx]; return p.off + ((p.numel + 63) & ~(size_t)63); };
+  t->emb_off = t->params[t->p_pos].off;
+  t->emb_end = seg_end_of(t->patch.pb);
+  for (int i = 0; i < t->L; ++i) {
+    t->layers[i].seg_off = t->params[t->layers[i].gate].off;
+    t->layers[i].seg_end = seg_end_of(t->layers[i].down.pb);
+  }
+  t->tail_off = t->params[t->post_g].off;
+  t->tail_end = t->n_train;
+
+  // ---- segment table for the optimizer ----------------------------------------------------------------
+  {
+    std::vector<const TParam*> order;
+    for (const TParam& p : t->params) order.push_back(&p);
+    std::vector<int> ends(order.size());
+    std::vector<unsigned char> dec(order.size()), tr(order.size());
+    // params are already offset-sorted within each pass; build by offset
+    std::vector<int> idx(order.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+    for (size_t i = 1; i < idx.size(); ++i)
+      for (size_t j = i; j > 0 && order[idx[j]]->off < order[idx[j - 1]]->off; --j) std::swap(idx[j], idx[j - 1]);
+    if (t->total >= ((size_t)1 << 31)) { delete t; return sf_set_err(SF_ERR_INVALID, "model too large for int32 segment offsets"); }
+    for (size_t i = 0; i < idx.size(); ++i) {
+      const TParam* p = order[idx[i]];
+      ends[i] = (int)(p->off + ((p->numel + 63) & ~(size_t)63));
+      dec[i] = p->decay; tr[i] = p->trainable;
+    }
+    t->nseg = (int)idx.size();
+    if (hipMalloc(&t->seg_end, ends.size() * sizeof(int)) != hipSuccess || hipMalloc(&t->seg_decay, dec.size()) != hipSuccess ||
+        hipMalloc(&t->seg_train, tr.size()) != hipSuccess) {
+      free_trainer_device(t); delete t;
+      return sf_set_err(SF_ERR_HIP, "hipMalloc failed (segment table)");
+    }
+    (void)hipMemcpy(t->seg_end, ends.data(), ends.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(t->seg_decay, dec.data(), dec.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(t->seg_train, tr.data(), tr.size(), hipMemcpyHostToDevice);
+  }
+
+  // ---- bf16 working-weight arena -----------------------------------------------------------------------
+  {
+    std::vector<TLin*> lins = {&t->patch, &t->head_kv, &t->head_out, &t->fc1, &t->fc2};
+    for (TLayer& l : t->layers) for (TLin* x : {&l.t_qkv, &l.t_out, &l.t_dense, &l.s_qkv, &l.s_out, &l.up, &l.down}) lins.push_back(x);
+    size_t nb = 0, nf = 0;
+    for (TLin* x : lins) {
+      nb += ((size_t)x->N * x->K + 127) & ~(size_t)127;
+      if (x->need_wT) nb += ((size_t)x->N * x->K + 127) & ~(size_t)127;
+      if (x->pgate >= 0) nf += ((size_t)x->N + 63) & ~(size_t)63;
+    }
+    nf += (size_t)D + 64 + 2048;          // head query + reduction scratch
+    if (hipMalloc(&t->arena, nb * sizeof(bf16_t)) != hipSuccess || hipMalloc(&t->farena, nf * sizeof(float)) != hipSuccess) {
+      free_trainer_device(t); delete t;
+      return sf_set_err(SF_ERR_HIP, "hipMalloc failed (working weights, %zu bytes)", nb * 2);
+    }
+    bf16_t* bp = t->arena;
+    float* fp = t->farena;
+    for (TLin* x : lins) {
+      const size_t n = ((size_t)x->N * x->K + 127) & ~(size_t)127;
+      x->w = bp; bp += n;
+      if (x->need_wT) { x->wT = bp; bp += n; }
+      if (x->pgate >= 0) { x->bias_scaled = fp; fp += ((size_t)x->N + 63) & ~(size_t)63; }
+    }
+    t->head_q = fp; fp += (size_t)D + 64;
+    t->red_partial = fp;
+  }
+  *out = t;
+  return SF_OK;
+}
+
+extern "C" void sf_trainer_destroy(sf_trainer* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  free_trainer_device(t);
+  delete t;
+}
+
+extern "C" int sf_trainer_num_params(const sf_trainer* t) { return t ? (int)t->params.size() : 0; }
+
+extern "C" int sf_trainer_param_info(const sf_trainer* t, int index, char* name_out, int name_cap, int64_t* offset_out,
+                                     int64_t* numel_out, int64_t* shape_out, int* ndim_out, int* trainable_out,
+                                     int* decay_out) {
+  if (!t || index < 0 || index >= (int)t->params.size()) return sf_set_err(SF_ERR_INVALID, "param index out of range");
+  const TParam& p = t->params[index];
+  if (name_out && name_cap > 0) snprintf(name_out, (size_t)name_cap, "%s", p.name.c_str());
+  if (offset_out) *offset_out = (int64_t)p.off;
+  if (numel_out) *numel_out = (int64_t)p.numel;
+  if (shape_out) for (int i = 0; i < 4; ++i) shape_out[i] = p.shape[i];
+  if (ndim_out) *ndim_out = p.ndim;
+  if (trainable_out) *trainable_out = p.trainable;
+  if (decay_out) *decay_out = p.decay;
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_total_floats(const sf_trainer* t, int64_t* total_out, int64_t* trainable_out) {
+  if (!t) return sf_set_err(SF_ERR_INVALID, "null handle");
+  if (total_out) *total_out = (int64_t)t->total;
+  if (trainable_out) *trainable_out = (int64_t)t->n_train;
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_num_stages(const sf_trainer* t) { return t ? t->L + 2 : 0; }
+
+extern "C" int sf_trainer_stage_range(const sf_trainer* t, int stage, int64_t* offset_out, int64_t* numel_out) {
+  if (!t || stage < 0 || stage > t->L + 1) return sf_set_err(SF_ERR_INVALID, "stage out of range");
+  size_t a, b;
+  if (stage == 0) { a = t->tail_off; b = t->tail_end; }
+  else if (stage == t->L + 1) { a = t->emb_off; b = t->emb_end; }
+  else { const TLayer& l = t->layers[t->L - stage]; a = l.seg_off; b = l.seg_end; }
+  if (offset_out) *offset_out = (int64_t)a;
+  if (numel_out) *numel_out = (int64_t)(b - a);
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// working weights
+// ------------------------------------------------------------------------------------------------
+static inline const float* PP(const sf_trainer* t, const float* base, int idx, size_t extra = 0) {
+  return idx < 0 ? nullptr : base + t->params[idx].off + extra;
+}
+static inline float* GG(const sf_trainer* t, float* grads, int idx, size_t extra = 0) {
+  return (idx < 0 || !t->params[idx].trainable) ? nullptr : grads + t->params[idx].off + extra;
+}
+static inline const float* lin_bias(const sf_trainer* t, const TLin& l) {
+  return l.pgate >= 0 ? l.bias_scaled : PP(t, t->params_dev, l.pb, l.pb_off);
+}
+
+extern "C" int sf_trainer_sync_weights(sf_trainer* t, const float* params_dev, sf_stream stream) {
+  if (!t || !params_dev) return sf_set_err(SF_ERR_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(t->device));
+  t->params_dev = params_dev;
+  auto prep = [&](const TLin& l) -> hipError_t {
+    return sf_launch_prep_weight(PP(t, params_dev, l.pw, l.pw_off), PP(t, params_dev, l.pla), PP(t, params_dev, l.plb), kRank,
+                                 PP(t, params_dev, l.pgate), l.w, l.wT, PP(t, params_dev, l.pb, l.pb_off), l.bias_scaled, l.N, l.K, s);
+  };
+  HIP_TRY(prep(t->patch));
+  for (const TLayer& l : t->layers)
+    for (const TLin* x : {&l.t_qkv, &l.t_out, &l.t_dense, &l.s_qkv, &l.s_out, &l.up, &l.down}) HIP_TRY(prep(*x));
+  for (const TLin* x : {&t->head_kv, &t->head_out, &t->fc1, &t->fc2}) HIP_TRY(prep(*x));
+  // nn.MultiheadAttention scales q by head_dim^-0.5 after the in-projection (modeling:1145-1149)
+  HIP_TRY(sf_launch_head_query(PP(t, params_dev, t->p_probe), PP(t, params_dev, t->p_inw), PP(t, params_dev, t->p_inb), 0.125f,
+                               t->head_q, t->D, s));
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+struct TCarver {
+  char* base;
+  size_t off = 0;
+  explicit TCarver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct TSavedLayer {
+  float *h1, *h2;
+  bf16_t *ln_t, *tqkv, *ctx_t, *t_out, *ln_b, *sqkv, *ctx_s, *ln_a, *pre, *act;
+};
+struct TWs {
+  // saved by the forward
+  bf16_t* patches; float* te_rows;
+  std::vector<float*> h;               // L+1 residual snapshots
+  std::vector<TSavedLayer> sl;
+  bf16_t *xn, *kv, *pc, *hn, *hm_pre, *hm;
+  float* attn_out;
+  // backward scratch
+  float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
+  bf16_t *g_bf, *d_wide, *d_ctx, *d_tout;
+  float *gh, *d_hn, *d_pc, *dq_frames, *dq_total;
+  bf16_t *gh_bf, *d_hm;
+  size_t bytes;
+};
+
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
+  TWs w;
+  TCarver c(base);
+  const size_t D = t->D, I = t->I, N = t->N;
+  const size_t M = (size_t)B * T * N, F = (size_t)B * T;
+  w.patches = c.take<bf16_t>(M * t->Kp);
+  w.te_rows = c.take<float>((size_t)T * D);
+  w.h.resize(t->L + 1);
+  w.sl.resize(t->L);
+  for (int i = 0; i <= t->L; ++i) w.h[i] = c.take<float>(M * D);
+  for (int i = 0; i < t->L; ++i) {
+    TSavedLayer& s = w.sl[i];
+    s.h1 = c.take<float>(M * D); s.h2 = c.take<float>(M * D);
+    s.ln_t = c.take<bf16_t>(M * D); s.tqkv = c.take<bf16_t>(M * 3 * D); s.ctx_t = c.take<bf16_t>(M * D);
+    s.t_out = c.take<bf16_t>(M * D);
+    s.ln_b = c.take<bf16_t>(M * D); s.sqkv = c.take<bf16_t>(M * 3 * D); s.ctx_s = c.take<bf16_t>(M * D);
+    s.ln_a = c.take<bf16_t>(M * D); s.pre = c.take<bf16_t>(M * I); s.act = c.take<bf16_t>(M * I);
+  }
+  w.xn = c.take<bf16_t>(M * D); w.kv = c.take<bf16_t>(M * 2 * D); w.pc = c.take<bf16_t>(F * D);
+  w.attn_out = c.take<float>(F * D); w.hn = c.take<bf16_t>(F * D);
+  w.hm_pre = c.take<bf16_t>(F * I); w.hm = c.take<bf16_t>(F * I);
+  // scratch
+  w.g = c.take<float>(M * D); w.d_ln = c.take<float>(M * D);
+  w.g_bf = c.take<bf16_t>(M * D);
+  w.d_wide = c.take<bf16_t>(M * max_sz(I, 3 * D));
+  w.d_ctx = c.take<bf16_t>(M * D); w.d_tout = c.take<bf16_t>(M * D);
+  size_t wp = 0;
+  const int Mi = (int)M, Fi = (int)F, Di = t->D, Ii = t->I;
+  wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Di, Ii)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Ii, Di));
+  wp = max_sz(wp, sf_wgrad_partial_floats(Mi, 3 * Di, Di)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Di, Di));
+  wp = max_sz(wp, sf_wgrad_partial_floats(Mi, 2 * Di, Di)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Di, t->Kp));
+  wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Di, Ii)); wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Ii, Di));
+  wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Di, Di));
+  w.wg_partial = c.take<float>(wp);
+  w.dw_scratch = c.take<float>((size_t)3 * D * D);
+  w.cs = c.take<float>(max_sz(I, 3 * D));
+  w.ln_partial = c.take<float>(sf_ln_bwd_partial_floats(t->D));
+  w.cs_partial = c.take<float>(sf_colsum_partial_floats((int)max_sz(I, 3 * D)));
+  w.s_tn = c.take<float>((size_t)T * N * D);
+  w.gh = c.take<float>(F * D); w.d_hn = c.take<float>(F * D); w.d_pc = c.take<float>(F * D);
+  w.dq_frames = c.take<float>(F * D); w.dq_total = c.take<float>(D);
+  w.gh_bf = c.take<bf16_t>(F * D); w.d_hm = c.take<bf16_t>(F * I);
+  w.bytes = (c.off + 255) & ~(size_t)255;
+  return w;
+}
+
+static int check_bt(const sf_trainer* t, int B, int T) {
+  if (!t) return sf_set_err(SF_ERR_INVALID, "null handle");
+  if (B <= 0 || T <= 0) return sf_set_err(SF_ERR_INVALID, "bad geometry B=%d T=%d", B, T);
+  if (T > t->cfg.num_frames) return sf_set_err(SF_ERR_INVALID, "training needs T <= config.num_frames (%d > %d)", T, t->cfg.num_frames);
+  if (T > 32) return sf_set_err(SF_ERR_INVALID, "temporal attention backward handles T <= 32 (got %d)", T);
+  if ((size_t)B * T * t->N * (size_t)(t->I > 3 * t->D ? t->I : 3 * t->D) * 2 >= ((size_t)1 << 32))
+    return sf_set_err(SF_ERR_INVALID, "batch too large for 32-bit buffer offsets");
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_workspace_bytes(const sf_trainer* t, int B, int T, size_t* out) {
+  int rc = check_bt(t, B, T);
+  if (rc) return rc;
+  if (!out) return sf_set_err(SF_ERR_INVALID, "null out");
+  *out = tcarve(t, nullptr, B, T).bytes;
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM helpers
+// ------------------------------------------------------------------------------------------------
+static hipError_t tgemm(const bf16_t* a, const bf16_t* w, const float* bias, int M, int N, int K, int epi, hipStream_t s,
+                        float* out_f32, bf16_t* out_bf, const float* resid = nullptr) {
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = a; g.w_hi = w; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.epi = epi; g.alpha = 1.f; g.resid = resid;
+  g.out_f32 = out_f32; g.out_hi = epi == SF_EPI_RESID_F32 ? nullptr : out_bf; g.ldc = N;
+  return sf_launch_gemm(g, false, s);
+}
+// y = x W^T + b
+static hipError_t lin_fwd(const sf_trainer* t, const TLin& l, const bf16_t* x, int M, int epi, hipStream_t s, float* out_f32,
+                          bf16_t* out_bf, const float* resid = nullptr) {
+  return tgemm(x, l.w, lin_bias(t, l), M, l.N, l.K, epi, s, out_f32, out_bf, resid);
+}
+// dx = dy W   (dy [M,N] -> dx [M,K]); the forward-scaled weight is used as is
+static hipError_t lin_dgrad(const TLin& l, const bf16_t* dy, int M, hipStream_t s, float* out_f32, bf16_t* out_bf) {
+  return tgemm(dy, l.wT, nullptr, M, l.K, l.N, out_f32 ? SF_EPI_F32 : SF_EPI_BF16, s, out_f32, out_bf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward (activations kept)
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_dtype, int B, int T, float* last_hidden,
+                                  float* pooler, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  int rc = check_bt(t, B, T);
+  if (rc) return rc;
+  if (!t->params_dev) return sf_set_err(SF_ERR_STATE, "sf_trainer_sync_weights has not been called");
+  if (!pixels || !workspace || !pooler) return sf_set_err(SF_ERR_INVALID, "null argument");
+  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16) return sf_set_err(SF_ERR_INVALID, "pixels must be fp32 or bf16");
+  HIP_TRY(hipSetDevice(t->device));
+  hipStream_t s = (hipStream_t)stream;
+  const TWs ws = tcarve(t, workspace, B, T);
+  if (workspace_bytes < ws.bytes) return sf_set_err(SF_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+  const sf_config& c = t->cfg;
+  const int D = t->D, I = t->I, N = t->N, heads = t->heads;
+  const int M = B * T * N, F = B * T;
+  const float eps = c.layer_norm_eps;
+  const float* P0 = t->params_dev;
+  t->fB = 0;
+
+  SfRowIndex idx;
+  idx.n = T;
+  for (int i = 0; i < T; ++i) idx.idx[i] = i;             // modeling:436-439 (T <= num_frames)
+  HIP_TRY(sf_launch_gather_rows(PP(t, P0, t->p_time), ws.te_rows, idx, D, s));
+  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_BF16, ws.patches, nullptr, F, c.num_channels, c.image_size, c.image_size,
+                             c.patch_size, s));
+  {
+    SfGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a_hi = ws.patches; g.w_hi = t->patch.w; g.bias = PP(t, P0, t->patch.pb);
+    g.M = M; g.N = D; g.K = t->Kp; g.epi = SF_EPI_EMBED_F32;
+    g.pos = PP(t, P0, t->p_pos); g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
+    g.out_f32 = ws.h[0]; g.ldc = D;
+    HIP_TRY(sf_launch_gemm(g, false, s));
+  }
+  const float scale = 0.125f;
+  for (int li = 0; li < t->L; ++li) {
+    const TLayer& l = t->layers[li];
+    const TSavedLayer& sv = ws.sl[li];
+    const float* h = ws.h[li];
+    // temporal attention (modeling:937-958)
+    HIP_TRY(sf_launch_layernorm(h, PP(t, P0, l.ln_t_g), PP(t, P0, l.ln_t_b), nullptr, sv.ln_t, nullptr, M, D, eps, s));
+    HIP_TRY(lin_fwd(t, l.t_qkv, sv.ln_t, M, SF_EPI_BF16, s, nullptr, sv.tqkv));
+    {
+      SfAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = sv.tqkv; a.k = sv.tqkv + D; a.v = sv.tqkv + 2 * D;
+      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.N = N; a.B = B; a.Tq = T; a.Tk = T; a.Tcap = T; a.t_past = 0; a.causal = c.enable_causal_temporal;
+      a.Tq_cap = T; a.q_t0 = 0; a.ctx_hi = sv.ctx_t; a.D = D;
+      HIP_TRY(sf_launch_temporal_attention(a, false, s));
+    }
+    HIP_TRY(lin_fwd(t, l.t_out, sv.ctx_t, M, SF_EPI_BF16, s, nullptr, sv.t_out));
+    HIP_TRY(lin_fwd(t, l.t_dense, sv.t_out, M, SF_EPI_RESID_F32, s, sv.h1, nullptr, h));      // h1 = h + tanh(g) * dense(.)
+    // spatial attention (modeling:962-996)
+    HIP_TRY(sf_launch_layernorm(sv.h1, PP(t, P0, l.ln_b_g), PP(t, P0, l.ln_b_b), nullptr, sv.ln_b, nullptr, M, D, eps, s));
+    HIP_TRY(lin_fwd(t, l.s_qkv, sv.ln_b, M, SF_EPI_BF16, s, nullptr, sv.sqkv));
+    {
+      SfAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = sv.sqkv; a.k = sv.sqkv + D; a.v = sv.sqkv + 2 * D;
+      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.N = N; a.frames = F; a.ctx_hi = sv.ctx_s; a.D = D;
+      HIP_TRY(sf_launch_spatial_attention(a, false, s));
+    }
+    HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_RESID_F32, s, sv.h2, nullptr, sv.h1));
+    // MLP (modeling:997-1000)
+    HIP_TRY(sf_launch_layernorm(sv.h2, PP(t, P0, l.ln_a_g), PP(t, P0, l.ln_a_b), nullptr, sv.ln_a, nullptr, M, D, eps, s));
+    HIP_TRY(lin_fwd(t, l.up, sv.ln_a, M, SF_EPI_BF16, s, nullptr, sv.pre));
+    HIP_TRY(sf_launch_gelu_fwd(sv.pre, sv.act, (size_t)M * I, s));
+    HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_RESID_F32, s, ws.h[li + 1], nullptr, sv.h2));
+  }
+  // post LayerNorm + pooling head (modeling:1330-1340, 1141-1154)
+  HIP_TRY(sf_launch_layernorm(ws.h[t->L], PP(t, P0, t->post_g), PP(t, P0, t->post_b), last_hidden, ws.xn, nullptr, M, D, eps, s));
+  HIP_TRY(lin_fwd(t, t->head_kv, ws.xn, M, SF_EPI_BF16, s, nullptr, ws.kv));
+  HIP_TRY(sf_launch_pool_attention(t->head_q, ws.kv, 0, 2 * D, ws.pc, nullptr, F, N, heads, D, s));
+  HIP_TRY(lin_fwd(t, t->head_out, ws.pc, F, SF_EPI_F32, s, ws.attn_out, nullptr));
+  HIP_TRY(sf_launch_layernorm(ws.attn_out, PP(t, P0, t->hln_g), PP(t, P0, t->hln_b), nullptr, ws.hn, nullptr, F, D, eps, s));
+  HIP_TRY(lin_fwd(t, t->fc1, ws.hn, F, SF_EPI_BF16, s, nullptr, ws.hm_pre));
+  HIP_TRY(sf_launch_gelu_fwd(ws.hm_pre, ws.hm, (size_t)F * I, s));
+  HIP_TRY(lin_fwd(t, t->fc2, ws.hm, F, SF_EPI_RESID_F32, s, pooler, nullptr, ws.attn_out));
+  t->fB = B; t->fT = T;
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+struct BwdCtx {
+  const sf_trainer* t;
+  const TWs* ws;
+  float* grads;
+  hipStream_t s;
+};
+
+// weight + bias gradients of one Linear: dW (+)= dy^T x, db += colsum(dy); LoRA factors from dW_eff
+static hipError_t lin_wgrad(const BwdCtx& c, const TLin& l, const bf16_t* dy, const bf16_t* x, int M) {
+  const sf_trainer* t = c.t;
+  float* gw = GG(t, c.grads, l.pw, l.pw_off);
+  float* gb = GG(t, c.grads, l.pb, l.pb_off);
+  SfWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.ldy = l.N; a.x = x; a.ldx = l.K; a.M = M; a.N1 = l.N; a.N2 = l.K; a.ldo = l.K; a.alpha = 1.f;
+  a.partial = c.ws->wg_partial;
+  hipError_t e = hipSuccess;
+  if (l.pla >= 0) {
+    a.out = c.ws->dw_scratch; a.accumulate = 0;
+    if ((e = sf_launch_wgrad(a, c.s)) != hipSuccess) return e;
+    e = sf_launch_lora_grad(c.ws->dw_scratch, PP(t, t->params_dev, l.pla), PP(t, t->params_dev, l.plb), GG(t, c.grads, l.pla),
+                            GG(t, c.grads, l.plb), l.N, l.K, kRank, c.s);
+    if (e != hipSuccess) return e;
+    if (gw) e = sf_launch_sum_rows(c.ws->dw_scratch, gw, l.N, l.N, 1, 0, 1, 0, l.K, 1, c.s);
+  } else if (gw) {
+    a.out = gw; a.accumulate = 1;
+    e = sf_launch_wgrad(a, c.s);
+  }
+  if (e != hipSuccess) return e;
+  if (gb) e = sf_launch_colsum_bf16(dy, M, l.N, l.N, 1.f, gb, 1, c.ws->cs_partial, c.s);
+  return e;
+}
+
+static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_lhs, int B, int T) {
+  const sf_trainer* t = c.t;
+  const TWs& ws = *c.ws;
+  hipStream_t s = c.s;
+  const int D = t->D, I = t->I, N = t->N;
+  const int M = B * T * N, F = B * T;
+  const float eps = t->cfg.layer_norm_eps;
+  const float* P0 = t->params_dev;
+  // pooler = attn_out + fc2(gelu(fc1(LN(attn_out))))
+  HIP_TRY(sf_launch_split(d_pooler, ws.gh_bf, nullptr, (size_t)F * D, s));
+  HIP_TRY(lin_dgrad(t->fc2, ws.gh_bf, F, s, nullptr, ws.d_hm));
+  HIP_TRY(lin_wgrad(c, t->fc2, ws.gh_bf, ws.hm, F));
+  HIP_TRY(sf_launch_gelu_bwd(ws.d_hm, ws.hm_pre, (size_t)F * I, s));
+  HIP_TRY(lin_dgrad(t->fc1, ws.d_hm, F, s, ws.d_hn, nullptr));
+  HIP_TRY(lin_wgrad(c, t->fc1, ws.d_hm, ws.hn, F));
+  HIP_TRY(sf_launch_ln_bwd(ws.attn_out, ws.d_hn, PP(t, P0, t->hln_g), d_pooler, ws.gh, GG(t, c.grads, t->hln_g), GG(t, c.grads, t->hln_b),
+                           ws.ln_partial, F, D, eps, s));
+  // attn_out = out_proj(ctx)
+  HIP_TRY(sf_launch_split(ws.gh, ws.gh_bf, nullptr, (size_t)F * D, s));
+  HIP_TRY(lin_dgrad(t->head_out, ws.gh_bf, F, s, ws.d_pc, nullptr));
+  HIP_TRY(lin_wgrad(c, t->head_out, ws.gh_bf, ws.pc, F));
+  // probe attention over the N tokens of every frame
+  bf16_t* d_kv = ws.d_wide;
+  HIP_TRY(sf_launch_pool_attention_bwd(t->head_q, ws.kv, ws.d_pc, d_kv, ws.dq_frames, F, N, t->heads, D, s));
+  HIP_TRY(sf_launch_sum_rows(ws.dq_frames, ws.dq_total, 1, 1, 0, 0, F, 1, D, 0, s));
+  HIP_TRY(sf_launch_head_query_bwd(ws.dq_total, PP(t, P0, t->p_probe), PP(t, P0, t->p_inw), 0.125f, GG(t, c.grads, t->p_inw),
+                                   GG(t, c.grads, t->p_inb), GG(t, c.grads, t->p_probe), D, s));
+  HIP_TRY(lin_wgrad(c, t->head_kv, d_kv, ws.xn, M));
+  HIP_TRY(lin_dgrad(t->head_kv, d_kv, M, s, ws.d_ln, nullptr));
+  if (d_lhs) HIP_TRY(sf_launch_sum_rows(d_lhs, ws.d_ln, M, M, 1, 0, 1, 0, D, 1, s));
+  // post_layernorm: g = dLN(h_L)
+  HIP_TRY(sf_launch_ln_bwd(ws.h[t->L], ws.d_ln, PP(t, P0, t->post_g), nullptr, ws.g, GG(t, c.grads, t->post_g), GG(t, c.grads, t->post_b),
+                           ws.ln_partial, M, D, eps, s));
+  return SF_OK;
+}
+
+static int backward_layer(const BwdCtx& c, int li, int B, int T) {
+  const sf_trainer* t = c.t;
+  const TWs& ws = *c.ws;
+  hipStream_t s = c.s;
+  const TLayer& l = t->layers[li];
+  const TSavedLayer& sv = ws.sl[li];
+  const int D = t->D, I = t->I, N = t->N;
+  const int M = B * T * N, F = B * T;
+  const float eps = t->cfg.layer_norm_eps;
+  const float* P0 = t->params_dev;
+  const size_t MD = (size_t)M * D;
+
+  // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
+  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, MD, s));
+  HIP_TRY(lin_dgrad(l.down, ws.g_bf, M, s, nullptr, ws.d_wide));                 // d act [M,I]
+  HIP_TRY(lin_wgrad(c, l.down, ws.g_bf, sv.act, M));
+  HIP_TRY(sf_launch_gelu_bwd(ws.d_wide, sv.pre, (size_t)M * I, s));              // d pre
+  HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, ws.d_ln, nullptr));
+  HIP_TRY(lin_wgrad(c, l.up, ws.d_wide, sv.ln_a, M));
+  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln, PP(t, P0, l.ln_a_g), ws.g, ws.g, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
+                           ws.ln_partial, M, D, eps, s));
+  // ---- spatial: h2 = h1 + out(attn(qkv(LN_b(h1)))) ---------------------------------------------------------
+  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, MD, s));
+  HIP_TRY(lin_dgrad(l.s_out, ws.g_bf, M, s, nullptr, ws.d_ctx));
+  HIP_TRY(lin_wgrad(c, l.s_out, ws.g_bf, sv.ctx_s, M));
+  {
+    SfAttnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = sv.sqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_s; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide;
+    a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = N; a.nseq = F; a.seq_rows = 1; a.causal = 0;
+    HIP_TRY(sf_launch_spatial_attention_bwd(a, s));
+  }
+  HIP_TRY(lin_wgrad(c, l.s_qkv, ws.d_wide, sv.ln_b, M));
+  HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide, M, s, ws.d_ln, nullptr));
+  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln, PP(t, P0, l.ln_b_g), ws.g, ws.g, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
+                           ws.ln_partial, M, D, eps, s));
+  // ---- temporal: h1 = h + tanh(gate) * dense(out(attn(qkv(LN_t(h))))) ----------------------------------------
+  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, MD, s));
+  HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
+  {
+    // unscaled G = g^T t_out and column sums -> dW, db, dgate (see sf_launch_gate_grad)
+    SfWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = ws.g_bf; a.ldy = D; a.x = sv.t_out; a.ldx = D; a.M = M; a.N1 = D; a.N2 = D; a.ldo = D; a.alpha = 1.f;
+    a.partial = ws.wg_partial; a.out = ws.dw_scratch; a.accumulate = 0;
+    HIP_TRY(sf_launch_wgrad(a, s));
+    HIP_TRY(sf_launch_colsum_bf16(ws.g_bf, M, D, D, 1.f, ws.cs, 0, ws.cs_partial, s));
+    HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
+                                GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), D, D, s));
+  }
+  HIP_TRY(lin_dgrad(l.t_out, ws.d_tout, M, s, nullptr, ws.d_ctx));
+  HIP_TRY(lin_wgrad(c, l.t_out, ws.d_tout, sv.ctx_t, M));
+  {
+    SfAttnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = sv.tqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_t; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide;
+    a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = T; a.nseq = B * N; a.seq_rows = N;
+    a.causal = t->cfg.enable_causal_temporal;
+    HIP_TRY(sf_launch_temporal_attention_bwd(a, s));
+  }
+  HIP_TRY(lin_wgrad(c, l.t_qkv, ws.d_wide, sv.ln_t, M));
+  HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide, M, s, ws.d_ln, nullptr));
+  HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln, PP(t, P0, l.ln_t_g), ws.g, ws.g, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
+                           ws.ln_partial, M, D, eps, s));
+  return SF_OK;
+}
+
+static int backward_embeddings(const BwdCtx& c, int B, int T) {
+  const sf_trainer* t = c.t;
+  const TWs& ws = *c.ws;
+  hipStream_t s = c.s;
+  const int D = t->D, N = t->N;
+  const int M = B * T * N;
+  // h0 = patches W^T + b + pos[n] + time[t]   (modeling:336-350, 413-457)
+  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, (size_t)M * D, s));
+  HIP_TRY(lin_wgrad(c, t->patch, ws.g_bf, ws.patches, M));
+  HIP_TRY(sf_launch_sum_rows(ws.g, ws.s_tn, T * N, T * N, 1, 0, B, (long)T * N, D, 0, s));       // sum over batch
+  if (float* gp = GG(t, c.grads, t->p_pos)) HIP_TRY(sf_launch_sum_rows(ws.s_tn, gp, N, N, 1, 0, T, N, D, 1, s));
+  if (float* gt = GG(t, c.grads, t->p_time)) HIP_TRY(sf_launch_sum_rows(ws.s_tn, gt, T, T, N, 0, N, 1, D, 1, s));
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_backward(sf_trainer* t, const float* d_pooler, const float* d_lhs, float* grads, int stage_first,
+                                   int stage_last, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  if (!t || !grads || !workspace) return sf_set_err(SF_ERR_INVALID, "null argument");
+  if (!t->fB) return sf_set_err(SF_ERR_STATE, "sf_trainer_backward needs a preceding sf_trainer_forward");
+  if (stage_first < 0 || stage_last > t->L + 1 || stage_first > stage_last) return sf_set_err(SF_ERR_INVALID, "bad stage range");
+  if (stage_first == 0 && !d_pooler) return sf_set_err(SF_ERR_INVALID, "stage 0 needs d_pooler");
+  HIP_TRY(hipSetDevice(t->device));
+  const int B = t->fB, T = t->fT;
+  const TWs ws = tcarve(t, workspace, B, T);
+  if (workspace_bytes < ws.bytes) return sf_set_err(SF_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+  BwdCtx c{t, &ws, grads, (hipStream_t)stream};
+  for (int st = stage_first; st <= stage_last; ++st) {
+    int rc;
+    if (st == 0) rc = backward_head(c, d_pooler, d_lhs, B, T);
+    else if (st == t->L + 1) rc = backward_embeddings(c, B, T);
+    else rc = backward_layer(c, t->L - st, B, T);
+    if (rc) return rc;
+  }
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, const float* grads, float* m, float* v, int step, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, sf_stream stream) {
+  if (!t || !params || !grads || !m || !v) return sf_set_err(SF_ERR_INVALID, "null argument");
+  if (step < 1) return sf_set_err(SF_ERR_INVALID, "step counts from 1");
+  HIP_TRY(hipSetDevice(t->device));
+  SfAdamWArgs a;
+  a.p = params; a.g = grads; a.m = m; a.v = v; a.n = t->n_train;
+  a.seg_end = t->seg_end; a.seg_decay = t->seg_decay; a.seg_train = t->seg_train; a.nseg = t->nseg;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  a.bias_correction1 = 1.0f - powf(beta1, (float)step);
+  a.bias_correction2 = 1.0f - powf(beta2, (float)step);
+  a.grad_scale = grad_scale;
+  HIP_TRY(sf_launch_adamw(a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_grad_sumsq(sf_trainer* t, const float* grads, float* out, sf_stream stream) {
+  if (!t || !grads || !out) return sf_set_err(SF_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(t->device));
+  HIP_TRY(sf_launch_sumsq(grads, t->n_train, out, t->red_partial, (hipStream_t)stream));
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single backward operators (parity tests)
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_op_wgrad(const void* dy, int ldy, const void* x, int ldx, int M, int N1, int N2, float alpha, int accumulate,
+                           float* out, int ldo, sf_stream stream) {
+  if (!dy || !x || !out) return sf_set_err(SF_ERR_INVALID, "null argument");
+  float* partial = nullptr;
+  HIP_TRY(hipMalloc(&partial, sf_wgrad_partial_floats(M, N1, N2) * sizeof(float)));
+  SfWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = (const bf16_t*)dy; a.ldy = ldy; a.x = (const bf16_t*)x; a.ldx = ldx; a.M = M; a.N1 = N1; a.N2 = N2;
+  a.out = out; a.ldo = ldo; a.accumulate = accumulate; a.alpha = alpha; a.partial = partial;
+  hipError_t e = sf_launch_wgrad(a, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return sf_set_err(SF_ERR_HIP, "sf_op_wgrad: %s", hipGetErrorString(e));
+  return SF_OK;
+}
+
+extern "C" int sf_op_attention_bwd(const void* qkv, const void* o, const void* d_o, void* d_qkv, int layout, int nseq, int L,
+                                   int seq_rows, int heads, int causal, sf_stream stream) {
+  if (!qkv || !o || !d_o || !d_qkv) return sf_set_err(SF_ERR_INVALID, "null argument");
+  SfAttnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  const int D = heads * 64;
+  a.qkv = (const bf16_t*)qkv; a.ld_qkv = 3 * D; a.o = (const bf16_t*)o; a.ld_o = D; a.d_o = (const bf16_t*)d_o;
+  a.d_qkv = (bf16_t*)d_qkv; a.heads = heads; a.D = D; a.scale = 0.125f; a.L = L; a.nseq = nseq; a.seq_rows = seq_rows;
+  a.causal = causal;
+  HIP_TRY(layout == 0 ? sf_launch_spatial_attention_bwd(a, (hipStream_t)stream) : sf_launch_temporal_attention_bwd(a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_op_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* dx,
+                                   float* d_gamma, float* d_beta, int rows, int D, float eps, sf_stream stream) {
+  if (!x || !dy || !gamma || !dx) return sf_set_err(SF_ERR_INVALID, "null argument");
+  float* partial = nullptr;
+  HIP_TRY(hipMalloc(&partial, sf_ln_bwd_partial_floats(D) * sizeof(float)));
+  hipError_t e = sf_launch_ln_bwd(x, dy, gamma, g_in, dx, d_gamma, d_beta, partial, rows, D, eps, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return sf_set_err(SF_ERR_HIP, "sf_op_layernorm_bwd: %s", hipGetErrorString(e));
+  return SF_OK;
+}

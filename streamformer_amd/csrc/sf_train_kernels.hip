@@ -1,0 +1,525 @@
+// Row-wise, elementwise and parameter-side kernels of the training step:
+// GELU forward/backward (modeling:819-824), LayerNorm backward (nn.LayerNorm at modeling:860-865,
+// 878-880, 1251, 1138), bias / embedding-table gradient reductions, fp32-master -> bf16 working
+// weights (LoRA merge modeling:519-573, temporal gate modeling:954-958), and the fused AdamW update
+// (torch.optim.AdamW as configured by optim_factory.py:59-104).  All HBM-bound; every reduction is
+// two-stage with a fixed order, so gradients are bit-reproducible run to run.
+#include "sf_train.h"
+
+// ------------------------------------------------------------------------------------------------
+// GELU
+// ------------------------------------------------------------------------------------------------
+SF_DEVICE void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = bf2f(v[i] & 0xffffu);
+    f[2 * i + 1] = bf2f(v[i] >> 16);
+  }
+}
+SF_DEVICE u32x4_t pack8(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void sf_gelu_fwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ act,
+                                                          size_t nchunks) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    unpack8(reinterpret_cast<const u32x4_t*>(pre)[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = gelu_erf(f[j]);
+    reinterpret_cast<u32x4_t*>(act)[i] = pack8(f);
+  }
+}
+
+__global__ __launch_bounds__(256) void sf_gelu_bwd_kernel(bf16_t* __restrict__ d, const bf16_t* __restrict__ pre,
+                                                          size_t nchunks) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    float x[8], g[8];
+    unpack8(reinterpret_cast<const u32x4_t*>(pre)[i], x);
+    unpack8(reinterpret_cast<const u32x4_t*>(d)[i], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+      const float cdf = 0.5f * (1.0f + erff(x[j] * 0.70710678118654752440f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * x[j] * x[j]);
+      g[j] *= cdf + x[j] * pdf;
+    }
+    reinterpret_cast<u32x4_t*>(d)[i] = pack8(g);
+  }
+}
+
+static int ew_grid(size_t nchunks) {
+  size_t b = (nchunks + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+hipError_t sf_launch_gelu_fwd(const bf16_t* pre, bf16_t* act, size_t n, hipStream_t s) {
+  if (n % 8) return hipErrorInvalidValue;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(sf_gelu_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, s, pre, act, n / 8);
+  return hipGetLastError();
+}
+hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_t s) {
+  if (n % 8) return hipErrorInvalidValue;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(sf_gelu_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, s, d, pre, n / 8);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row (row in registers), waves walk rows with a grid stride and
+// keep per-lane column sums of dy*xhat / dy; one partial row pair per block, then a column reduce.
+// ------------------------------------------------------------------------------------------------
+#define LN_BWD_MAX_BLOCKS 1024
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ gamma, const float* g_in,
+                                                        float* g_out, float* __restrict__ partial, int rows, int D,
+                                                        float eps) {
+  extern __shared__ float red[];                      // [3][2][D] for waves 1..3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  f32x4_t ag[MAXV], ab[MAXV], gm[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    ag[i] = ab[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int c = i * 64 + lane;
+    gm[i] = c < nv ? reinterpret_cast<const f32x4_t*>(gamma)[c] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_d = 1.0f / (float)D;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D);
+    const f32x4_t* dr = reinterpret_cast<const f32x4_t*>(dy + (size_t)row * D);
+    f32x4_t v[MAXV], d[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nv) {
+        v[i] = xr[c];
+        d[i] = dr[c];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i] = d[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum_dpp(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = v[i][j] - mean;
+          q += t * t;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum_dpp(q) * inv_d + eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (v[i][j] - mean) * rstd;
+          const float dg = d[i][j] * gm[i][j];
+          v[i][j] = xh;                  // keep xhat
+          ag[i][j] += d[i][j] * xh;
+          ab[i][j] += d[i][j];
+          d[i][j] = dg;                  // keep dy * gamma
+          c1 += dg;
+          c2 += dg * xh;
+        }
+      }
+    }
+    c1 = wave_sum_dpp(c1) * inv_d;
+    c2 = wave_sum_dpp(c2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nv) {
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (d[i][j] - c1 - v[i][j] * c2);
+        const size_t off = (size_t)row * D + (size_t)c * 4;
+        if (g_in) o += *reinterpret_cast<const f32x4_t*>(g_in + off);
+        *reinterpret_cast<f32x4_t*>(g_out + off) = o;
+      }
+    }
+  }
+  // block reduce of the column sums (waves 1..3 -> LDS -> wave 0), fixed order
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nv) {
+        *reinterpret_cast<f32x4_t*>(red + ((wave - 1) * 2 + 0) * D + c * 4) = ag[i];
+        *reinterpret_cast<f32x4_t*>(red + ((wave - 1) * 2 + 1) * D + c * 4) = ab[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nv) {
+        for (int w = 0; w < 3; ++w) {
+          ag[i] += *reinterpret_cast<const f32x4_t*>(red + (w * 2 + 0) * D + c * 4);
+          ab[i] += *reinterpret_cast<const f32x4_t*>(red + (w * 2 + 1) * D + c * 4);
+        }
+        *reinterpret_cast<f32x4_t*>(partial + ((size_t)blockIdx.x * 2 + 0) * D + c * 4) = ag[i];
+        *reinterpret_cast<f32x4_t*>(partial + ((size_t)blockIdx.x * 2 + 1) * D + c * 4) = ab[i];
+      }
+    }
+  }
+}
+
+// out0[c] += sum_b partial[b][0][c], out1[c] += sum_b partial[b][1][c]
+__global__ __launch_bounds__(256) void sf_ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                               float* d_gamma, float* d_beta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < nblocks; ++i) {
+    a += partial[((size_t)i * 2 + 0) * D + c];
+    b += partial[((size_t)i * 2 + 1) * D + c];
+  }
+  if (d_gamma) d_gamma[c] += a;
+  if (d_beta) d_beta[c] += b;
+}
+
+size_t sf_ln_bwd_partial_floats(int D) { return (size_t)LN_BWD_MAX_BLOCKS * 2 * D; }
+
+hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* g_out,
+                            float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
+                            hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (D % 4 || D > 64 * 4 * 8) return hipErrorInvalidValue;
+  int blocks = (rows + 3) / 4;
+  if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+  const size_t lds = (size_t)3 * 2 * D * sizeof(float);
+  const int nv = (D / 4 + 63) / 64;
+#define SF_LNB(MV) hipLaunchKernelGGL(sf_ln_bwd_kernel<MV>, dim3(blocks), dim3(256), lds, s, x, dy, gamma, g_in, g_out, partial, rows, D, eps)
+  if (nv <= 1) SF_LNB(1);
+  else if (nv <= 3) SF_LNB(3);
+  else SF_LNB(8);
+#undef SF_LNB
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (d_gamma || d_beta) {
+    hipLaunchKernelGGL(sf_ln_bwd_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partial, blocks, D, d_gamma, d_beta);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums of a bf16 matrix (bias gradients)
+// ------------------------------------------------------------------------------------------------
+#define CS_MAX_CHUNKS 1024
+
+__global__ __launch_bounds__(256) void sf_colsum_bf16_kernel(const bf16_t* __restrict__ x, int rows, int cols, int ld,
+                                                             int rows_per_chunk, float* __restrict__ partial) {
+  __shared__ float red[8][32][9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + tx) * 8;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c0 < cols) {
+    for (int r = r0 + ty; r < r1; r += 8) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(x + (size_t)r * ld + c0), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx][j] = acc[j];
+  __syncthreads();
+  if (ty == 0 && c0 < cols) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+      for (int y = 0; y < 8; ++y) t += red[y][tx][j];
+      if (c0 + j < cols) partial[(size_t)blockIdx.y * cols + c0 + j] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sf_colsum_finish_kernel(const float* __restrict__ partial, int nchunks, int cols,
+                                                               float alpha, float* out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float t = 0.f;
+  for (int i = 0; i < nchunks; ++i) t += partial[(size_t)i * cols + c];
+  out[c] = (accumulate ? out[c] : 0.f) + alpha * t;
+}
+
+size_t sf_colsum_partial_floats(int cols) { return (size_t)CS_MAX_CHUNKS * cols; }
+
+hipError_t sf_launch_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float alpha, float* out, int accumulate,
+                                 float* partial, hipStream_t s) {
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (ld % 8)) return hipErrorInvalidValue;
+  int rpc = 256;
+  while ((rows + rpc - 1) / rpc > CS_MAX_CHUNKS) rpc *= 2;
+  const int nchunks = (rows + rpc - 1) / rpc;
+  hipLaunchKernelGGL(sf_colsum_bf16_kernel, dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, x, rows, cols, ld, rpc, partial);
+  hipLaunchKernelGGL(sf_colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nchunks, cols, alpha, out, accumulate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 row reductions (position / time embedding gradients) and row scatter-add
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_sum_rows_kernel(const float* __restrict__ in, float* out, int n_a, long stride_a,
+                                                          long stride_b, int R, long stride_r, int D, int accumulate) {
+  const int o = blockIdx.x;
+  const long base = (long)(o % n_a) * stride_a + (long)(o / n_a) * stride_b;
+  for (int c = threadIdx.x; c < (D >> 2); c += 256) {
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) t += *reinterpret_cast<const f32x4_t*>(in + (size_t)(base + r * stride_r) * D + c * 4);
+    f32x4_t* dst = reinterpret_cast<f32x4_t*>(out + (size_t)o * D + c * 4);
+    if (accumulate) t += *dst;
+    *dst = t;
+  }
+}
+hipError_t sf_launch_sum_rows(const float* in, float* out, int n_out, int n_a, long stride_a, long stride_b, int R,
+                              long stride_r, int D, int accumulate, hipStream_t s) {
+  if (n_out <= 0) return hipSuccess;
+  if (D % 4 || n_a <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_sum_rows_kernel, dim3(n_out), dim3(256), 0, s, in, out, n_a, stride_a, stride_b, R, stride_r, D, accumulate);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sf_scatter_add_rows_kernel(const float* __restrict__ in, float* out, SfRowIndex idx, int D) {
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) out[(size_t)idx.idx[t] * D + c] += in[(size_t)t * D + c];
+}
+hipError_t sf_launch_scatter_add_rows(const float* in, float* out, const SfRowIndex& idx, int D, hipStream_t s) {
+  if (idx.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sf_scatter_add_rows_kernel, dim3(idx.n), dim3(256), 0, s, in, out, idx, D);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 master weights -> bf16 working copies (row-major and transposed), LoRA merge, gate scaling
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_prep_weight_kernel(const float* __restrict__ w, const float* __restrict__ la,
+                                                             const float* __restrict__ lb, int rank, const float* gate,
+                                                             bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out,
+                                                             int N, int K) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const float scale = gate ? tanhf(*gate) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = w[(size_t)n * K + k];
+      if (la) {
+        float t = 0.f;
+        for (int r = 0; r < rank; ++r) t += lb[(size_t)n * rank + r] * la[(size_t)r * K + k];
+        v += t;
+      }
+      v *= scale;
+      if (w_bf) w_bf[(size_t)n * K + k] = (bf16_t)f2bf(v);
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+  if (wT_bf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + ty + 8 * i, n = n0 + tx;
+      if (n < N && k < K) wT_bf[(size_t)k * N + n] = (bf16_t)f2bf(tile[tx][ty + 8 * i]);
+    }
+  }
+  if (bias_out && blockIdx.x == 0 && threadIdx.x < 32) {
+    const int n = n0 + threadIdx.x;
+    if (n < N) bias_out[n] = bias ? scale * bias[n] : 0.f;
+  }
+}
+
+hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const float* lora_b, int rank, const float* gate,
+                                 bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out, int N, int K,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(sf_prep_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, s, w, lora_a, lora_b, rank,
+                     gate, w_bf, wT_bf, bias, bias_out, N, K);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling-head query (probe path) forward / backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_head_query_kernel(const float* __restrict__ probe, const float* __restrict__ wq,
+                                                            const float* __restrict__ bq, float scale, float* q, int D) {
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (d >= D) return;
+  float t = 0.f;
+  for (int k = lane; k < D; k += 64) t += probe[k] * wq[(size_t)d * D + k];
+  t = wave_sum(t);
+  if (lane == 0) q[d] = (t + bq[d]) * scale;
+}
+hipError_t sf_launch_head_query(const float* probe, const float* wq, const float* bq, float scale, float* q, int D,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(sf_head_query_kernel, dim3((D + 3) / 4), dim3(256), 0, s, probe, wq, bq, scale, q, D);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sf_head_query_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ probe,
+                                                                const float* __restrict__ wq, float scale, float* d_wq,
+                                                                float* d_bq, float* d_probe, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;       // over D*D
+  if (i < D * D) {
+    const int d = i / D, k = i % D;
+    d_wq[i] += scale * dq[d] * probe[k];
+    if (k == 0) d_bq[d] += scale * dq[d];
+  }
+  if (i < D) {                                        // thread k: dprobe[k] = scale * sum_d Wq[d,k] dq[d]
+    float t = 0.f;
+    for (int d = 0; d < D; ++d) t += wq[(size_t)d * D + i] * dq[d];
+    d_probe[i] += scale * t;
+  }
+}
+hipError_t sf_launch_head_query_bwd(const float* dq, const float* probe, const float* wq, float scale, float* d_wq,
+                                    float* d_bq, float* d_probe, int D, hipStream_t s) {
+  hipLaunchKernelGGL(sf_head_query_bwd_kernel, dim3((D * D + 255) / 256), dim3(256), 0, s, dq, probe, wq, scale, d_wq, d_bq, d_probe, D);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LoRA factor gradients from the merged-weight gradient
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_lora_grad_kernel(const float* __restrict__ dW, const float* __restrict__ A,
+                                                           const float* __restrict__ Bm, float* dA, float* dB, int N, int K,
+                                                           int rank) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rank * K) {                                 // dA[r,k] += sum_n B[n,r] dW[n,k]
+    const int r = i / K, k = i % K;
+    float t = 0.f;
+    for (int n = 0; n < N; ++n) t += Bm[(size_t)n * rank + r] * dW[(size_t)n * K + k];
+    dA[i] += t;
+  } else if (i < rank * K + N * rank) {               // dB[n,r] += sum_k dW[n,k] A[r,k]
+    const int j = i - rank * K;
+    const int n = j / rank, r = j % rank;
+    float t = 0.f;
+    for (int k = 0; k < K; ++k) t += dW[(size_t)n * K + k] * A[(size_t)r * K + k];
+    dB[j] += t;
+  }
+}
+hipError_t sf_launch_lora_grad(const float* dW, const float* A, const float* Bm, float* dA, float* dB, int N, int K,
+                               int rank, hipStream_t s) {
+  const int total = rank * K + N * rank;
+  hipLaunchKernelGGL(sf_lora_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dW, A, Bm, dA, dB, N, K, rank);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// temporal gate (one deterministic workgroup: the dot product <G, W> fixes the summation order)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sf_gate_grad_kernel(const float* __restrict__ G, const float* __restrict__ cs,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* gate, float* d_w, float* d_b, float* d_gate, int N,
+                                                            int K) {
+  __shared__ float red[16];
+  const float t = tanhf(*gate);
+  float dot = 0.f;
+  const size_t total = (size_t)N * K;
+  for (size_t i = threadIdx.x; i < total; i += 1024) {
+    const float g = G[i];
+    dot += g * w[i];
+    d_w[i] += t * g;
+  }
+  for (int n = threadIdx.x; n < N; n += 1024) {
+    const float c = cs[n];
+    if (b) dot += c * b[n];
+    if (d_b) d_b[n] += t * c;
+  }
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int i = 0; i < 16; ++i) a += red[i];
+    *d_gate += (1.0f - t * t) * a;
+  }
+}
+hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, const float* b, const float* gate,
+                               float* d_w, float* d_b, float* d_gate, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(sf_gate_grad_kernel, dim3(1), dim3(1024), 0, s, G, cs, w, b, gate, d_w, d_b, d_gate, N, K);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW over the flat parameter buffer (torch.optim.AdamW update order)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_adamw_kernel(SfAdamWArgs a) {
+  const size_t nv = a.n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    const size_t e = i << 2;                     // segments start on multiples of 64 elements
+    int lo = 0, hi = a.nseg - 1;                 // first segment with seg_end > e
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((size_t)a.seg_end[mid] > e) hi = mid; else lo = mid + 1;
+    }
+    if (!a.seg_train[lo]) continue;
+    const float wd = a.seg_decay[lo] ? a.weight_decay : 0.f;
+    f32x4_t p = reinterpret_cast<f32x4_t*>(a.p)[i];
+    f32x4_t g = reinterpret_cast<const f32x4_t*>(a.g)[i];
+    f32x4_t m = reinterpret_cast<f32x4_t*>(a.m)[i];
+    f32x4_t v = reinterpret_cast<f32x4_t*>(a.v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = g[j] * a.grad_scale;
+      p[j] *= 1.0f - a.lr * wd;
+      m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
+      v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
+      const float denom = sqrtf(v[j]) / sqrtf(a.bias_correction2) + a.eps;
+      p[j] -= (a.lr / a.bias_correction1) * (m[j] / denom);
+    }
+    reinterpret_cast<f32x4_t*>(a.p)[i] = p;
+    reinterpret_cast<f32x4_t*>(a.m)[i] = m;
+    reinterpret_cast<f32x4_t*>(a.v)[i] = v;
+  }
+}
+hipError_t sf_launch_adamw(const SfAdamWArgs& a, hipStream_t s) {
+  if (a.n % 4 || a.nseg <= 0) return hipErrorInvalidValue;
+  if (!a.n) return hipSuccess;
+  hipLaunchKernelGGL(sf_adamw_kernel, dim3(ew_grid(a.n / 4)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sf_sumsq_kernel(const float* __restrict__ g, size_t n, float* partial) {
+  __shared__ float red[4];
+  float t = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) t += g[i] * g[i];
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void sf_sumsq_finish_kernel(const float* __restrict__ partial, int n, float* out) {
+  float t = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) t += partial[i];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) out[0] = t;
+}
+hipError_t sf_launch_sumsq(const float* g, size_t n, float* out, float* partial, hipStream_t s) {
+  const int blocks = 1024;
+  hipLaunchKernelGGL(sf_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, partial);
+  hipLaunchKernelGGL(sf_sumsq_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, out);
+  return hipGetLastError();
+}

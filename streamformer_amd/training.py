@@ -1,0 +1,301 @@
+"""Training step of the multitask pre-training (BASELINE configs #3 / #4) on the HIP library.
+
+Host-side mirror of the reference's step:
+
+* ``train_one_epoch_multi_task`` (``tools/finetune_tools.py:395-573``): one task per micro-batch,
+  ``loss /= update_freq``, backward every micro-step, optimizer step + zero_grad every
+  ``update_freq``-th micro-step, lr / weight-decay values written per step from the cosine tables
+  (``utils.py:574-605``, :func:`cosine_scheduler` here);
+* what trains: everything except the spatial ``attention.attention.qkv`` / ``attention.output.dense``
+  base weights when ``freeze_spatial`` (``modeling:1471-1484``); LoRA factors, the temporal branch,
+  the MLPs, embeddings, the pooling head and each task head's ``logit_scale`` / ``logit_bias`` train;
+* AdamW with the ``optim_factory.py:59-104`` grouping (no decay for 1-D and ``*.bias``);
+* data parallel: one process per GPU, gradients summed by RCCL all-reduce in ``L + 2`` slices that are
+  issued as the staged backward finishes them, averaged inside the optimizer kernel
+  (``run_finetuning_multi_task.py:421`` wraps the model in DDP; same mathematics, fewer, larger
+  collectives over xGMI).
+
+All state lives in four flat fp32 device tensors (params / grads / exp_avg / exp_avg_sq) whose layout
+the library defines (``sf_trainer_param_info``); the compute path is the C ABI — there is no torch
+autograd and no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as nat
+from .configuration import StreamformerConfig
+
+_ACT = {"gelu": 0}
+
+
+def cosine_scheduler(base_value: float, final_value: float, epochs: int, niter_per_ep: int, warmup_epochs: int = 0,
+                     start_warmup_value: float = 0.0, warmup_steps: int = -1) -> List[float]:
+    """Per-iteration value table of the reference (``utils.py:574-605``): linear warm-up then half-cosine."""
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_steps > 0:
+        warmup_iters = warmup_steps
+    sched = [start_warmup_value + (base_value - start_warmup_value) * i / max(1, warmup_iters - 1) if warmup_iters > 1
+             else base_value for i in range(warmup_iters)]
+    n = epochs * niter_per_ep - warmup_iters
+    sched += [final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)]
+    assert len(sched) == epochs * niter_per_ep
+    return sched
+
+
+def scaled_lr(lr: float, batch_size: int, update_freq: int, world_size: int) -> float:
+    """``args.lr * total_batch_size / 256`` (``run_finetuning_multi_task.py:386-388``)."""
+    return lr * batch_size * update_freq * world_size / 256.0
+
+
+def bucket_ranges(stage_ranges: Sequence[Tuple[int, int]], min_floats: int) -> List[Tuple[int, int, int]]:
+    """Group consecutive backward stages into all-reduce buckets of at least ``min_floats`` floats.
+
+    Stages finish in order 0, 1, ...; their slices are adjacent going DOWN the buffer (head first, then
+    layers L-1..0, then embeddings), so a bucket is one contiguous slice.  Returns
+    ``(last_stage, offset, numel)`` per bucket: issue it once ``last_stage`` has been enqueued.
+    xGMI rings are per-link bound (7 links x ~153 GB/s): few large slices beat many small ones.
+    """
+    out, lo, hi, count = [], None, None, 0
+    for st, (off, n) in enumerate(stage_ranges):
+        lo = off if lo is None else min(lo, off)
+        hi = off + n if hi is None else max(hi, off + n)
+        count += n
+        if count >= min_floats or st == len(stage_ranges) - 1:
+            out.append((st, lo, hi - lo))
+            lo = hi = None
+            count = 0
+    return out
+
+
+class StreamformerTrainer:
+    """Owns the flat training state of one rank and runs micro-steps through ``libstreamformer_hip``."""
+
+    def __init__(self, config: StreamformerConfig, state_dict: Dict[str, torch.Tensor], task_heads: Sequence[str],
+                 freeze_spatial: bool = True, device="cuda", lr: float = 1e-3, weight_decay: float = 0.05,
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StreamformerTrainer needs an AMD GPU: the training step runs only on the HIP library")
+        if config.hidden_act not in _ACT:
+            raise NotImplementedError(f"training supports hidden_act in {sorted(_ACT)}")
+        if config.attention_type != "divided_space_time":
+            raise NotImplementedError("only divided_space_time is implemented")
+        self.config = config
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.task_heads = list(task_heads)
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.group = process_group
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size(process_group) if dist_on else 1
+        self.rank = torch.distributed.get_rank(process_group) if dist_on else 0
+        c = config
+        sc = nat.SfConfig(c.image_size, c.patch_size, c.num_channels, c.num_frames, c.hidden_size, c.num_hidden_layers,
+                          c.num_attention_heads, c.intermediate_size, _ACT[c.hidden_act], int(c.qkv_bias),
+                          int(c.enable_causal_temporal), int(c.add_lora_spatial), float(c.layer_norm_eps))
+        h = C.c_void_p()
+        nat.check(nat.lib.sf_trainer_create(C.byref(sc), self.device.index or 0, int(freeze_spatial), 2 * len(self.task_heads),
+                                            C.byref(h)))
+        self._h = h
+        # ---- layout -------------------------------------------------------------------------------------
+        self.layout: Dict[str, dict] = {}
+        name = C.create_string_buffer(256)
+        off, numel, nd, tr, dec = C.c_int64(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        for i in range(nat.lib.sf_trainer_num_params(h)):
+            nat.check(nat.lib.sf_trainer_param_info(h, i, name, 256, C.byref(off), C.byref(numel), shape, C.byref(nd),
+                                                    C.byref(tr), C.byref(dec)))
+            self.layout[name.value.decode()] = dict(offset=off.value, numel=numel.value, shape=tuple(shape[:nd.value]),
+                                                    trainable=bool(tr.value), decay=bool(dec.value))
+        total, ntrain = C.c_int64(), C.c_int64()
+        nat.check(nat.lib.sf_trainer_total_floats(h, C.byref(total), C.byref(ntrain)))
+        self.total, self.n_train = total.value, ntrain.value
+        self.extra_slot = {}
+        for i, t in enumerate(self.task_heads):
+            self.extra_slot[f"task_heads.{t}.logit_scale"] = f"extra.{2 * i}"
+            self.extra_slot[f"task_heads.{t}.logit_bias"] = f"extra.{2 * i + 1}"
+        self.stage_ranges = []
+        for st in range(nat.lib.sf_trainer_num_stages(h)):
+            nat.check(nat.lib.sf_trainer_stage_range(h, st, C.byref(off), C.byref(numel)))
+            self.stage_ranges.append((off.value, numel.value))
+        self.buckets = bucket_ranges(self.stage_ranges, int(bucket_mb * (1 << 20) / 4))
+        # ---- state ----------------------------------------------------------------------------------------
+        dev = self.device
+        self.params = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self.micro = 0
+        self._ws = None
+        self._ws_key = None
+        self._pooler = self._lhs = None
+        self.load_state_dict(state_dict)
+        for t in self.task_heads:           # modeling:1363-1364: each head deep-copies log(10) / -2
+            self._view(f"task_heads.{t}.logit_scale").fill_(math.log(10.0))
+            self._view(f"task_heads.{t}.logit_bias").fill_(-2.0)
+        self.sync_weights()
+
+    # ---- parameter access --------------------------------------------------------------------------------
+    def _entry(self, key: str) -> dict:
+        return self.layout[self.extra_slot.get(key, key)]
+
+    def _view(self, key: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        e = self._entry(key)
+        buf = self.params if buf is None else buf
+        return buf[e["offset"]: e["offset"] + e["numel"]].view(e["shape"])
+
+    def parameter_names(self, trainable_only: bool = False) -> List[str]:
+        inv = {v: k for k, v in self.extra_slot.items()}
+        return [inv.get(k, k) for k, e in self.layout.items() if e["trainable"] or not trainable_only]
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        missing = []
+        for k, e in self.layout.items():
+            if k.startswith("extra."):
+                continue
+            if k not in sd:
+                missing.append(k)
+                continue
+            self._view(k).copy_(sd[k].to(torch.float32).reshape(e["shape"]))
+        if missing:
+            raise KeyError(f"state_dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {k: self._view(k).detach().clone() for k in self.layout if not k.startswith("extra.")}
+        for k in self.extra_slot:
+            out[k] = self._view(k).detach().clone()
+        return out
+
+    def grad(self, key: str) -> torch.Tensor:
+        e = self._entry(key)
+        if not e["trainable"]:
+            raise KeyError(f"{key} is frozen")
+        return self.grads[e["offset"]: e["offset"] + e["numel"]].view(e["shape"])
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            nat.lib.sf_trainer_destroy(h)
+            self._h = None
+
+    # ---- the step ---------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return nat.current_stream_handle(self.device)
+
+    def sync_weights(self) -> None:
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib.sf_trainer_sync_weights(self._h, self.params.data_ptr(), self._stream()))
+
+    def _workspace(self, B: int, T: int) -> torch.Tensor:
+        if self._ws_key != (B, T):
+            n = C.c_size_t()
+            nat.check(nat.lib.sf_trainer_workspace_bytes(self._h, B, T, C.byref(n)))
+            self._ws = None
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            self._ws_key = (B, T)
+        return self._ws
+
+    def forward(self, pixel_values: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Forward with saved activations.  Returns (last_hidden_state [B,T,N,D], pooler_output [B,T,D])."""
+        x = pixel_values
+        if x.device != self.device:
+            raise RuntimeError("pixel_values must already be on the trainer's GPU")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        B, T, Cc, H, W = x.shape
+        c = self.config
+        if (Cc, H, W) != (c.num_channels, c.image_size, c.image_size):
+            raise ValueError(f"training takes {c.num_channels}x{c.image_size}x{c.image_size} frames, got {Cc}x{H}x{W}")
+        N = (H // c.patch_size) * (W // c.patch_size)
+        ws = self._workspace(B, T)
+        lhs = torch.empty(B, T, N, c.hidden_size, dtype=torch.float32, device=self.device)
+        pool = torch.empty(B, T, c.hidden_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib.sf_trainer_forward(self._h, x.data_ptr(), nat.SF_BF16 if x.dtype == torch.bfloat16 else nat.SF_F32,
+                                                 B, T, lhs.data_ptr(), pool.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        self._lhs, self._pooler = lhs, pool
+        return lhs, pool
+
+    def backward(self, d_pooler: torch.Tensor, d_last_hidden: Optional[torch.Tensor] = None, reduce: bool = False) -> None:
+        """grads += d loss / d params.  ``reduce``: all-reduce each bucket as soon as its stages are enqueued."""
+        dp = d_pooler.to(torch.float32).contiguous()
+        dl = None if d_last_hidden is None else d_last_hidden.to(torch.float32).contiguous()
+        ws = self._ws
+        works = []
+        nst = len(self.stage_ranges)
+        with torch.cuda.device(self.device):
+            first = 0
+            plan = self.buckets if (reduce and self.world > 1) else [(nst - 1, 0, 0)]
+            for last, off, n in plan:
+                nat.check(nat.lib.sf_trainer_backward(self._h, dp.data_ptr(), nat.ptr(dl), self.grads.data_ptr(), first, last,
+                                                      ws.data_ptr(), ws.numel(), self._stream()))
+                first = last + 1
+                if reduce and self.world > 1:
+                    works.append(torch.distributed.all_reduce(self.grads[off: off + n], group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def loss_and_grad(self, task: str, pooler: torch.Tensor, task_input: dict):
+        """Task-head loss (HIP kernels of heads.py) -> (loss [1], d loss/d pooler, d loss/d (scale, bias))."""
+        from .heads import LocalizationHead, RetrievalHead
+        ls, lb = self._view(f"task_heads.{task}.logit_scale"), self._view(f"task_heads.{task}.logit_bias")
+        scal = torch.stack([ls.reshape(()), lb.reshape(())]).cpu().tolist()
+        if task_input["kind"] == "retrieval":
+            text = task_input["text"]
+            rank = 0
+            if task_input.get("gather_negatives") and self.world > 1:
+                from .parallel import all_gather_rows
+                text = all_gather_rows(text, group=self.group)
+                rank = self.rank
+            return RetrievalHead(*scal).loss(pooler, text, rank=rank)
+        return LocalizationHead(task_input["label_emb"], *scal).loss(pooler, task_input["labels"])
+
+    def micro_step(self, task: str, pixel_values: torch.Tensor, task_input: dict, update_freq: int = 1,
+                   lr: Optional[float] = None, weight_decay: Optional[float] = None,
+                   clip_grad: Optional[float] = None) -> torch.Tensor:
+        """One micro-batch of ``train_one_epoch_multi_task``; returns the (unscaled) loss tensor [1]."""
+        _, pooler = self.forward(pixel_values)
+        loss, gp, gs = self.loss_and_grad(task, pooler, task_input)
+        inv = 1.0 / update_freq
+        gs = gs * inv
+        self.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+        self.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+        self.micro += 1
+        last = self.micro % update_freq == 0
+        self.backward(gp * inv, reduce=last)
+        if last:
+            self.optimizer_step(lr=lr, weight_decay=weight_decay, clip_grad=clip_grad)
+        return loss
+
+    def grad_norm(self) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib.sf_trainer_grad_sumsq(self._h, self.grads.data_ptr(), self._scratch.data_ptr(), self._stream()))
+        return self._scratch[0].sqrt() / self.world
+
+    def optimizer_step(self, lr: Optional[float] = None, weight_decay: Optional[float] = None,
+                       clip_grad: Optional[float] = None) -> None:
+        """AdamW on the trainable prefix, then refresh the bf16 working weights and clear the gradients."""
+        self.step_count += 1
+        scale = 1.0 / self.world                                  # all-reduce summed; DDP averages
+        if clip_grad is not None:                                  # torch.nn.utils.clip_grad_norm_ semantics
+            total = float(self.grad_norm())
+            scale *= min(1.0, clip_grad / (total + 1e-6))
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib.sf_trainer_adamw_step(
+                self._h, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
+                self.weight_decay if weight_decay is None else weight_decay, scale, self._stream()))
+        self.sync_weights()
+        self.grads.zero_()
+
+    def zero_grad(self) -> None:
+        self.grads.zero_()
+        self.micro = 0
