@@ -148,7 +148,7 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
       const int m = m0 + grp * 64 + wave + 8 * j;
-      const bool ok = j < rows_w && m < m_end;
+      const bool ok = j < rows_w && m < m_end && p.resid != nullptr;     // no residual: plain F32 / BF16 output
       const float* rp = p.resid + (size_t)m * (size_t)p.ldc + n0;
       res[j][0] = ok ? *reinterpret_cast<const f32x4_t*>(rp + elane * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       res[j][1] = (ok && elane < 32) ? *reinterpret_cast<const f32x4_t*>(rp + 256 + elane * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
             const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1536 + (((c & ~31) | ((c ^ r) & 31)) << 4));
             const f32x4_t x = res[j][hp] + p.alpha * v;
             const size_t o = (size_t)m * (size_t)p.ldc + n0 + c * 4;
-            *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = x;
+            if (p.out_f32) *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = x;
             if (p.out_hi) {
               *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
               s1 += (x[0] + x[1]) + (x[2] + x[3]);
@@ -233,13 +233,18 @@ static PanelPlan panel_plan(int M) {
 }
 
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split) {
-  if (split || a.epi != SF_EPI_RESID_F32 || a.N != 768 || a.grp_rows > 0) return false;
+  if (split || a.N != 768 || a.grp_rows > 0 || a.out_lo) return false;
+  if (a.epi != SF_EPI_RESID_F32 && a.epi != SF_EPI_F32 && a.epi != SF_EPI_BF16) return false;
+  if (a.ln_stats) return false;                     // LN-folded consumers run on the 256^2 kernel
   if (a.K % 32 || a.K < 128) return false;
   if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32)) return false;
   return panel_plan(a.M).ok != 0;
 }
 
-hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s) {
+hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
+  SfGemmArgs a = a_in;
+  if (a.epi == SF_EPI_F32) { a.resid = nullptr; a.alpha = 1.f; a.out_hi = nullptr; }
+  if (a.epi == SF_EPI_BF16) { a.resid = nullptr; a.alpha = 1.f; a.out_f32 = nullptr; }
   const PanelPlan pl = panel_plan(a.M);
   if (!pl.ok) return hipErrorInvalidValue;
   const int cus = panel_cus();

@@ -82,13 +82,11 @@ hipError_t sf_launch_head_query(const float* probe, const float* wq, const float
 // ... and its backward: dWq += scale * dq (x) probe, dbq += scale * dq, dprobe += scale * Wq^T dq
 hipError_t sf_launch_head_query_bwd(const float* dq, const float* probe, const float* wq, float scale, float* d_wq,
                                     float* d_bq, float* d_probe, int D, hipStream_t s);
-// LoRA factors from the gradient of the merged weight: dA += B^T dW, dB += dW A^T   (W_eff = W + B A)
-hipError_t sf_launch_lora_grad(const float* dW, const float* A, const float* Bm, float* dA, float* dB, int N, int K,
-                               int rank, hipStream_t s);
 // temporal gate: h1 = h + tanh(g) * (t_out W^T + b).  G = unscaled dW, cs = unscaled db (colsum of dL/dh1):
 //   dW += tanh(g) G, db += tanh(g) cs, dgate += (1 - tanh(g)^2) * (<G, W> + <cs, b>)
 hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, const float* b, const float* gate,
-                               float* d_w, float* d_b, float* d_gate, int N, int K, hipStream_t s);
+                               float* d_w, float* d_b, float* d_gate, float* partial /* >= 128 floats */, int N, int K,
+                               hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // optimizer

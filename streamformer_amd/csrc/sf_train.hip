@@ -31,6 +31,8 @@ struct TLin {                    // y = x W^T + b over the flat buffer
   int pgate = -1;                   // temporal_dense: forward weight = tanh(gate) * W
   bf16_t* w = nullptr;              // [N,K] working copy
   bf16_t* wT = nullptr;             // [K,N] for the input-gradient GEMM
+  bf16_t* la_bf = nullptr;          // LoRA A [r,K] and B^T [r,N] (factor gradients through skinny GEMMs)
+  bf16_t* lbT_bf = nullptr;
   float* bias_scaled = nullptr;     // tanh(gate) * b
   bool need_wT = true;
 };
@@ -224,6 +226,7 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
     for (TLin* x : lins) {
       nb += ((size_t)x->N * x->K + 127) & ~(size_t)127;
       if (x->need_wT) nb += ((size_t)x->N * x->K + 127) & ~(size_t)127;
+      if (x->pla >= 0) nb += (((size_t)kRank * x->K + 127) & ~(size_t)127) + (((size_t)kRank * x->N + 127) & ~(size_t)127);
       if (x->pgate >= 0) nf += ((size_t)x->N + 63) & ~(size_t)63;
     }
     nf += (size_t)D + 64 + 2048;          // head query + reduction scratch
@@ -237,6 +240,10 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
       const size_t n = ((size_t)x->N * x->K + 127) & ~(size_t)127;
       x->w = bp; bp += n;
       if (x->need_wT) { x->wT = bp; bp += n; }
+      if (x->pla >= 0) {
+        x->la_bf = bp; bp += ((size_t)kRank * x->K + 127) & ~(size_t)127;
+        x->lbT_bf = bp; bp += ((size_t)kRank * x->N + 127) & ~(size_t)127;
+      }
       if (x->pgate >= 0) { x->bias_scaled = fp; fp += ((size_t)x->N + 63) & ~(size_t)63; }
     }
     t->head_q = fp; fp += (size_t)D + 64;
@@ -309,8 +316,14 @@ extern "C" int sf_trainer_sync_weights(sf_trainer* t, const float* params_dev, s
   HIP_TRY(hipSetDevice(t->device));
   t->params_dev = params_dev;
   auto prep = [&](const TLin& l) -> hipError_t {
-    return sf_launch_prep_weight(PP(t, params_dev, l.pw, l.pw_off), PP(t, params_dev, l.pla), PP(t, params_dev, l.plb), kRank,
-                                 PP(t, params_dev, l.pgate), l.w, l.wT, PP(t, params_dev, l.pb, l.pb_off), l.bias_scaled, l.N, l.K, s);
+    hipError_t e = sf_launch_prep_weight(PP(t, params_dev, l.pw, l.pw_off), PP(t, params_dev, l.pla), PP(t, params_dev, l.plb), kRank,
+                                         PP(t, params_dev, l.pgate), l.w, l.wT, PP(t, params_dev, l.pb, l.pb_off), l.bias_scaled, l.N, l.K, s);
+    if (e == hipSuccess && l.pla >= 0) {
+      e = sf_launch_prep_weight(PP(t, params_dev, l.pla), nullptr, nullptr, 0, nullptr, l.la_bf, nullptr, nullptr, nullptr, kRank, l.K, s);
+      if (e == hipSuccess)
+        e = sf_launch_prep_weight(PP(t, params_dev, l.plb), nullptr, nullptr, 0, nullptr, nullptr, l.lbT_bf, nullptr, nullptr, l.N, kRank, s);
+    }
+    return e;
   };
   HIP_TRY(prep(t->patch));
   for (const TLayer& l : t->layers)
@@ -351,7 +364,7 @@ struct TWs {
   float* attn_out;
   // backward scratch
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
-  bf16_t *g_bf, *d_wide, *d_ctx, *d_tout;
+  bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
   float *gh, *d_hn, *d_pc, *dq_frames, *dq_total;
   bf16_t *gh_bf, *d_hm;
   size_t bytes;
@@ -385,6 +398,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   w.g_bf = c.take<bf16_t>(M * D);
   w.d_wide = c.take<bf16_t>(M * max_sz(I, 3 * D));
   w.d_ctx = c.take<bf16_t>(M * D); w.d_tout = c.take<bf16_t>(M * D);
+  w.lora_u = c.take<bf16_t>(M * kRank); w.lora_v = c.take<bf16_t>(M * kRank);
   size_t wp = 0;
   const int Mi = (int)M, Fi = (int)F, Di = t->D, Ii = t->I;
   wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Di, Ii)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Ii, Di));
@@ -392,6 +406,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   wp = max_sz(wp, sf_wgrad_partial_floats(Mi, 2 * Di, Di)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Di, t->Kp));
   wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Di, Ii)); wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Ii, Di));
   wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Di, Di));
+  wp = max_sz(wp, sf_wgrad_partial_floats(Mi, 3 * Di, kRank)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, kRank, Di));
   w.wg_partial = c.take<float>(wp);
   w.dw_scratch = c.take<float>((size_t)3 * D * D);
   w.cs = c.take<float>(max_sz(I, 3 * D));
@@ -552,13 +567,19 @@ static hipError_t lin_wgrad(const BwdCtx& c, const TLin& l, const bf16_t* dy, co
   a.partial = c.ws->wg_partial;
   hipError_t e = hipSuccess;
   if (l.pla >= 0) {
-    a.out = c.ws->dw_scratch; a.accumulate = 0;
-    if ((e = sf_launch_wgrad(a, c.s)) != hipSuccess) return e;
-    e = sf_launch_lora_grad(c.ws->dw_scratch, PP(t, t->params_dev, l.pla), PP(t, t->params_dev, l.plb), GG(t, c.grads, l.pla),
-                            GG(t, c.grads, l.plb), l.N, l.K, kRank, c.s);
-    if (e != hipSuccess) return e;
-    if (gw) e = sf_launch_sum_rows(c.ws->dw_scratch, gw, l.N, l.N, 1, 0, 1, 0, l.K, 1, c.s);
-  } else if (gw) {
+    // W_eff = W + B A (modeling:541-545):  dB = dy^T (x A^T),  dA = (dy B)^T x  — two rank-32 projections
+    // and two skinny weight-gradient GEMMs instead of the full [N,K] one (the base weight is frozen)
+    if ((e = tgemm(x, l.la_bf, nullptr, M, kRank, l.K, SF_EPI_BF16, c.s, nullptr, c.ws->lora_u)) != hipSuccess) return e;
+    if ((e = tgemm(dy, l.lbT_bf, nullptr, M, kRank, l.N, SF_EPI_BF16, c.s, nullptr, c.ws->lora_v)) != hipSuccess) return e;
+    SfWgradArgs b = a;
+    b.dy = dy; b.ldy = l.N; b.x = c.ws->lora_u; b.ldx = kRank; b.N1 = l.N; b.N2 = kRank; b.ldo = kRank;
+    b.out = GG(t, c.grads, l.plb); b.accumulate = 1;
+    if (b.out && (e = sf_launch_wgrad(b, c.s)) != hipSuccess) return e;
+    b.dy = c.ws->lora_v; b.ldy = kRank; b.x = x; b.ldx = l.K; b.N1 = kRank; b.N2 = l.K; b.ldo = l.K;
+    b.out = GG(t, c.grads, l.pla);
+    if (b.out && (e = sf_launch_wgrad(b, c.s)) != hipSuccess) return e;
+  }
+  if (gw) {
     a.out = gw; a.accumulate = 1;
     e = sf_launch_wgrad(a, c.s);
   }
@@ -651,7 +672,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     HIP_TRY(sf_launch_wgrad(a, s));
     HIP_TRY(sf_launch_colsum_bf16(ws.g_bf, M, D, D, 1.f, ws.cs, 0, ws.cs_partial, s));
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
-                                GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), D, D, s));
+                                GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   }
   HIP_TRY(lin_dgrad(l.t_out, ws.d_tout, M, s, nullptr, ws.d_ctx));
   HIP_TRY(lin_wgrad(c, l.t_out, ws.d_tout, sv.ctx_t, M));

@@ -182,18 +182,29 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
   }
 }
 
-// out0[c] += sum_b partial[b][0][c], out1[c] += sum_b partial[b][1][c]
+// d_gamma[c] += sum_b partial[b][0][c], d_beta[c] += sum_b partial[b][1][c]: 64 columns per block,
+// the four waves split the partial rows, fixed combination order
 __global__ __launch_bounds__(256) void sf_ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                                float* d_gamma, float* d_beta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= D) return;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float a = 0.f, b = 0.f;
-  for (int i = 0; i < nblocks; ++i) {
-    a += partial[((size_t)i * 2 + 0) * D + c];
-    b += partial[((size_t)i * 2 + 1) * D + c];
+  if (c < D) {
+    for (int i = wave; i < nblocks; i += 4) {
+      a += partial[((size_t)i * 2 + 0) * D + c];
+      b += partial[((size_t)i * 2 + 1) * D + c];
+    }
   }
-  if (d_gamma) d_gamma[c] += a;
-  if (d_beta) d_beta[c] += b;
+  red[0][wave][lane] = a;
+  red[1][wave][lane] = b;
+  __syncthreads();
+  if (wave == 0 && c < D) {
+    a = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    b = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    if (d_gamma) d_gamma[c] += a;
+    if (d_beta) d_beta[c] += b;
+  }
 }
 
 size_t sf_ln_bwd_partial_floats(int D) { return (size_t)LN_BWD_MAX_BLOCKS * 2 * D; }
@@ -215,7 +226,7 @@ hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (d_gamma || d_beta) {
-    hipLaunchKernelGGL(sf_ln_bwd_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partial, blocks, D, d_gamma, d_beta);
+    hipLaunchKernelGGL(sf_ln_bwd_finish_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, blocks, D, d_gamma, d_beta);
     e = hipGetLastError();
   }
   return e;
@@ -259,11 +270,18 @@ __global__ __launch_bounds__(256) void sf_colsum_bf16_kernel(const bf16_t* __res
 
 __global__ __launch_bounds__(256) void sf_colsum_finish_kernel(const float* __restrict__ partial, int nchunks, int cols,
                                                                float alpha, float* out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float t = 0.f;
-  for (int i = 0; i < nchunks; ++i) t += partial[(size_t)i * cols + c];
-  out[c] = (accumulate ? out[c] : 0.f) + alpha * t;
+  if (c < cols)
+    for (int i = wave; i < nchunks; i += 4) t += partial[(size_t)i * cols + c];
+  red[wave][lane] = t;
+  __syncthreads();
+  if (wave == 0 && c < cols) {
+    t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[c] = (accumulate ? out[c] : 0.f) + alpha * t;
+  }
 }
 
 size_t sf_colsum_partial_floats(int cols) { return (size_t)CS_MAX_CHUNKS * cols; }
@@ -275,7 +293,7 @@ hipError_t sf_launch_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, fl
   while ((rows + rpc - 1) / rpc > CS_MAX_CHUNKS) rpc *= 2;
   const int nchunks = (rows + rpc - 1) / rpc;
   hipLaunchKernelGGL(sf_colsum_bf16_kernel, dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, x, rows, cols, ld, rpc, partial);
-  hipLaunchKernelGGL(sf_colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nchunks, cols, alpha, out, accumulate);
+  hipLaunchKernelGGL(sf_colsum_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nchunks, cols, alpha, out, accumulate);
   return hipGetLastError();
 }
 
@@ -401,65 +419,55 @@ hipError_t sf_launch_head_query_bwd(const float* dq, const float* probe, const f
 }
 
 // ------------------------------------------------------------------------------------------------
-// LoRA factor gradients from the merged-weight gradient
+// temporal gate: GATE_BLOCKS workgroups update dW and produce partial dots, a finish kernel combines
+// them in a fixed order
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sf_lora_grad_kernel(const float* __restrict__ dW, const float* __restrict__ A,
-                                                           const float* __restrict__ Bm, float* dA, float* dB, int N, int K,
-                                                           int rank) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < rank * K) {                                 // dA[r,k] += sum_n B[n,r] dW[n,k]
-    const int r = i / K, k = i % K;
-    float t = 0.f;
-    for (int n = 0; n < N; ++n) t += Bm[(size_t)n * rank + r] * dW[(size_t)n * K + k];
-    dA[i] += t;
-  } else if (i < rank * K + N * rank) {               // dB[n,r] += sum_k dW[n,k] A[r,k]
-    const int j = i - rank * K;
-    const int n = j / rank, r = j % rank;
-    float t = 0.f;
-    for (int k = 0; k < K; ++k) t += dW[(size_t)n * K + k] * A[(size_t)r * K + k];
-    dB[j] += t;
-  }
-}
-hipError_t sf_launch_lora_grad(const float* dW, const float* A, const float* Bm, float* dA, float* dB, int N, int K,
-                               int rank, hipStream_t s) {
-  const int total = rank * K + N * rank;
-  hipLaunchKernelGGL(sf_lora_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dW, A, Bm, dA, dB, N, K, rank);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// temporal gate (one deterministic workgroup: the dot product <G, W> fixes the summation order)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sf_gate_grad_kernel(const float* __restrict__ G, const float* __restrict__ cs,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            const float* gate, float* d_w, float* d_b, float* d_gate, int N,
-                                                            int K) {
-  __shared__ float red[16];
+#define GATE_BLOCKS 128
+__global__ __launch_bounds__(256) void sf_gate_grad_kernel(const float* __restrict__ G, const float* __restrict__ cs,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* gate, float* d_w, float* d_b, float* partial, int N,
+                                                           int K) {
+  __shared__ float red[4];
   const float t = tanhf(*gate);
   float dot = 0.f;
-  const size_t total = (size_t)N * K;
-  for (size_t i = threadIdx.x; i < total; i += 1024) {
-    const float g = G[i];
-    dot += g * w[i];
-    d_w[i] += t * g;
+  const size_t nv = ((size_t)N * K) >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)GATE_BLOCKS * 256) {
+    const f32x4_t g = reinterpret_cast<const f32x4_t*>(G)[i];
+    const f32x4_t ww = reinterpret_cast<const f32x4_t*>(w)[i];
+    dot += (g[0] * ww[0] + g[1] * ww[1]) + (g[2] * ww[2] + g[3] * ww[3]);
+    if (d_w) {
+      f32x4_t d = reinterpret_cast<f32x4_t*>(d_w)[i];
+      d += g * t;
+      reinterpret_cast<f32x4_t*>(d_w)[i] = d;
+    }
   }
-  for (int n = threadIdx.x; n < N; n += 1024) {
-    const float c = cs[n];
-    if (b) dot += c * b[n];
-    if (d_b) d_b[n] += t * c;
+  if (blockIdx.x == 0) {
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float c = cs[n];
+      if (b) dot += c * b[n];
+      if (d_b) d_b[n] += t * c;
+    }
   }
   dot = wave_sum(dot);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float a = 0.f;
-    for (int i = 0; i < 16; ++i) a += red[i];
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void sf_gate_grad_finish_kernel(const float* __restrict__ partial, const float* gate,
+                                                                 float* d_gate) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < GATE_BLOCKS; i += 64) a += partial[i];
+  a = wave_sum(a);
+  if (threadIdx.x == 0 && d_gate) {
+    const float t = tanhf(*gate);
     *d_gate += (1.0f - t * t) * a;
   }
 }
 hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, const float* b, const float* gate,
-                               float* d_w, float* d_b, float* d_gate, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL(sf_gate_grad_kernel, dim3(1), dim3(1024), 0, s, G, cs, w, b, gate, d_w, d_b, d_gate, N, K);
+                               float* d_w, float* d_b, float* d_gate, float* partial, int N, int K, hipStream_t s) {
+  if (((size_t)N * K) % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_gate_grad_kernel, dim3(GATE_BLOCKS), dim3(256), 0, s, G, cs, w, b, gate, d_w, d_b, partial, N, K);
+  hipLaunchKernelGGL(sf_gate_grad_finish_kernel, dim3(1), dim3(64), 0, s, partial, gate, d_gate);
   return hipGetLastError();
 }
 

@@ -181,7 +181,7 @@ class StreamformerTrainer:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and nat is not None and getattr(nat, "lib", None) is not None:    # interpreter shutdown: globals may be gone
             nat.lib.sf_trainer_destroy(h)
             self._h = None
 
