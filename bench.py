@@ -17,6 +17,9 @@ Extra objects on that line:
   accurate_mode frames/s of the fp32-accurate (bf16x3) mode on the same workload
   cpu_baseline  the CPU oracle (a restatement pinned against the reference, kind "port") timed on the
                 host cores on a bounded sample: B=1 clips of the same shape
+  train_step    BASELINE configs[2]: frames/s of one multitask pre-training step (forward + loss + backward +
+                AdamW) on the same clip shape, with its own CPU baseline; `--mode train` makes that step THE
+                timed step (configs[2] at N=1, configs[3] with the gradient all-reduce at N>1)
 """
 from __future__ import annotations
 
@@ -49,6 +52,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="batches in flight: consecutive steps alternate over this many HIP streams")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run of the N>1 path with every rank on cuda:0")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward = BASELINE configs[1] (the headline metric); train = configs[2]/[3]: one multitask "
+                         "pre-training step (forward + loss + backward + gradient all-reduce + AdamW) per GPU batch")
+    ap.add_argument("--no-train", action="store_true", help="forward mode: skip the short training-step measurement")
     return ap.parse_args()
 
 
@@ -110,6 +117,77 @@ def timed_steps(model, x, steps, warmup, dist, world, nstreams=1):
     return dt
 
 
+# forward + input-gradient + weight-gradient products, minus the weight-gradient GEMMs of the frozen spatial
+# qkv / output.dense (12 x (11.098 + 3.699) GF per clip; their rank-32 LoRA factors cost < 1 %): SURVEY.md §8(d)
+TRAIN_GFLOP_PER_FRAME = (3 * 790.48 - 12 * (11.098 + 3.699)) / 16
+
+
+def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
+    """Time `steps` training micro-steps (update_freq = 1) of the LoRA recipe: SigLIP-base, add_lora_spatial,
+    spatial base weights frozen, tasks alternating retrieval / localization, AdamW, gradients all-reduced."""
+    import streamformer_amd as sa
+    from streamformer_amd.training import StreamformerTrainer, scaled_lr
+    cfg = sa.siglip_base(add_lora_spatial=True)
+    sd = sa.make_state_dict(cfg, seed=0, lora=True)
+    B, T, D = args.batch, cfg.num_frames, cfg.hidden_size
+    tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device=dev,
+                             lr=scaled_lr(2e-5, B, 1, world), weight_decay=0.05)
+    g = torch.Generator().manual_seed(2000 + rank)
+    x = torch.randn(B, T, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
+    lab = torch.randn(20, D, generator=g)
+    lab = (lab / lab.norm(dim=-1, keepdim=True)).to(dev)
+    tasks = [("retrieval", {"kind": "retrieval", "text": torch.randn(B, D, generator=g).to(dev)}),
+             ("localization", {"kind": "localization", "label_emb": lab,
+                               "labels": torch.randint(-1, 20, (B, T), generator=g).to(dev)})]
+    losses = []
+    for i in range(warmup):
+        tr.micro_step(*tasks[i % 2][:1], x, tasks[i % 2][1])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        losses.append(tr.micro_step(tasks[i % 2][0], x, tasks[i % 2][1]))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * T * steps / dt
+    res = {"value": round(value, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "clips_per_gpu": B, "losses_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "trainable_params": int(sum(e["numel"] for e in tr.layout.values() if e["trainable"])),
+           "grad_allreduce_MB": round(tr.n_train * 4 / 1e6, 1), "allreduce_buckets": len(tr.buckets),
+           "workspace_GiB": round(tr._ws.numel() / 2**30, 2),
+           "e2e_mfma_frac": round(value / world * TRAIN_GFLOP_PER_FRAME / 1e3 / PEAK_BF16_TFLOPS, 4),
+           "recipe": "SigLIP-base + LoRA r=32 on spatial attention, spatial base frozen, retrieval/localization alternating, "
+                     "AdamW (fp32 master weights, bf16 MFMA operands), update_freq 1"}
+    if with_cpu and rank == 0:
+        # CPU baseline of the same step: the oracle's autograd + torch.optim.AdamW on ONE clip (bounded sample)
+        from oracle import train_oracle as TO
+        cores = args.cpu_threads or usable_cores()
+        torch.set_num_threads(cores)
+        orc = TO.OracleTrainer(sd, cfg, ["retrieval", "localization"], freeze_spatial=True, lr=1e-5)
+        x1 = x[:1].cpu()
+        ti = {"kind": "localization", "label_emb": lab.cpu(), "labels": tasks[1][1]["labels"][:1].cpu()}
+        t0 = time.perf_counter(); orc.micro_step("localization", x1, ti); t1 = time.perf_counter() - t0
+        ts = []
+        for _ in range(max(1, min(3, int(20.0 / max(t1, 1e-3))))):
+            t0 = time.perf_counter(); orc.micro_step("localization", x1, ti); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        res["cpu_baseline"] = {"value": round(T / ts[len(ts) // 2], 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"{len(ts)} training steps of one [1,16,3,224,224] clip (torch autograd + AdamW, fp32) after 1 warm-up"}
+        res["speedup_vs_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    del tr
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,6 +213,24 @@ def main():
 
     import streamformer_amd as sa
     from streamformer_amd import _native as nat
+
+    if args.mode == "train":
+        r = train_bench(args, dev, dist, world, rank, args.steps, args.warmup, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        if rank == 0:
+            out = {"metric": "frames/s (multitask pre-training step, 16x224^2 clips)", "value": r["value"], "unit": "frames/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                   "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: multitask pre-training step, "
+                                          f"{args.batch} clips x 16 x 224^2 per GPU, " + r["recipe"],
+                              "global_batch_clips": args.batch * world, "parallelism": f"dp{world}",
+                              "collective": "RCCL all-reduce of the fp32 gradient buffer in buckets issued behind the staged backward"
+                                            if world > 1 else "none"}}
+            out.update({k: v for k, v in r.items() if k not in ("value", "unit", "ms_per_step", "steps", "recipe")})
+            print(json.dumps(out), flush=True)
+        if world > 1 and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     cfg = sa.siglip_base()
     sd = sa.make_state_dict(cfg, seed=0)
@@ -258,6 +354,14 @@ def main():
                                              f"(median {med:.3f}s, best {ts[0]:.3f}s), fp32 eager torch {torch.__version__}",
                                    "cpu": cpu_model, "best": round(T / ts[0], 2)}
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        if world == 1 and not args.no_train:
+            # BASELINE configs[2]: the multitask pre-training step on the same clip shape (short measurement;
+            # `--mode train` times it under the full contract, also at N > 1)
+            try:
+                torch.cuda.empty_cache()
+                out["train_step"] = train_bench(args, dev, dist, world, rank, 6, 2, with_cpu=not args.no_cpu_baseline)
+            except Exception as e:      # never lose the headline line to the extra measurement
+                out["train_step"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1 and dist.is_initialized():
         dist.barrier()

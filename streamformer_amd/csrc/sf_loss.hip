@@ -99,73 +99,104 @@ hipError_t sf_launch_retrieval_loss(const float* pooler, const float* text, int 
 
 // per frame (b,t): z[l] = s * <p/|p|, E_l> + bias ; target +1 at labels[b,t] (if >= 0) else -1
 // loss = mean_b( -sum_{t,l} logsigmoid(y z) / T )
+// One workgroup per frame row writes {loss, d scale, d bias} partials; a finish workgroup adds them in
+// row order (deterministic).
 __global__ __launch_bounds__(256) void sf_localization_loss_kernel(const float* __restrict__ pooler,
                                                                    const float* __restrict__ label_emb,
                                                                    const int* __restrict__ labels, int B, int T,
                                                                    int D, int L, float logit_scale, float logit_bias,
-                                                                   float* __restrict__ loss,
-                                                                   float* __restrict__ grad_pooler,
-                                                                   float* __restrict__ grad_scalars) {
+                                                                   float* __restrict__ partial,
+                                                                   float* __restrict__ grad_pooler) {
   extern __shared__ float sm[];
-  float* simr = sm;          // [L] similarity of the current row
+  float* simr = sm;          // [L] similarity of the row
   float* dzr = simr + L;     // [L]
   float* red = dzr + L;      // [4]
-  float* nrm = red + 4;      // [1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float s = expf(logit_scale);
   const float wgt = 1.f / ((float)T * (float)B);
   float lsum = 0.f, gs = 0.f, gb = 0.f;
-  for (int row = 0; row < B * T; ++row) {
-    const float* x = pooler + (size_t)row * D;
-    float a = 0.f;
-    for (int d = threadIdx.x; d < D; d += 256) a = fmaf(x[d], x[d], a);
-    a = block_sum(a, red);
-    const float n = sqrtf(a);
-    const int lab = labels[row];
-    for (int l = wave; l < L; l += 4) {
-      const float* e = label_emb + (size_t)l * D;
-      float c = 0.f;
-      for (int d = lane; d < D; d += 64) c = fmaf(x[d], e[d], c);
-      c = wave_sum(c) / n;
-      const float z = s * c + logit_bias;
-      const float y = (lab >= 0 && lab == l) ? 1.f : -1.f;
-      const float g = -y * sigmoidf(-y * z) * wgt;
-      if (lane == 0) {
-        simr[l] = c;
-        dzr[l] = g;
-        lsum += -log_sigmoid(y * z) * wgt;
-        gs += g * s * c;
-        gb += g;
-      }
+  const int row = blockIdx.x;
+  const float* x = pooler + (size_t)row * D;
+  float a = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) a = fmaf(x[d], x[d], a);
+  a = block_sum(a, red);
+  const float n = sqrtf(a);
+  const int lab = labels[row];
+  for (int l = wave; l < L; l += 4) {
+    const float* e = label_emb + (size_t)l * D;
+    float c = 0.f;
+    for (int d = lane; d < D; d += 64) c = fmaf(x[d], e[d], c);
+    c = wave_sum(c) / n;
+    const float z = s * c + logit_bias;
+    const float y = (lab >= 0 && lab == l) ? 1.f : -1.f;
+    const float g = -y * sigmoidf(-y * z) * wgt;
+    if (lane == 0) {
+      simr[l] = c;
+      dzr[l] = g;
+      lsum += -log_sigmoid(y * z) * wgt;
+      gs += g * s * c;
+      gb += g;
     }
-    __syncthreads();
-    if (grad_pooler) {
-      float dotg = 0.f;
-      for (int l = 0; l < L; ++l) dotg += dzr[l] * s * simr[l];
-      for (int d = threadIdx.x; d < D; d += 256) {
-        float g = 0.f;
-        for (int l = 0; l < L; ++l) g = fmaf(dzr[l] * s, label_emb[(size_t)l * D + d], g);
-        grad_pooler[(size_t)row * D + d] = (g - x[d] / n * dotg) / n;
-      }
+  }
+  __syncthreads();
+  if (grad_pooler) {
+    float dotg = 0.f;
+    for (int l = 0; l < L; ++l) dotg += dzr[l] * s * simr[l];
+    for (int d = threadIdx.x; d < D; d += 256) {
+      float g = 0.f;
+      for (int l = 0; l < L; ++l) g = fmaf(dzr[l] * s, label_emb[(size_t)l * D + d], g);
+      grad_pooler[(size_t)row * D + d] = (g - x[d] / n * dotg) / n;
     }
-    __syncthreads();
   }
   lsum = block_sum(lsum, red);
   gs = block_sum(gs, red);
   gb = block_sum(gb, red);
   if (threadIdx.x == 0) {
-    loss[0] = lsum;
-    if (grad_scalars) { grad_scalars[0] = gs; grad_scalars[1] = gb; }
+    partial[row * 3 + 0] = lsum;
+    partial[row * 3 + 1] = gs;
+    partial[row * 3 + 2] = gb;
   }
-  (void)nrm;
+}
+
+__global__ __launch_bounds__(64) void sf_localization_loss_finish_kernel(const float* __restrict__ partial, int rows,
+                                                                         float* __restrict__ loss,
+                                                                         float* __restrict__ grad_scalars) {
+  if (threadIdx.x != 0) return;
+  float l = 0.f, gs = 0.f, gb = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    l += partial[r * 3 + 0];
+    gs += partial[r * 3 + 1];
+    gb += partial[r * 3 + 2];
+  }
+  loss[0] = l;
+  if (grad_scalars) { grad_scalars[0] = gs; grad_scalars[1] = gb; }
+}
+
+// per-device scratch for the row partials (grown on demand; the loss heads take no workspace argument)
+static float* loc_scratch(int rows) {
+  static float* buf[64] = {nullptr};
+  static int cap[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (cap[dev] < rows) {
+    if (buf[dev]) (void)hipFree(buf[dev]);
+    buf[dev] = nullptr;
+    const int want = rows < 4096 ? 4096 : rows;
+    if (hipMalloc(&buf[dev], (size_t)want * 3 * sizeof(float)) != hipSuccess) { cap[dev] = 0; return nullptr; }
+    cap[dev] = want;
+  }
+  return buf[dev];
 }
 
 hipError_t sf_launch_localization_loss(const float* pooler, const float* label_emb, const int* labels,
                                        int B, int T, int D, int L, float logit_scale, float logit_bias,
                                        float* loss, float* grad_pooler, float* grad_scalars, hipStream_t s) {
   if (B <= 0 || T <= 0 || D <= 0 || L <= 0 || L > 4096) return hipErrorInvalidValue;
+  float* partial = loc_scratch(B * T);
+  if (!partial) return hipErrorOutOfMemory;
   const size_t lds = (size_t)(2 * L + 8) * sizeof(float);
-  hipLaunchKernelGGL(sf_localization_loss_kernel, dim3(1), dim3(256), lds, s, pooler, label_emb, labels, B, T, D, L,
-                     logit_scale, logit_bias, loss, grad_pooler, grad_scalars);
+  hipLaunchKernelGGL(sf_localization_loss_kernel, dim3(B * T), dim3(256), lds, s, pooler, label_emb, labels, B, T, D, L,
+                     logit_scale, logit_bias, partial, grad_pooler);
+  hipLaunchKernelGGL(sf_localization_loss_finish_kernel, dim3(1), dim3(64), 0, s, partial, B * T, loss, grad_scalars);
   return hipGetLastError();
 }

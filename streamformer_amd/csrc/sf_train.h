@@ -76,6 +76,15 @@ hipError_t sf_launch_scatter_add_rows(const float* in, float* out, const SfRowIn
 hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const float* lora_b, int rank,
                                  const float* gate, bf16_t* w_bf, bf16_t* wT_bf, const float* bias,
                                  float* bias_out, int N, int K, hipStream_t s);
+// the same for a table of weights in one launch; offsets are floats from `base` (-1 = absent)
+struct SfPrepJob {
+  long w_off, la_off, lb_off, gate_off, bias_off;
+  bf16_t* w_bf; bf16_t* wT_bf; float* bias_out;
+  int N, K, rank;
+  int tile0;                 // first workgroup of this job (32x32 tiles, k fastest)
+};
+hipError_t sf_launch_prep_weights_batched(const float* base, const SfPrepJob* jobs_dev, int njobs, int total_tiles,
+                                          hipStream_t s);
 // pooling-head query: q[D] = (probe * Wq^T + bq) * scale     (modeling:1145-1149 with nn.MultiheadAttention)
 hipError_t sf_launch_head_query(const float* probe, const float* wq, const float* bq, float scale, float* q, int D,
                                 hipStream_t s);

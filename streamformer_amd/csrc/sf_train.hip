@@ -63,6 +63,8 @@ struct sf_trainer {
   float* farena = nullptr;          // scaled biases, head query, reduction scratch
   float* head_q = nullptr;
   float* red_partial = nullptr;
+  SfPrepJob* prep_jobs = nullptr;   // device table for sf_trainer_sync_weights
+  int n_prep_jobs = 0, prep_tiles = 0;
   const float* params_dev = nullptr;
   int fB = 0, fT = 0;               // geometry of the last forward (0 = none)
 };
@@ -96,6 +98,7 @@ static void free_trainer_device(sf_trainer* t) {
   if (t->seg_train) (void)hipFree(t->seg_train);
   if (t->arena) (void)hipFree(t->arena);
   if (t->farena) (void)hipFree(t->farena);
+  if (t->prep_jobs) (void)hipFree(t->prep_jobs);
 }
 
 extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_spatial, int n_extra, sf_trainer** out) {
@@ -248,6 +251,31 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
     }
     t->head_q = fp; fp += (size_t)D + 64;
     t->red_partial = fp;
+    // one-launch weight refresh: job table with offsets into the flat parameter buffer
+    std::vector<SfPrepJob> jobs;
+    int tiles = 0;
+    auto push = [&](long w_off, long la, long lb, int rank, long gate, long bias, bf16_t* w_bf, bf16_t* wT_bf, float* bias_out, int N, int K) {
+      SfPrepJob j;
+      j.w_off = w_off; j.la_off = la; j.lb_off = lb; j.gate_off = gate; j.bias_off = bias;
+      j.w_bf = w_bf; j.wT_bf = wT_bf; j.bias_out = bias_out; j.N = N; j.K = K; j.rank = rank; j.tile0 = tiles;
+      tiles += ((N + 31) / 32) * ((K + 31) / 32);
+      jobs.push_back(j);
+    };
+    auto off = [&](int idx, size_t extra = 0) -> long { return idx < 0 ? -1 : (long)(t->params[idx].off + extra); };
+    for (TLin* x : lins) {
+      push(off(x->pw, x->pw_off), off(x->pla), off(x->plb), kRank, off(x->pgate), x->pgate >= 0 ? off(x->pb, x->pb_off) : -1, x->w, x->wT,
+           x->bias_scaled, x->N, x->K);
+      if (x->pla >= 0) {
+        push(off(x->pla), -1, -1, 0, -1, -1, x->la_bf, nullptr, nullptr, kRank, x->K);
+        push(off(x->plb), -1, -1, 0, -1, -1, nullptr, x->lbT_bf, nullptr, x->N, kRank);
+      }
+    }
+    t->n_prep_jobs = (int)jobs.size(); t->prep_tiles = tiles;
+    if (hipMalloc(&t->prep_jobs, jobs.size() * sizeof(SfPrepJob)) != hipSuccess) {
+      free_trainer_device(t); delete t;
+      return sf_set_err(SF_ERR_HIP, "hipMalloc failed (prep table)");
+    }
+    (void)hipMemcpy(t->prep_jobs, jobs.data(), jobs.size() * sizeof(SfPrepJob), hipMemcpyHostToDevice);
   }
   *out = t;
   return SF_OK;
@@ -315,20 +343,7 @@ extern "C" int sf_trainer_sync_weights(sf_trainer* t, const float* params_dev, s
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(t->device));
   t->params_dev = params_dev;
-  auto prep = [&](const TLin& l) -> hipError_t {
-    hipError_t e = sf_launch_prep_weight(PP(t, params_dev, l.pw, l.pw_off), PP(t, params_dev, l.pla), PP(t, params_dev, l.plb), kRank,
-                                         PP(t, params_dev, l.pgate), l.w, l.wT, PP(t, params_dev, l.pb, l.pb_off), l.bias_scaled, l.N, l.K, s);
-    if (e == hipSuccess && l.pla >= 0) {
-      e = sf_launch_prep_weight(PP(t, params_dev, l.pla), nullptr, nullptr, 0, nullptr, l.la_bf, nullptr, nullptr, nullptr, kRank, l.K, s);
-      if (e == hipSuccess)
-        e = sf_launch_prep_weight(PP(t, params_dev, l.plb), nullptr, nullptr, 0, nullptr, nullptr, l.lbT_bf, nullptr, nullptr, l.N, kRank, s);
-    }
-    return e;
-  };
-  HIP_TRY(prep(t->patch));
-  for (const TLayer& l : t->layers)
-    for (const TLin* x : {&l.t_qkv, &l.t_out, &l.t_dense, &l.s_qkv, &l.s_out, &l.up, &l.down}) HIP_TRY(prep(*x));
-  for (const TLin* x : {&t->head_kv, &t->head_out, &t->fc1, &t->fc2}) HIP_TRY(prep(*x));
+  HIP_TRY(sf_launch_prep_weights_batched(params_dev, t->prep_jobs, t->n_prep_jobs, t->prep_tiles, s));
   // nn.MultiheadAttention scales q by head_dim^-0.5 after the in-projection (modeling:1145-1149)
   HIP_TRY(sf_launch_head_query(PP(t, params_dev, t->p_probe), PP(t, params_dev, t->p_inw), PP(t, params_dev, t->p_inb), 0.125f,
                                t->head_q, t->D, s));

@@ -73,7 +73,7 @@ hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_
 // LayerNorm backward: one wave per row (row in registers), waves walk rows with a grid stride and
 // keep per-lane column sums of dy*xhat / dy; one partial row pair per block, then a column reduce.
 // ------------------------------------------------------------------------------------------------
-#define LN_BWD_MAX_BLOCKS 1024
+#define LN_BWD_MAX_BLOCKS 512
 
 template <int MAXV>
 __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -183,15 +183,15 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
 }
 
 // d_gamma[c] += sum_b partial[b][0][c], d_beta[c] += sum_b partial[b][1][c]: 64 columns per block,
-// the four waves split the partial rows, fixed combination order
-__global__ __launch_bounds__(256) void sf_ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
-                                                               float* d_gamma, float* d_beta) {
-  __shared__ float red[2][4][64];
+// the sixteen waves split the partial rows, fixed combination order
+__global__ __launch_bounds__(1024) void sf_ln_bwd_finish_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                                float* d_gamma, float* d_beta) {
+  __shared__ float red[2][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float a = 0.f, b = 0.f;
   if (c < D) {
-    for (int i = wave; i < nblocks; i += 4) {
+    for (int i = wave; i < nblocks; i += 16) {
       a += partial[((size_t)i * 2 + 0) * D + c];
       b += partial[((size_t)i * 2 + 1) * D + c];
     }
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_finish_kernel(const float* __re
   red[1][wave][lane] = b;
   __syncthreads();
   if (wave == 0 && c < D) {
-    a = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-    b = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    a = b = 0.f;
+    for (int w = 0; w < 16; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
     if (d_gamma) d_gamma[c] += a;
     if (d_beta) d_beta[c] += b;
   }
@@ -226,7 +226,7 @@ hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (d_gamma || d_beta) {
-    hipLaunchKernelGGL(sf_ln_bwd_finish_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, blocks, D, d_gamma, d_beta);
+    hipLaunchKernelGGL(sf_ln_bwd_finish_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, partial, blocks, D, d_gamma, d_beta);
     e = hipGetLastError();
   }
   return e;
@@ -333,13 +333,11 @@ hipError_t sf_launch_scatter_add_rows(const float* in, float* out, const SfRowIn
 // ------------------------------------------------------------------------------------------------
 // fp32 master weights -> bf16 working copies (row-major and transposed), LoRA merge, gate scaling
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sf_prep_weight_kernel(const float* __restrict__ w, const float* __restrict__ la,
-                                                             const float* __restrict__ lb, int rank, const float* gate,
-                                                             bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out,
-                                                             int N, int K) {
-  __shared__ float tile[32][33];
+SF_DEVICE void prep_tile(const float* __restrict__ w, const float* __restrict__ la, const float* __restrict__ lb, int rank,
+                         const float* gate, bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out, int N, int K,
+                         int kt, int nt, float (*tile)[33]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int k0 = kt * 32, n0 = nt * 32;
   const float scale = gate ? tanhf(*gate) : 1.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -365,10 +363,18 @@ __global__ __launch_bounds__(256) void sf_prep_weight_kernel(const float* __rest
       if (n < N && k < K) wT_bf[(size_t)k * N + n] = (bf16_t)f2bf(tile[tx][ty + 8 * i]);
     }
   }
-  if (bias_out && blockIdx.x == 0 && threadIdx.x < 32) {
+  if (bias_out && kt == 0 && threadIdx.x < 32) {
     const int n = n0 + threadIdx.x;
     if (n < N) bias_out[n] = bias ? scale * bias[n] : 0.f;
   }
+}
+
+__global__ __launch_bounds__(256) void sf_prep_weight_kernel(const float* __restrict__ w, const float* __restrict__ la,
+                                                             const float* __restrict__ lb, int rank, const float* gate,
+                                                             bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out,
+                                                             int N, int K) {
+  __shared__ float tile[32][33];
+  prep_tile(w, la, lb, rank, gate, w_bf, wT_bf, bias, bias_out, N, K, blockIdx.x, blockIdx.y, tile);
 }
 
 hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const float* lora_b, int rank, const float* gate,
@@ -376,6 +382,29 @@ hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const floa
                                  hipStream_t s) {
   hipLaunchKernelGGL(sf_prep_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, s, w, lora_a, lora_b, rank,
                      gate, w_bf, wT_bf, bias, bias_out, N, K);
+  return hipGetLastError();
+}
+
+// every weight of the model in ONE launch: workgroup -> (job, tile) through the jobs' tile prefix sums
+__global__ __launch_bounds__(256) void sf_prep_weights_batched_kernel(const float* __restrict__ base,
+                                                                      const SfPrepJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = njobs - 1;                   // last job with tile0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SfPrepJob j = jobs[lo];
+  const int t = blockIdx.x - j.tile0;
+  const int tiles_k = (j.K + 31) / 32;
+  prep_tile(base + j.w_off, j.la_off >= 0 ? base + j.la_off : nullptr, j.lb_off >= 0 ? base + j.lb_off : nullptr, j.rank,
+            j.gate_off >= 0 ? base + j.gate_off : nullptr, j.w_bf, j.wT_bf, j.bias_off >= 0 ? base + j.bias_off : nullptr,
+            j.bias_out, j.N, j.K, t % tiles_k, t / tiles_k, tile);
+}
+hipError_t sf_launch_prep_weights_batched(const float* base, const SfPrepJob* jobs_dev, int njobs, int total_tiles,
+                                          hipStream_t s) {
+  if (njobs <= 0 || total_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sf_prep_weights_batched_kernel, dim3(total_tiles), dim3(256), 0, s, base, jobs_dev, njobs);
   return hipGetLastError();
 }
 
