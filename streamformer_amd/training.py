@@ -36,14 +36,17 @@ _ACT = {"gelu": 0}
 def cosine_scheduler(base_value: float, final_value: float, epochs: int, niter_per_ep: int, warmup_epochs: int = 0,
                      start_warmup_value: float = 0.0, warmup_steps: int = -1) -> List[float]:
     """Per-iteration value table of the reference (``utils.py:574-605``): linear warm-up then half-cosine."""
-    warmup_iters = warmup_epochs * niter_per_ep
+    warmup_iters = int(warmup_epochs * niter_per_ep)
     if warmup_steps > 0:
         warmup_iters = warmup_steps
-    sched = [start_warmup_value + (base_value - start_warmup_value) * i / max(1, warmup_iters - 1) if warmup_iters > 1
-             else base_value for i in range(warmup_iters)]
+    sched: List[float] = []
+    if warmup_epochs > 0:            # np.linspace(start, base, warmup_iters): both endpoints included
+        sched = [start_warmup_value if warmup_iters == 1 else
+                 start_warmup_value + (base_value - start_warmup_value) * i / (warmup_iters - 1) for i in range(warmup_iters)]
     n = epochs * niter_per_ep - warmup_iters
     sched += [final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)]
-    assert len(sched) == epochs * niter_per_ep
+    if len(sched) != epochs * niter_per_ep:
+        raise ValueError("warmup_steps without warmup_epochs leaves the table short (the reference asserts here too)")
     return sched
 
 

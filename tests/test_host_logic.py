@@ -164,3 +164,32 @@ def test_window_starts_match_reference_formula():
         w = window_starts(n)
         assert len(w) == n // 6 and w[0] == 0 and (np.diff(w) >= 0).all()
         assert (w[-1] == n) == (n // 6 > 1)        # with >1 windows the last start is n itself -> clamped to the final 6 frames
+
+
+# ---- training host logic (streamformer_amd/training.py; reference utils.py:574-605, run_finetuning_multi_task.py:386) ----
+def test_cosine_scheduler_table():
+    import math
+    from streamformer_amd.training import cosine_scheduler, scaled_lr
+    s = cosine_scheduler(1.0, 0.1, epochs=4, niter_per_ep=10, warmup_epochs=1, start_warmup_value=0.0)
+    assert len(s) == 40
+    assert s[0] == 0.0 and abs(s[9] - 1.0) < 1e-12                 # linspace includes both ends
+    assert all(b > a for a, b in zip(s[:9], s[1:10]))
+    assert abs(s[10] - 1.0) < 1e-12                                  # cosine part starts at the base value
+    assert abs(s[25] - (0.1 + 0.45 * (1 + math.cos(math.pi * 15 / 30)))) < 1e-12
+    assert s[-1] > 0.1 and all(b <= a + 1e-15 for a, b in zip(s[10:], s[11:]))
+    flat = cosine_scheduler(0.05, 0.05, 2, 5)                        # weight-decay table of the recipe: constant
+    assert flat == [0.05] * 10
+    assert abs(scaled_lr(2e-5, 8, 1, 8) - 2e-5 * 64 / 256) < 1e-18
+
+
+def test_allreduce_bucket_plan():
+    from streamformer_amd.training import bucket_ranges
+    # stage slices as the library lays them out: head last in the buffer, finished first
+    stages = [(900, 100)] + [(100 + 200 * i, 200) for i in (3, 2, 1, 0)] + [(0, 100)]
+    b = bucket_ranges(stages, 250)
+    assert [x[0] for x in b] == [1, 3, 5]
+    covered = sorted((off, off + n) for _, off, n in b)
+    assert covered[0][0] == 0 and covered[-1][1] == 1000
+    assert all(a[1] == c[0] for a, c in zip(covered, covered[1:]))      # contiguous, disjoint, complete
+    one = bucket_ranges(stages, 10**9)
+    assert one == [(5, 0, 1000)]

@@ -312,3 +312,62 @@ def test_base_model_gradients_match_oracle():
     torch.cuda.synchronize()
     assert abs(float(loss) - float(want)) < 2e-2 * abs(float(want))
     _compare_grads(tr, orc)
+
+
+# ---------------------------------------------------------------------------------------------------
+# data parallel: 2 ranks (both on cuda:0, gloo) == one rank on the concatenated batch
+# ---------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from oracle import train_oracle as TO
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        cfg = small_cfg(add_lora_spatial=True)
+        sd = make_state_dict(cfg, seed=8, lora=True)
+        tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device="cuda:0", bucket_mb=0.05)
+        assert len(tr.buckets) > 1
+        task, x, ti, _ = TO.schedule(cfg, B=4)[1]
+        lo, hi = rank * 2, rank * 2 + 2
+        ti_r = {"kind": "localization", "label_emb": ti["label_emb"].cuda(), "labels": ti["labels"][lo:hi].cuda()}
+        _, pooler = tr.forward(x[lo:hi].cuda())
+        _, gp, gs = tr.loss_and_grad(task, pooler, ti_r)
+        tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+        tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+        tr.backward(gp, reduce=True)
+        torch.cuda.synchronize()
+        if rank == 0:
+            ret["grads"] = (tr.grads / world).cpu()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_allreduced_gradients_equal_the_big_batch():
+    import torch.multiprocessing as mp
+    from oracle import train_oracle as TO
+    _dev()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, 29655, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    cfg = small_cfg(add_lora_spatial=True)
+    tr, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True)
+    task, x, ti, _ = TO.schedule(cfg, B=4)[1]
+    dev = tr.device
+    _, pooler = tr.forward(x.to(dev))
+    _, gp, gs = tr.loss_and_grad(task, pooler, _to_dev(ti, dev))
+    tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+    tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+    tr.backward(gp)
+    torch.cuda.synchronize()
+    # mean over 4 clips == average of the two ranks' means over 2 clips; only summation order differs
+    assert rel_l2(ret["grads"], tr.grads.cpu()) < 2e-3
