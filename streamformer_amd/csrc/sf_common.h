@@ -129,10 +129,12 @@ struct SfGemmArgs {
   float* ln_stats_out;
   const float* ln_stats; const float* ln_s; float ln_eps;
 };
-hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches 128^2 / 256^2
+hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches skinny / panel / 256^2 / 128^2
 hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   // sf_gemm.hip
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split);                      // sf_gemm256.hip
 hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s);
+bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split);                  // sf_gemm_skinny.hip (M <= 512)
+hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s);
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip
 hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 

@@ -14,6 +14,7 @@
 //     fragment pair (hi*hi + hi*lo + lo*hi), BK halves so the LDS footprint stays 64 KB.
 //   * block id -> tile map is XCD-aware: the 8 XCDs each walk a contiguous band of row panels.
 #include "sf_common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -221,6 +222,7 @@ static hipError_t launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStre
 }
 
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
+  if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);
   if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
   return sf_launch_gemm128(a, split, s);

@@ -1,0 +1,200 @@
+// "Skinny" MFMA GEMM for few token rows (M <= 512): the per-frame streaming step (M = 196 rows per
+// call, vqa_enc:1316-1392), the pooling-head MLP (M = frames) and small test shapes.
+//   C[M,N] = A[M,K] * W[N,K]^T (+ the same fused epilogues as sf_gemm.hip)
+//
+// Why a separate kernel: at M = 196 the 128x128 tiling yields 12-48 workgroups on 256 CUs and every
+// Linear of the streaming step costs 18-60 us although its weight matrix (1.2-4.7 MB) streams in ~1 us.
+// Here a workgroup owns a [112 rows x 16 columns] output tile and the whole K range:
+//   * N/16 x ceil(M/112) workgroups (96 for N = 768 at one frame, 384 for N = 3072);
+//   * 4 waves, wave w multiplies m-tiles {w, w+4} (7 m-tiles of 16 rows) against the one 16-column
+//     weight fragment; no split-K, so the result is deterministic and every epilogue stays fused;
+//   * operands go HBM/L2 -> LDS by global_load_lds into a 4-stage ring of [112+16 rows x 64 k] tiles,
+//     three K-tiles in flight, ONE barrier per K-tile, counted vmcnt (never 0 in steady state);
+//   * the A panel is re-read by the N/16 column workgroups from L2 (it is 0.3-1.2 MB), the weights are
+//     read exactly once: the kernel is bound by L2 -> LDS delivery of the A stream per CU.
+// SPLIT = the fp32-accurate bf16x3 mode (hi/lo planes of both operands, three MFMAs per fragment pair).
+#include "sf_common.h"
+
+#define SK_BM 112
+#define SK_MT 7
+#define SK_BN 16
+#define SK_BK 64
+#define SK_THREADS 256
+#define SK_STAGES 4
+#define SK_ROWS (SK_BM + SK_BN)               // A rows then W rows in one stage image
+#define SK_PLANE (SK_ROWS * SK_BK * 2)        // 16 KB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+SF_DEVICE f32x4_t sk_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+SF_DEVICE bf16x8_t sk_frag(const char* img, int row, int kc) {
+  return *reinterpret_cast<const bf16x8_t*>(img + row * (SK_BK * 2) + ((kc ^ ((row >> 1) & 7)) << 4));
+}
+template <int N>
+SF_DEVICE void sk_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool SPLIT, int EPI>
+__global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p) {
+  constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);     // hi plane (+ lo plane)
+  constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // 16-byte chunks per thread per plane = 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
+
+  // per-thread DMA sources: chunk c of the stage image = (row, 16-byte slot); rows 0..111 = A, 112..127 = W
+  const bf16_t* src_hi[LOADS];
+  const bf16_t* src_lo[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int c = i * SK_THREADS + tid;
+    const int row = c >> 3, slot = c & 7;
+    const int kc = slot ^ ((row >> 1) & 7);
+    if (row < SK_BM) {
+      int gr = m0 + row;
+      gr = gr < p.M ? gr : p.M - 1;
+      src_hi[i] = p.a_hi + (size_t)gr * p.K + kc * 8;
+      src_lo[i] = SPLIT ? p.a_lo + (size_t)gr * p.K + kc * 8 : nullptr;
+    } else {
+      int gr = n0 + row - SK_BM;
+      gr = gr < p.N ? gr : p.N - 1;
+      src_hi[i] = p.w_hi + (size_t)gr * p.K + kc * 8;
+      src_lo[i] = SPLIT ? p.w_lo + (size_t)gr * p.K + kc * 8 : nullptr;
+    }
+  }
+  auto issue = [&](int kt) {
+    char* dst = smem + (kt % SK_STAGES) * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
+      if (SPLIT) __builtin_amdgcn_global_load_lds((gptr_t)(src_lo[i] + kt * SK_BK), (lptr_t)(dst + SK_PLANE + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[2];
+  acc[0] = acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nkt = p.K / SK_BK;
+  constexpr int PER = LOADS * (SPLIT ? 2 : 1);            // load instructions per stage per thread
+  const bool two = wave + 4 < SK_MT;                      // wave 3 owns one m-tile
+
+  for (int s = 0; s < SK_STAGES - 1 && s < nkt; ++s) issue(s);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // stage kt complete: at most the later in-flight stages may remain outstanding
+    const int later = min(nkt - 1 - kt, SK_STAGES - 2);
+    if (later >= 2) sk_wait<2 * PER>(); else if (later == 1) sk_wait<PER>(); else sk_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + SK_STAGES - 1 < nkt) issue(kt + SK_STAGES - 1);     // overwrites the stage read in iteration kt-1
+    const char* img = smem + (kt % SK_STAGES) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 4 + g;
+      const bf16x8_t wf = sk_frag(img, SK_BM + l15, kc);
+      const bf16x8_t a0 = sk_frag(img, wave * 16 + l15, kc);
+      const bf16x8_t a1 = two ? sk_frag(img, (wave + 4) * 16 + l15, kc) : a0;
+      if (SPLIT) {
+        const char* lo = img + SK_PLANE;
+        const bf16x8_t wl = sk_frag(lo, SK_BM + l15, kc);
+        const bf16x8_t b0 = sk_frag(lo, wave * 16 + l15, kc);
+        const bf16x8_t b1 = two ? sk_frag(lo, (wave + 4) * 16 + l15, kc) : b0;
+        acc[0] = sk_mfma(wl, a0, acc[0]);
+        acc[0] = sk_mfma(wf, b0, acc[0]);
+        acc[0] = sk_mfma(wf, a0, acc[0]);
+        if (two) {
+          acc[1] = sk_mfma(wl, a1, acc[1]);
+          acc[1] = sk_mfma(wf, b1, acc[1]);
+          acc[1] = sk_mfma(wf, a1, acc[1]);
+        }
+      } else {
+        acc[0] = sk_mfma(wf, a0, acc[0]);
+        if (two) acc[1] = sk_mfma(wf, a1, acc[1]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds C[m = tile row l15][n = n0 + 4g .. 4g+3] ----------------------------------
+  const int n = n0 + g * 4;
+  if (n >= p.N) return;
+  f32x4_t bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (q == 1 && !two) break;
+    const int m = m0 + (wave + 4 * q) * 16 + l15;
+    if (m >= p.M) continue;
+    size_t orow = (size_t)m;
+    if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+    f32x4_t v = acc[q] + bias;
+    const size_t o = orow * (size_t)p.ldc + n;
+    if (EPI == SF_EPI_F32) {
+      *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+    } else if (EPI == SF_EPI_RESID_F32) {
+      const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.resid + o);
+      v = r + p.alpha * v;
+      *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+    } else if (EPI == SF_EPI_EMBED_F32) {
+      const int pn = m % p.Np, tt = (m / p.Np) % p.Tn;
+      const f32x4_t pe = *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)pn * p.N + n);
+      const f32x4_t te = *reinterpret_cast<const f32x4_t*>(p.time_rows + (size_t)tt * p.N + n);
+      v = v + pe + te;
+      *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+    } else {
+      if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_fast(v[j], p.act);
+      }
+      unsigned int h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf(v[j], h[j], l[j]);
+      *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+      if (p.out_lo) *reinterpret_cast<u32x2_t*>(p.out_lo + o) = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    }
+  }
+}
+
+bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
+  if (a.M <= 0 || a.M > 512 || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
+  if (a.ln_stats || a.ln_stats_out) return false;
+  if (a.epi == SF_EPI_RESID_F32 && a.out_hi) return false;         // LayerNorm-fold producer: panel kernel only
+  if (split && (!a.a_lo || !a.w_lo)) return false;
+  return true;
+}
+
+template <bool SPLIT>
+static hipError_t sk_launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+#define SK_CASE(E)                                                                               \
+  case E:                                                                                        \
+    hipLaunchKernelGGL((sf_gemm_skinny_kernel<SPLIT, E>), grid, dim3(SK_THREADS), lds, s, a);    \
+    break;
+  switch (a.epi) {
+    SK_CASE(SF_EPI_F32)
+    SK_CASE(SF_EPI_BF16)
+    SK_CASE(SF_EPI_ACT_BF16)
+    SK_CASE(SF_EPI_RESID_F32)
+    SK_CASE(SF_EPI_EMBED_F32)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef SK_CASE
+  return hipGetLastError();
+}
+
+hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s) {
+  if (!sf_gemm_skinny_supported(a, split)) return hipErrorInvalidValue;
+  const dim3 grid((a.N + SK_BN - 1) / SK_BN, (a.M + SK_BM - 1) / SK_BM);
+  const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+#define SK_ATTR(S, E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
+    SK_ATTR(false, SF_EPI_F32) SK_ATTR(false, SF_EPI_BF16) SK_ATTR(false, SF_EPI_ACT_BF16)
+    SK_ATTR(false, SF_EPI_RESID_F32) SK_ATTR(false, SF_EPI_EMBED_F32)
+    SK_ATTR(true, SF_EPI_F32) SK_ATTR(true, SF_EPI_BF16) SK_ATTR(true, SF_EPI_ACT_BF16)
+    SK_ATTR(true, SF_EPI_RESID_F32) SK_ATTR(true, SF_EPI_EMBED_F32)
+#undef SK_ATTR
+    attr_set = true;
+  }
+  return split ? sk_launch_epi<true>(a, grid, lds, s) : sk_launch_epi<false>(a, grid, lds, s);
+}
