@@ -4,25 +4,25 @@
 //
 // Why a separate kernel: at M = 196 the 128x128 tiling yields 12-48 workgroups on 256 CUs and every
 // Linear of the streaming step costs 18-60 us although its weight matrix (1.2-4.7 MB) streams in ~1 us.
-// Here a workgroup owns a [112 rows x 16 columns] output tile and the whole K range:
-//   * N/16 x ceil(M/112) workgroups (96 for N = 768 at one frame, 384 for N = 3072);
-//   * 4 waves, wave w multiplies m-tiles {w, w+4} (7 m-tiles of 16 rows) against the one 16-column
-//     weight fragment; no split-K, so the result is deterministic and every epilogue stays fused;
-//   * operands go HBM/L2 -> LDS by global_load_lds into a 4-stage ring of [112+16 rows x 64 k] tiles,
-//     three K-tiles in flight, ONE barrier per K-tile, counted vmcnt (never 0 in steady state);
-//   * the A panel is re-read by the N/16 column workgroups from L2 (it is 0.3-1.2 MB), the weights are
-//     read exactly once: the kernel is bound by L2 -> LDS delivery of the A stream per CU.
+// These launches are latency-bound (Little's law on the bytes a CU keeps in flight), so the tile is
+// made SMALL and the ring DEEP:
+//   * a workgroup owns a [32 rows x 32 columns] output tile and the whole K range: N/32 x ceil(M/32)
+//     workgroups (168 for N = 768 at one frame, 672 for N = 3072); no split-K, so the result is
+//     deterministic and every epilogue stays fused;
+//   * 4 waves, one 16x16 MFMA tile each;
+//   * operands go HBM/L2 -> LDS by global_load_lds into an 8-stage ring of [32+32 rows x 64 k] tiles
+//     (8 KB per stage), seven K-tiles in flight, ONE barrier per K-tile, counted vmcnt;
+//   * A is re-read by the N/32 column workgroups from L2 (it is 0.3-1.2 MB), W by the M/32 row groups.
 // SPLIT = the fp32-accurate bf16x3 mode (hi/lo planes of both operands, three MFMAs per fragment pair).
 #include "sf_common.h"
 
-#define SK_BM 112
-#define SK_MT 7
-#define SK_BN 16
+#define SK_BM 32
+#define SK_BN 32
 #define SK_BK 64
 #define SK_THREADS 256
-#define SK_STAGES 4
+#define SK_STAGES 8
 #define SK_ROWS (SK_BM + SK_BN)               // A rows then W rows in one stage image
-#define SK_PLANE (SK_ROWS * SK_BK * 2)        // 16 KB
+#define SK_PLANE (SK_ROWS * SK_BK * 2)        // 8 KB
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -40,13 +40,13 @@ SF_DEVICE void sk_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory
 template <bool SPLIT, int EPI>
 __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p) {
   constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);     // hi plane (+ lo plane)
-  constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // 16-byte chunks per thread per plane = 4
+  constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // 16-byte chunks per thread per plane = 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
 
-  // per-thread DMA sources: chunk c of the stage image = (row, 16-byte slot); rows 0..111 = A, 112..127 = W
+  // per-thread DMA sources: chunk c of the stage image = (row, 16-byte slot); rows 0..31 = A, 32..63 = W
   const bf16_t* src_hi[LOADS];
   const bf16_t* src_lo[LOADS];
 #pragma unroll
@@ -75,59 +75,52 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
     }
   };
 
-  f32x4_t acc[2];
-  acc[0] = acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   const int nkt = p.K / SK_BK;
   constexpr int PER = LOADS * (SPLIT ? 2 : 1);            // load instructions per stage per thread
-  const bool two = wave + 4 < SK_MT;                      // wave 3 owns one m-tile
+  const int mt = wave & 1, nt = wave >> 1;                // this wave's 16x16 output tile
 
   for (int s = 0; s < SK_STAGES - 1 && s < nkt; ++s) issue(s);
   for (int kt = 0; kt < nkt; ++kt) {
     // stage kt complete: at most the later in-flight stages may remain outstanding
-    const int later = min(nkt - 1 - kt, SK_STAGES - 2);
-    if (later >= 2) sk_wait<2 * PER>(); else if (later == 1) sk_wait<PER>(); else sk_wait<0>();
+    switch (min(nkt - 1 - kt, SK_STAGES - 2)) {
+      case 6: sk_wait<6 * PER>(); break;
+      case 5: sk_wait<5 * PER>(); break;
+      case 4: sk_wait<4 * PER>(); break;
+      case 3: sk_wait<3 * PER>(); break;
+      case 2: sk_wait<2 * PER>(); break;
+      case 1: sk_wait<PER>(); break;
+      default: sk_wait<0>(); break;
+    }
     __builtin_amdgcn_s_barrier();
     if (kt + SK_STAGES - 1 < nkt) issue(kt + SK_STAGES - 1);     // overwrites the stage read in iteration kt-1
     const char* img = smem + (kt % SK_STAGES) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 4 + g;
-      const bf16x8_t wf = sk_frag(img, SK_BM + l15, kc);
-      const bf16x8_t a0 = sk_frag(img, wave * 16 + l15, kc);
-      const bf16x8_t a1 = two ? sk_frag(img, (wave + 4) * 16 + l15, kc) : a0;
+      const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
+      const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
       if (SPLIT) {
         const char* lo = img + SK_PLANE;
-        const bf16x8_t wl = sk_frag(lo, SK_BM + l15, kc);
-        const bf16x8_t b0 = sk_frag(lo, wave * 16 + l15, kc);
-        const bf16x8_t b1 = two ? sk_frag(lo, (wave + 4) * 16 + l15, kc) : b0;
-        acc[0] = sk_mfma(wl, a0, acc[0]);
-        acc[0] = sk_mfma(wf, b0, acc[0]);
-        acc[0] = sk_mfma(wf, a0, acc[0]);
-        if (two) {
-          acc[1] = sk_mfma(wl, a1, acc[1]);
-          acc[1] = sk_mfma(wf, b1, acc[1]);
-          acc[1] = sk_mfma(wf, a1, acc[1]);
-        }
-      } else {
-        acc[0] = sk_mfma(wf, a0, acc[0]);
-        if (two) acc[1] = sk_mfma(wf, a1, acc[1]);
+        const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
+        const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
+        acc = sk_mfma(wl, af, acc);
+        acc = sk_mfma(wf, al, acc);
       }
+      acc = sk_mfma(wf, af, acc);
     }
   }
 
-  // ---- epilogue: lane holds C[m = tile row l15][n = n0 + 4g .. 4g+3] ----------------------------------
-  const int n = n0 + g * 4;
-  if (n >= p.N) return;
+  // ---- epilogue: lane holds C[m = tile row l15][n = tile col 4g .. 4g+3] ----------------------------------
+  const int n = n0 + nt * 16 + g * 4;
+  const int m = m0 + mt * 16 + l15;
+  if (n >= p.N || m >= p.M) return;
   f32x4_t bias = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (q == 1 && !two) break;
-    const int m = m0 + (wave + 4 * q) * 16 + l15;
-    if (m >= p.M) continue;
+  {
     size_t orow = (size_t)m;
     if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
-    f32x4_t v = acc[q] + bias;
+    f32x4_t v = acc + bias;
     const size_t o = orow * (size_t)p.ldc + n;
     if (EPI == SF_EPI_F32) {
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
