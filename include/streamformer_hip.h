@@ -203,9 +203,10 @@ int sf_trainer_adamw_step(sf_trainer* tr, float* params_dev, const float* grads_
 int sf_trainer_grad_sumsq(sf_trainer* tr, const float* grads_dev, float* out_dev, sf_stream stream);
 
 /* single backward operators (parity tests).  bf16 tensors are raw uint16 device buffers.         */
-/* C[N1,N2] = alpha * dY^T X  (+ C) : dy [M,ldy], x [M,ldx] bf16; out fp32 [N1,ldo]               */
+/* C[N1,N2] = alpha * dY^T X  (+ C) : dy [M,ldy], x [M,ldx] bf16; out fp32 [N1,ldo];
+ * dbias_dev (optional) fp32 [N1] += alpha * column sums of dY (the bias gradient of the same Linear) */
 int sf_op_wgrad(const void* dy_dev, int ldy, const void* x_dev, int ldx, int M, int N1, int N2, float alpha,
-                int accumulate, float* out_dev, int ldo, sf_stream stream);
+                int accumulate, float* out_dev, int ldo, float* dbias_dev, sf_stream stream);
 /* attention backward; layout 0 = spatial (nseq sequences of L consecutive token rows),
  * 1 = temporal (token row of (b, t, n) = (b*L + t)*seq_rows + n, nseq = B*seq_rows).
  * qkv/d_qkv bf16 [rows, 3D], o/d_o bf16 [rows, D].                                               */

@@ -74,7 +74,7 @@ SIGNATURES = {
     "sf_trainer_backward": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
     "sf_trainer_adamw_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P]),
     "sf_trainer_grad_sumsq": (_I, [_P, _P, _P, _P]),
-    "sf_op_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "sf_op_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     "sf_op_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sf_op_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "sf_bench_gemm": (_I, [_P, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double)]),

@@ -19,6 +19,8 @@ struct SfWgradArgs {
   int accumulate;                  // out += result (else out = result)
   float alpha;                     // result scaled by alpha
   float* partial;                  // scratch, >= sf_wgrad_partial_floats(...) floats
+  float* dbias;                    // optional: dbias[N1] += alpha * column sums of dY (bias gradient)
+  float* dbias_scratch;            // >= sf_colsum_partial_floats(N1) floats (used when the tile kernel cannot fuse it)
 };
 size_t sf_wgrad_partial_floats(int M, int N1, int N2);
 hipError_t sf_launch_wgrad(const SfWgradArgs& a, hipStream_t s);
@@ -52,11 +54,12 @@ hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const 
 hipError_t sf_launch_gelu_fwd(const bf16_t* pre, bf16_t* act, size_t n, hipStream_t s);
 // d = d * gelu'(pre)   in place
 hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_t s);
-// LayerNorm backward over rows of x (statistics recomputed): g_out = (g_in ? g_in : 0) + dL/dx;
+// LayerNorm backward over rows of x (statistics recomputed): g_out = (g_in ? g_in : 0) + dL/dx, optionally
+// also as a bf16 copy (the A operand of the next input-gradient GEMM);
 // d_gamma += sum_rows dy * xhat, d_beta += sum_rows dy.   partial: >= sf_ln_bwd_partial_floats(D)
 size_t sf_ln_bwd_partial_floats(int D);
 hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* g_out,
-                            float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
+                            bf16_t* g_out_bf, float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
                             hipStream_t s);
 // out[c] += alpha * sum_r x[r, c]   (bias gradients); partial >= sf_colsum_partial_floats(cols)
 size_t sf_colsum_partial_floats(int cols);

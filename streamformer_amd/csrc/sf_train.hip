@@ -596,10 +596,11 @@ static hipError_t lin_wgrad(const BwdCtx& c, const TLin& l, const bf16_t* dy, co
   }
   if (gw) {
     a.out = gw; a.accumulate = 1;
+    a.dbias = gb; a.dbias_scratch = c.ws->cs_partial;      // bias gradient rides on the same launch
     e = sf_launch_wgrad(a, c.s);
+  } else if (gb) {
+    e = sf_launch_colsum_bf16(dy, M, l.N, l.N, 1.f, gb, 1, c.ws->cs_partial, c.s);
   }
-  if (e != hipSuccess) return e;
-  if (gb) e = sf_launch_colsum_bf16(dy, M, l.N, l.N, 1.f, gb, 1, c.ws->cs_partial, c.s);
   return e;
 }
 
@@ -618,10 +619,9 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   HIP_TRY(sf_launch_gelu_bwd(ws.d_hm, ws.hm_pre, (size_t)F * I, s));
   HIP_TRY(lin_dgrad(t->fc1, ws.d_hm, F, s, ws.d_hn, nullptr));
   HIP_TRY(lin_wgrad(c, t->fc1, ws.d_hm, ws.hn, F));
-  HIP_TRY(sf_launch_ln_bwd(ws.attn_out, ws.d_hn, PP(t, P0, t->hln_g), d_pooler, ws.gh, GG(t, c.grads, t->hln_g), GG(t, c.grads, t->hln_b),
+  HIP_TRY(sf_launch_ln_bwd(ws.attn_out, ws.d_hn, PP(t, P0, t->hln_g), d_pooler, ws.gh, ws.gh_bf, GG(t, c.grads, t->hln_g), GG(t, c.grads, t->hln_b),
                            ws.ln_partial, F, D, eps, s));
-  // attn_out = out_proj(ctx)
-  HIP_TRY(sf_launch_split(ws.gh, ws.gh_bf, nullptr, (size_t)F * D, s));
+  // attn_out = out_proj(ctx)   (gh_bf = bf16(gh) written by the LayerNorm backward)
   HIP_TRY(lin_dgrad(t->head_out, ws.gh_bf, F, s, ws.d_pc, nullptr));
   HIP_TRY(lin_wgrad(c, t->head_out, ws.gh_bf, ws.pc, F));
   // probe attention over the N tokens of every frame
@@ -634,7 +634,7 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   HIP_TRY(lin_dgrad(t->head_kv, d_kv, M, s, ws.d_ln, nullptr));
   if (d_lhs) HIP_TRY(sf_launch_sum_rows(d_lhs, ws.d_ln, M, M, 1, 0, 1, 0, D, 1, s));
   // post_layernorm: g = dLN(h_L)
-  HIP_TRY(sf_launch_ln_bwd(ws.h[t->L], ws.d_ln, PP(t, P0, t->post_g), nullptr, ws.g, GG(t, c.grads, t->post_g), GG(t, c.grads, t->post_b),
+  HIP_TRY(sf_launch_ln_bwd(ws.h[t->L], ws.d_ln, PP(t, P0, t->post_g), nullptr, ws.g, ws.g_bf, GG(t, c.grads, t->post_g), GG(t, c.grads, t->post_b),
                            ws.ln_partial, M, D, eps, s));
   return SF_OK;
 }
@@ -649,19 +649,17 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   const int M = B * T * N, F = B * T;
   const float eps = t->cfg.layer_norm_eps;
   const float* P0 = t->params_dev;
-  const size_t MD = (size_t)M * D;
 
+  // g (fp32) and g_bf (its bf16 copy) are both written by the LayerNorm backward that produced them
   // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
-  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, MD, s));
   HIP_TRY(lin_dgrad(l.down, ws.g_bf, M, s, nullptr, ws.d_wide));                 // d act [M,I]
   HIP_TRY(lin_wgrad(c, l.down, ws.g_bf, sv.act, M));
   HIP_TRY(sf_launch_gelu_bwd(ws.d_wide, sv.pre, (size_t)M * I, s));              // d pre
   HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, ws.d_ln, nullptr));
   HIP_TRY(lin_wgrad(c, l.up, ws.d_wide, sv.ln_a, M));
-  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln, PP(t, P0, l.ln_a_g), ws.g, ws.g, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
+  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- spatial: h2 = h1 + out(attn(qkv(LN_b(h1)))) ---------------------------------------------------------
-  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, MD, s));
   HIP_TRY(lin_dgrad(l.s_out, ws.g_bf, M, s, nullptr, ws.d_ctx));
   HIP_TRY(lin_wgrad(c, l.s_out, ws.g_bf, sv.ctx_s, M));
   {
@@ -673,10 +671,9 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   }
   HIP_TRY(lin_wgrad(c, l.s_qkv, ws.d_wide, sv.ln_b, M));
   HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide, M, s, ws.d_ln, nullptr));
-  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln, PP(t, P0, l.ln_b_g), ws.g, ws.g, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
+  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- temporal: h1 = h + tanh(gate) * dense(out(attn(qkv(LN_t(h))))) ----------------------------------------
-  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, MD, s));
   HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
   {
     // unscaled G = g^T t_out and column sums -> dW, db, dgate (see sf_launch_gate_grad)
@@ -684,8 +681,9 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     memset(&a, 0, sizeof(a));
     a.dy = ws.g_bf; a.ldy = D; a.x = sv.t_out; a.ldx = D; a.M = M; a.N1 = D; a.N2 = D; a.ldo = D; a.alpha = 1.f;
     a.partial = ws.wg_partial; a.out = ws.dw_scratch; a.accumulate = 0;
+    HIP_TRY(hipMemsetAsync(ws.cs, 0, (size_t)D * sizeof(float), s));
+    a.dbias = ws.cs; a.dbias_scratch = ws.cs_partial;
     HIP_TRY(sf_launch_wgrad(a, s));
-    HIP_TRY(sf_launch_colsum_bf16(ws.g_bf, M, D, D, 1.f, ws.cs, 0, ws.cs_partial, s));
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
                                 GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   }
@@ -701,7 +699,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   }
   HIP_TRY(lin_wgrad(c, l.t_qkv, ws.d_wide, sv.ln_t, M));
   HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide, M, s, ws.d_ln, nullptr));
-  HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln, PP(t, P0, l.ln_t_g), ws.g, ws.g, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
+  HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
                            ws.ln_partial, M, D, eps, s));
   return SF_OK;
 }
@@ -713,7 +711,6 @@ static int backward_embeddings(const BwdCtx& c, int B, int T) {
   const int D = t->D, N = t->N;
   const int M = B * T * N;
   // h0 = patches W^T + b + pos[n] + time[t]   (modeling:336-350, 413-457)
-  HIP_TRY(sf_launch_split(ws.g, ws.g_bf, nullptr, (size_t)M * D, s));
   HIP_TRY(lin_wgrad(c, t->patch, ws.g_bf, ws.patches, M));
   HIP_TRY(sf_launch_sum_rows(ws.g, ws.s_tn, T * N, T * N, 1, 0, B, (long)T * N, D, 0, s));       // sum over batch
   if (float* gp = GG(t, c.grads, t->p_pos)) HIP_TRY(sf_launch_sum_rows(ws.s_tn, gp, N, N, 1, 0, T, N, D, 1, s));
@@ -772,14 +769,15 @@ extern "C" int sf_trainer_grad_sumsq(sf_trainer* t, const float* grads, float* o
 // single backward operators (parity tests)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sf_op_wgrad(const void* dy, int ldy, const void* x, int ldx, int M, int N1, int N2, float alpha, int accumulate,
-                           float* out, int ldo, sf_stream stream) {
+                           float* out, int ldo, float* dbias, sf_stream stream) {
   if (!dy || !x || !out) return sf_set_err(SF_ERR_INVALID, "null argument");
   float* partial = nullptr;
-  HIP_TRY(hipMalloc(&partial, sf_wgrad_partial_floats(M, N1, N2) * sizeof(float)));
+  HIP_TRY(hipMalloc(&partial, (sf_wgrad_partial_floats(M, N1, N2) + sf_colsum_partial_floats(N1)) * sizeof(float)));
   SfWgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = (const bf16_t*)dy; a.ldy = ldy; a.x = (const bf16_t*)x; a.ldx = ldx; a.M = M; a.N1 = N1; a.N2 = N2;
   a.out = out; a.ldo = ldo; a.accumulate = accumulate; a.alpha = alpha; a.partial = partial;
+  a.dbias = dbias; a.dbias_scratch = partial + sf_wgrad_partial_floats(M, N1, N2);
   hipError_t e = sf_launch_wgrad(a, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(partial);
@@ -805,7 +803,7 @@ extern "C" int sf_op_layernorm_bwd(const float* x, const float* dy, const float*
   if (!x || !dy || !gamma || !dx) return sf_set_err(SF_ERR_INVALID, "null argument");
   float* partial = nullptr;
   HIP_TRY(hipMalloc(&partial, sf_ln_bwd_partial_floats(D) * sizeof(float)));
-  hipError_t e = sf_launch_ln_bwd(x, dy, gamma, g_in, dx, d_gamma, d_beta, partial, rows, D, eps, (hipStream_t)stream);
+  hipError_t e = sf_launch_ln_bwd(x, dy, gamma, g_in, dx, nullptr, d_gamma, d_beta, partial, rows, D, eps, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(partial);
   if (e != hipSuccess) return sf_set_err(SF_ERR_HIP, "sf_op_layernorm_bwd: %s", hipGetErrorString(e));

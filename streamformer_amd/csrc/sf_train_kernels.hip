@@ -78,8 +78,8 @@ hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_
 template <int MAXV>
 __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ gamma, const float* g_in,
-                                                        float* g_out, float* __restrict__ partial, int rows, int D,
-                                                        float eps) {
+                                                        float* g_out, bf16_t* __restrict__ g_out_bf,
+                                                        float* __restrict__ partial, int rows, int D, float eps) {
   extern __shared__ float red[];                      // [3][2][D] for waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
         const size_t off = (size_t)row * D + (size_t)c * 4;
         if (g_in) o += *reinterpret_cast<const f32x4_t*>(g_in + off);
         *reinterpret_cast<f32x4_t*>(g_out + off) = o;
+        if (g_out_bf) *reinterpret_cast<u32x2_t*>(g_out_bf + off) = (u32x2_t){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
       }
     }
   }
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(1024) void sf_ln_bwd_finish_kernel(const float* __r
 size_t sf_ln_bwd_partial_floats(int D) { return (size_t)LN_BWD_MAX_BLOCKS * 2 * D; }
 
 hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* g_out,
-                            float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
+                            bf16_t* g_out_bf, float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
                             hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > 64 * 4 * 8) return hipErrorInvalidValue;
@@ -218,7 +219,7 @@ hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma,
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   const size_t lds = (size_t)3 * 2 * D * sizeof(float);
   const int nv = (D / 4 + 63) / 64;
-#define SF_LNB(MV) hipLaunchKernelGGL(sf_ln_bwd_kernel<MV>, dim3(blocks), dim3(256), lds, s, x, dy, gamma, g_in, g_out, partial, rows, D, eps)
+#define SF_LNB(MV) hipLaunchKernelGGL(sf_ln_bwd_kernel<MV>, dim3(blocks), dim3(256), lds, s, x, dy, gamma, g_in, g_out, g_out_bf, partial, rows, D, eps)
   if (nv <= 1) SF_LNB(1);
   else if (nv <= 3) SF_LNB(3);
   else SF_LNB(8);

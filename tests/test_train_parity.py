@@ -50,7 +50,7 @@ def cosine(a, b):
 # ---------------------------------------------------------------------------------------------------
 # single operators
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N1,N2", [(3136, 768, 768), (777, 136, 72), (40, 128, 256), (25088, 768, 3072), (130, 64, 64)])
+@pytest.mark.parametrize("M,N1,N2", [(3136, 768, 768), (777, 136, 72), (40, 128, 256), (25088, 768, 3072), (130, 64, 64), (25088, 2304, 768), (2100, 256, 512)])
 def test_wgrad_matches_torch(M, N1, N2):
     import streamformer_amd._native as nat
     dev = _dev()
@@ -59,14 +59,16 @@ def test_wgrad_matches_torch(M, N1, N2):
     x = torch.randn(M, N2, generator=g).to(dev).bfloat16()
     base = torch.randn(N1, N2, generator=g).to(dev)
     out = base.clone()
-    nat.check(nat.lib.sf_op_wgrad(dy.data_ptr(), N1, x.data_ptr(), N2, M, N1, N2, 0.5, 1, out.data_ptr(), N2,
+    db = torch.full((N1,), 3.0, device=dev)
+    nat.check(nat.lib.sf_op_wgrad(dy.data_ptr(), N1, x.data_ptr(), N2, M, N1, N2, 0.5, 1, out.data_ptr(), N2, db.data_ptr(),
                                   nat.current_stream_handle(dev)))
     want = base.double() + 0.5 * dy.double().t() @ x.double()
     assert rel_max(out, want) < 1e-4          # fp32 accumulation of exact bf16 products
+    assert rel_max(db - 3.0, 0.5 * dy.double().sum(0)) < 1e-4      # bias gradient of the same Linear
     # column-sliced operands (leading dimension > width), no accumulate
     out2 = torch.full((N1, N2), 7.0, device=dev)
     wide = torch.randn(M, N1 + 64, generator=g).to(dev).bfloat16()
-    nat.check(nat.lib.sf_op_wgrad(wide.data_ptr(), N1 + 64, x.data_ptr(), N2, M, N1, N2, 1.0, 0, out2.data_ptr(), N2,
+    nat.check(nat.lib.sf_op_wgrad(wide.data_ptr(), N1 + 64, x.data_ptr(), N2, M, N1, N2, 1.0, 0, out2.data_ptr(), N2, 0,
                                   nat.current_stream_handle(dev)))
     assert rel_max(out2, wide[:, :N1].double().t() @ x.double()) < 1e-4
 
