@@ -88,6 +88,12 @@ SF_DEVICE float gelu_fast(float x) {
   const float h = poly * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044f);     // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
   return x * (x >= 0.f ? 1.0f - h : h);
 }
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x), Phi through the same A&S erf
+SF_DEVICE float gelu_grad_fast(float x) {
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(x * x * -0.72134752044f);
+  return cdf + x * pdf;
+}
 SF_DEVICE float apply_act_fast(float x, int act) {
   if (act == 0) return gelu_fast(x);
   return act == 1 ? gelu_tanh(x) : fmaxf(x, 0.0f);
@@ -128,10 +134,16 @@ struct SfGemmArgs {
   // (A = bf16(x), W' = W * gamma) finishes y = rstd * (acc - mean * ln_s[n]) + bias' in its epilogue.
   float* ln_stats_out;
   const float* ln_stats; const float* ln_s; float ln_eps;
+  // training-step fusions on a bf16 output (256^2 kernel only; sf_gemm256_aux_supported):
+  //   aux_mode 1: also write aux[row, col] = gelu(out)            (forward: pre-activation + activation)
+  //   aux_mode 2: out *= gelu'(aux[row, col])                     (backward: d pre = d act * gelu'(pre))
+  int aux_mode;
+  bf16_t* aux;                              // [*, ldc], same row remap as the output
 };
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches skinny / panel / 256^2 / 128^2
 hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   // sf_gemm.hip
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split);                      // sf_gemm256.hip
+bool sf_gemm256_aux_supported(const SfGemmArgs& a);                              // aux_mode epilogues
 hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s);
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split);                  // sf_gemm_skinny.hip (M <= 512)
 hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s);

@@ -222,6 +222,7 @@ static hipError_t launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStre
 }
 
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
+  if (a.aux_mode) return sf_gemm256_aux_supported(a) && !split ? sf_launch_gemm256(a, s) : hipErrorInvalidValue;
   if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);
   if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);

@@ -44,6 +44,8 @@ SF_DEVICE void wait_vm() {
 // BM = 256, or 224 when that tiles M with fewer idle tile slots (M = 25088 = 112 x 224: the qkv GEMM runs
 // 4 full rounds of 224-row tiles instead of 3.45 -> 4 rounds of 256-row ones).  With BM = 224 a wave row
 // owns 112 rows: quadrant mq = 0 has 4 m-tiles, mq = 1 has 3 (its A piece is padded with clamped rows).
+#define G256_EPI_BF16_AUX 5     // kernel-internal: SF_EPI_BF16 with the training-step aux epilogue compiled in
+
 template <int EPI, bool LNF, int BM>
 __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles) {
   constexpr int HR = BM / 2;                 // rows per wave row
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) lns4[nq][nt] = *reinterpret_cast<const f32x4_t*>(p.ln_s + n0 + wn * 64 + nq * 32 + nt * 16 + g * 4);
     }
-    if (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16) {
+    if (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16 || EPI == G256_EPI_BF16_AUX) {
       // [256 rows][32 chunks of 16 B], chunk index XOR (row & 31)
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq)
@@ -261,12 +263,25 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
       for (int it = 0; it < BM / 16; ++it) {
         const int idx = it * G_THREADS + tid;
         const int r = idx >> 5, c = idx & 31;
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * 512 + ((c ^ (r & 31)) << 4));
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * 512 + ((c ^ (r & 31)) << 4));
         const int m = m0 + r;
         if (m < p.M) {
           size_t orow = (size_t)m;
           if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
-          *reinterpret_cast<u32x4_t*>(p.out_hi + orow * (size_t)p.ldc + n0 + c * 8) = v;
+          const size_t o = orow * (size_t)p.ldc + n0 + c * 8;
+          if (EPI == G256_EPI_BF16_AUX && p.aux_mode == 1) {               // training forward: the GELU of the (bf16) pre-activation
+            u32x4_t a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = pack_bf2(gelu_fast(bf2f(v[j] & 0xffffu)), gelu_fast(bf2f(v[j] >> 16)));
+            *reinterpret_cast<u32x4_t*>(p.aux + o) = a;
+          } else if (EPI == G256_EPI_BF16_AUX && p.aux_mode == 2) {        // training backward: d pre = d act * gelu'(pre)
+            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(p.aux + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              v[j] = pack_bf2(bf2f(v[j] & 0xffffu) * gelu_grad_fast(bf2f(a[j] & 0xffffu)),
+                              bf2f(v[j] >> 16) * gelu_grad_fast(bf2f(a[j] >> 16)));
+          }
+          *reinterpret_cast<u32x4_t*>(p.out_hi + o) = v;
         }
       }
       __syncthreads();   // staging reads retired before the next tile's DMA lands in the ring
@@ -318,6 +333,10 @@ bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
   return true;
 }
 
+bool sf_gemm256_aux_supported(const SfGemmArgs& a) {
+  return a.epi == SF_EPI_BF16 && a.aux != nullptr && sf_gemm256_supported(a, false);
+}
+
 static int g256_grid() {
   static int cus = 0;
   if (!cus) {
@@ -338,7 +357,7 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
   if (!attr_set) {
 #define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
-    SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true)
+    SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true) SF_ATTR(G256_EPI_BF16_AUX, false)
 #undef SF_ATTR
     attr_set = true;
   }
@@ -348,7 +367,10 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
   switch (a.epi) {
     case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32, false, BM>), grid, block, lds, s, a, tiles); break;
     case SF_EPI_BF16:
-      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, true, BM>), grid, block, lds, s, a, tiles);
+      if (a.aux_mode) {
+        if (lnf || !a.aux) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((sf_gemm256_kernel<G256_EPI_BF16_AUX, false, BM>), grid, block, lds, s, a, tiles);
+      } else if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, true, BM>), grid, block, lds, s, a, tiles);
       else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, false, BM>), grid, block, lds, s, a, tiles);
       break;
     case SF_EPI_ACT_BF16:

@@ -456,15 +456,23 @@ extern "C" int sf_trainer_workspace_bytes(const sf_trainer* t, int B, int T, siz
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
 // ------------------------------------------------------------------------------------------------
-static hipError_t tgemm(const bf16_t* a, const bf16_t* w, const float* bias, int M, int N, int K, int epi, hipStream_t s,
-                        float* out_f32, bf16_t* out_bf, const float* resid = nullptr) {
+static SfGemmArgs tgemm_args(const bf16_t* a, const bf16_t* w, const float* bias, int M, int N, int K, int epi, float* out_f32,
+                            bf16_t* out_bf, const float* resid) {
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   g.a_hi = a; g.w_hi = w; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.alpha = 1.f; g.resid = resid;
   g.out_f32 = out_f32; g.out_hi = epi == SF_EPI_RESID_F32 ? nullptr : out_bf; g.ldc = N;
-  return sf_launch_gemm(g, false, s);
+  return g;
 }
+static hipError_t tgemm(const bf16_t* a, const bf16_t* w, const float* bias, int M, int N, int K, int epi, hipStream_t s,
+                        float* out_f32, bf16_t* out_bf, const float* resid = nullptr) {
+  return sf_launch_gemm(tgemm_args(a, w, bias, M, N, K, epi, out_f32, out_bf, resid), false, s);
+}
+// pre = x W^T + b and act = gelu(pre): one launch where the 256^2 kernel takes the shape, else GEMM + GELU pass
+static hipError_t lin_fwd_gelu(const sf_trainer* t, const TLin& l, const bf16_t* x, int M, hipStream_t s, bf16_t* pre, bf16_t* act);
+// d_pre = (dy W) * gelu'(pre): same
+static hipError_t lin_dgrad_dgelu(const TLin& l, const bf16_t* dy, int M, hipStream_t s, bf16_t* d_pre, const bf16_t* pre);
 // y = x W^T + b
 static hipError_t lin_fwd(const sf_trainer* t, const TLin& l, const bf16_t* x, int M, int epi, hipStream_t s, float* out_f32,
                           bf16_t* out_bf, const float* resid = nullptr) {
@@ -473,6 +481,23 @@ static hipError_t lin_fwd(const sf_trainer* t, const TLin& l, const bf16_t* x, i
 // dx = dy W   (dy [M,N] -> dx [M,K]); the forward-scaled weight is used as is
 static hipError_t lin_dgrad(const TLin& l, const bf16_t* dy, int M, hipStream_t s, float* out_f32, bf16_t* out_bf) {
   return tgemm(dy, l.wT, nullptr, M, l.K, l.N, out_f32 ? SF_EPI_F32 : SF_EPI_BF16, s, out_f32, out_bf);
+}
+
+static hipError_t lin_fwd_gelu(const sf_trainer* t, const TLin& l, const bf16_t* x, int M, hipStream_t s, bf16_t* pre, bf16_t* act) {
+  SfGemmArgs g = tgemm_args(x, l.w, lin_bias(t, l), M, l.N, l.K, SF_EPI_BF16, nullptr, pre, nullptr);
+  g.aux_mode = 1; g.aux = act;
+  if (sf_gemm256_aux_supported(g)) return sf_launch_gemm(g, false, s);
+  g.aux_mode = 0; g.aux = nullptr;
+  hipError_t e = sf_launch_gemm(g, false, s);
+  return e != hipSuccess ? e : sf_launch_gelu_fwd(pre, act, (size_t)M * l.N, s);
+}
+static hipError_t lin_dgrad_dgelu(const TLin& l, const bf16_t* dy, int M, hipStream_t s, bf16_t* d_pre, const bf16_t* pre) {
+  SfGemmArgs g = tgemm_args(dy, l.wT, nullptr, M, l.K, l.N, SF_EPI_BF16, nullptr, d_pre, nullptr);
+  g.aux_mode = 2; g.aux = const_cast<bf16_t*>(pre);
+  if (sf_gemm256_aux_supported(g)) return sf_launch_gemm(g, false, s);
+  g.aux_mode = 0; g.aux = nullptr;
+  hipError_t e = sf_launch_gemm(g, false, s);
+  return e != hipSuccess ? e : sf_launch_gelu_bwd(d_pre, pre, (size_t)M * l.K, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -544,8 +569,7 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
     HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_RESID_F32, s, sv.h2, nullptr, sv.h1));
     // MLP (modeling:997-1000)
     HIP_TRY(sf_launch_layernorm(sv.h2, PP(t, P0, l.ln_a_g), PP(t, P0, l.ln_a_b), nullptr, sv.ln_a, nullptr, M, D, eps, s));
-    HIP_TRY(lin_fwd(t, l.up, sv.ln_a, M, SF_EPI_BF16, s, nullptr, sv.pre));
-    HIP_TRY(sf_launch_gelu_fwd(sv.pre, sv.act, (size_t)M * I, s));
+    HIP_TRY(lin_fwd_gelu(t, l.up, sv.ln_a, M, s, sv.pre, sv.act));
     HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_RESID_F32, s, ws.h[li + 1], nullptr, sv.h2));
   }
   // post LayerNorm + pooling head (modeling:1330-1340, 1141-1154)
@@ -645,16 +669,15 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   hipStream_t s = c.s;
   const TLayer& l = t->layers[li];
   const TSavedLayer& sv = ws.sl[li];
-  const int D = t->D, I = t->I, N = t->N;
+  const int D = t->D, N = t->N;
   const int M = B * T * N, F = B * T;
   const float eps = t->cfg.layer_norm_eps;
   const float* P0 = t->params_dev;
 
   // g (fp32) and g_bf (its bf16 copy) are both written by the LayerNorm backward that produced them
   // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
-  HIP_TRY(lin_dgrad(l.down, ws.g_bf, M, s, nullptr, ws.d_wide));                 // d act [M,I]
+  HIP_TRY(lin_dgrad_dgelu(l.down, ws.g_bf, M, s, ws.d_wide, sv.pre));            // d pre = (g W_down) * gelu'(pre)  [M,I]
   HIP_TRY(lin_wgrad(c, l.down, ws.g_bf, sv.act, M));
-  HIP_TRY(sf_launch_gelu_bwd(ws.d_wide, sv.pre, (size_t)M * I, s));              // d pre
   HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, ws.d_ln, nullptr));
   HIP_TRY(lin_wgrad(c, l.up, ws.d_wide, sv.ln_a, M));
   HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
