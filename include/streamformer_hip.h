@@ -43,7 +43,7 @@ typedef enum {
   SF_ERR_CAPACITY = -6      /* streaming past the cache / time-embedding capacity            */
 } sf_status;
 
-typedef enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_F64 = 3 } sf_dtype;
+typedef enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_F64 = 3, SF_U8 = 4 } sf_dtype;
 
 /* Arithmetic mode of the matrix products (reported as "dtype" by bench.py):
  *   SF_COMPUTE_BF16   : bf16 operands, fp32 accumulate, one MFMA pass            (throughput)
@@ -81,9 +81,14 @@ int sf_load_tensor(sf_encoder* enc, const char* key, const void* host_ptr, int d
 int sf_finalize_weights(sf_encoder* enc, int compute, int merge_lora, int fuse_temporal_proj);
 /* number of weight tensors still missing (0 when complete); names via sf_last_error()          */
 int sf_missing_weights(sf_encoder* enc);
+/* TimesformerImageProcessor's arithmetic for SF_U8 frames (vqa_enc:1400-1447): y = (x * rescale - mean[c]) / std[c].
+ * Defaults: mean = std = 0.5, rescale = 1/255.  The bicubic resize stays with the caller.          */
+int sf_set_pixel_normalization(sf_encoder* enc, const float* mean, const float* std, int channels, float rescale);
 
 /* ---- full-clip forward: replaces .forward(pixel_values) (modeling:1299-1354) -----------------
- * pixels_dev         [B,T,C,H,W] contiguous, dtype pixel_dtype (SF_F32 or SF_BF16)
+ * pixels_dev         [B,T,C,H,W] contiguous, dtype pixel_dtype: SF_F32 / SF_BF16 = normalised frames;
+ *                    SF_U8 = raw frames, the image processor's rescale + normalize (see
+ *                    sf_set_pixel_normalization) is fused into the patch-extraction kernel
  * last_hidden_dev    fp32 [B,T,N,D]   (post-LayerNorm tokens, modeling:1330,1342-1346)
  * pooler_dev         fp32 [B,T,D]     (modeling:1338-1340)
  * hidden_states_dev  NULL, or fp32 [L+1,B,T,N,D]: the input of every layer + the last output

@@ -17,5 +17,6 @@ from .modeling import (  # noqa: F401
     TimesformerVisionTower,
 )
 from . import heads  # noqa: F401
+from .processing import TimesformerImageProcessor  # noqa: F401
 
 __version__ = "0.1.0"

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libstreamformer_hip.so")
 
 SF_OK = 0
 SF_ERR_INVALID, SF_ERR_STATE, SF_ERR_HIP, SF_ERR_WORKSPACE, SF_ERR_UNKNOWN_KEY, SF_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
-SF_F32, SF_BF16, SF_F16, SF_F64 = 0, 1, 2, 3
+SF_F32, SF_BF16, SF_F16, SF_F64, SF_U8 = 0, 1, 2, 3, 4
 SF_COMPUTE_BF16, SF_COMPUTE_BF16X3 = 0, 1
 
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "sf_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64), _I]),
     "sf_finalize_weights": (_I, [_P, _I, _I, _I]),
     "sf_missing_weights": (_I, [_P]),
+    "sf_set_pixel_normalization": (_I, [_P, _P, _P, _I, _F]),
     "sf_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "sf_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_cache_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),

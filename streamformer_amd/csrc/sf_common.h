@@ -156,9 +156,11 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 // LayerNorm over D: x fp32 [rows,D] -> any of {y_f32, y_hi, y_lo} (nullptr = skip)
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
                                bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s);
-// pixels [F,C,H,W] (fp32 or bf16) -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw)
-hipError_t sf_launch_patchify(const void* pixels, int pixel_is_bf16, bf16_t* out_hi, bf16_t* out_lo,
-                              int F, int C, int H, int W, int P, hipStream_t s);
+// pixels [F,C,H,W] -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw).
+// pixel_kind 0 fp32, 1 bf16, 2 uint8 raw frames normalised on the fly: y = x * scale[c] + shift[c]
+struct SfPixelNorm { float scale[4]; float shift[4]; };
+hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
+                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr);
 // fp32 [n] -> bf16 hi (+lo)
 hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])

@@ -85,6 +85,7 @@ struct sf_encoder {
   DevLinear head_kv, head_out, head_fc1, head_fc2;
   float* head_q = nullptr;    // [D] probe query, projected and scaled
   size_t weight_bytes = 0;
+  SfPixelNorm pixel_norm = {{1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f}, {-1.f, -1.f, -1.f, -1.f}};
 };
 
 struct sf_cache {
@@ -226,6 +227,17 @@ extern "C" int sf_load_tensor(sf_encoder* e, const char* key, const void* host_p
   }
   e->host[k] = std::move(t);
   e->finalized = false;
+  return SF_OK;
+}
+
+extern "C" int sf_set_pixel_normalization(sf_encoder* e, const float* mean, const float* std, int channels, float rescale) {
+  if (!e || !mean || !std || channels < 1 || channels > 4) return set_err(SF_ERR_INVALID, "bad pixel normalisation");
+  for (int c = 0; c < 4; ++c) {
+    const int k = c < channels ? c : channels - 1;
+    if (!(std[k] > 0.f)) return set_err(SF_ERR_INVALID, "image_std must be positive");
+    e->pixel_norm.scale[c] = rescale / std[k];       // (x * rescale - mean) / std
+    e->pixel_norm.shift[c] = -mean[k] / std[k];
+  }
   return SF_OK;
 }
 
@@ -558,7 +570,8 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   int rc = time_rows(e, t_past, T, streaming, &idx);
   if (rc) return rc;
   HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s));
-  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_BF16, ws.xn_hi, ws.xn_lo, F, c.num_channels, H, W, P, s));
+  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), ws.xn_hi, ws.xn_lo, F, c.num_channels, H, W, P, s,
+                             &e->pixel_norm));
   {
     SfGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -673,7 +686,7 @@ extern "C" int sf_forward(sf_encoder* e, const void* pixels, int pixel_dtype, in
   if (rc) return rc;
   if (!e->finalized) return set_err(SF_ERR_STATE, "sf_finalize_weights has not run");
   if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
-  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16) return set_err(SF_ERR_INVALID, "pixels must be fp32 or bf16");
+  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8) return set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8");
   if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per clip");
   Workspace ws = carve(e, workspace, B, T, N, true);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
@@ -734,6 +747,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
   int rc = check_geometry(e, c->B, T_new, c->H, c->W, pos_dev, &N);
   if (rc) return rc;
   if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
+  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8) return set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8");
   if (c->len + T_new > c->cap)
     return set_err(SF_ERR_CAPACITY, "cache holds %d of %d frames; %d more do not fit", c->len, c->cap, T_new);
   Workspace ws = carve(e, workspace, c->B, T_new, N, false);

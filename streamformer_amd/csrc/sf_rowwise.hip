@@ -84,12 +84,15 @@ hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* 
 // ------------------------------------------------------------------------------------------------
 // patchify: pixels [F,C,H,W] -> A[F*N, C*P*P] (bf16 hi/lo), column = (c*P + ph)*P + pw,
 // patch n = prow*(W/P) + pcol.  One thread moves 8 consecutive pw pixels (16 B of bf16 out).
+// IN = 0 fp32, 1 bf16 (already normalised frames), 2 uint8 raw frames: the image processor's
+// rescale + normalize (vqa_enc:1436-1447: x / 255, then (x - mean) / std per channel) is fused here as
+// one FMA per pixel, so frames cross PCIe / HBM as bytes.
 // ------------------------------------------------------------------------------------------------
-template <bool IN_BF16>
+template <int IN>
 __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict__ pixels,
                                                           bf16_t* __restrict__ out_hi,
                                                           bf16_t* __restrict__ out_lo, int F, int C, int H,
-                                                          int W, int P, int gh, int gw) {
+                                                          int W, int P, int gh, int gw, SfPixelNorm norm) {
   const int Kp = C * P * P;
   const int chunks_per_row = Kp >> 3;
   const size_t total = (size_t)F * gh * gw * chunks_per_row;
@@ -104,7 +107,12 @@ __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict
     const int y = (n / gw) * P + ph, x0 = (n % gw) * P + pw;
     const size_t src = (((size_t)f * C + c) * H + y) * W + x0;
     float v[8];
-    if (IN_BF16) {
+    if (IN == 2) {
+      const u32x2_t raw = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(pixels) + src);
+      const float sc = norm.scale[c & 3], sh = norm.shift[c & 3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf((float)((raw[j >> 2] >> ((j & 3) * 8)) & 0xffu), sc, sh);
+    } else if (IN == 1) {
       const bf16_t* pp = reinterpret_cast<const bf16_t*>(pixels) + src;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = bf2f(pp[j]);
@@ -125,17 +133,22 @@ __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict
   }
 }
 
-hipError_t sf_launch_patchify(const void* pixels, int pixel_is_bf16, bf16_t* out_hi, bf16_t* out_lo,
-                              int F, int C, int H, int W, int P, hipStream_t s) {
-  if (P % 8) return hipErrorInvalidValue;
+hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
+                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* pnorm) {
+  if (P % 8 || (pixel_kind == 2 && (W % 8 || C > 4))) return hipErrorInvalidValue;
+  SfPixelNorm norm;
+  for (int i = 0; i < 4; ++i) { norm.scale[i] = 1.0f / 127.5f; norm.shift[i] = -1.0f; }    // mean = std = 0.5, rescale 1/255
+  if (pnorm) norm = *pnorm;
   const int gh = H / P, gw = W / P;
   const size_t total = (size_t)F * gh * gw * (C * P * P / 8);
   if (!total) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (pixel_is_bf16)
-    hipLaunchKernelGGL(sf_patchify_kernel<true>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw);
+  if (pixel_kind == 2)
+    hipLaunchKernelGGL(sf_patchify_kernel<2>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm);
+  else if (pixel_kind == 1)
+    hipLaunchKernelGGL(sf_patchify_kernel<1>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm);
   else
-    hipLaunchKernelGGL(sf_patchify_kernel<false>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw);
+    hipLaunchKernelGGL(sf_patchify_kernel<0>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm);
   return hipGetLastError();
 }
 

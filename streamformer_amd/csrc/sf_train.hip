@@ -509,7 +509,8 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
   if (rc) return rc;
   if (!t->params_dev) return sf_set_err(SF_ERR_STATE, "sf_trainer_sync_weights has not been called");
   if (!pixels || !workspace || !pooler) return sf_set_err(SF_ERR_INVALID, "null argument");
-  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16) return sf_set_err(SF_ERR_INVALID, "pixels must be fp32 or bf16");
+  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8)
+    return sf_set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8 (uint8: (x/255 - 0.5)/0.5 fused)");
   HIP_TRY(hipSetDevice(t->device));
   hipStream_t s = (hipStream_t)stream;
   const TWs ws = tcarve(t, workspace, B, T);
@@ -525,7 +526,7 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
   idx.n = T;
   for (int i = 0; i < T; ++i) idx.idx[i] = i;             // modeling:436-439 (T <= num_frames)
   HIP_TRY(sf_launch_gather_rows(PP(t, P0, t->p_time), ws.te_rows, idx, D, s));
-  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_BF16, ws.patches, nullptr, F, c.num_channels, c.image_size, c.image_size,
+  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), ws.patches, nullptr, F, c.num_channels, c.image_size, c.image_size,
                              c.patch_size, s));
   {
     SfGemmArgs g;

@@ -33,7 +33,7 @@ _ACT_CODES = {"gelu": 0, "gelu_new": 1, "gelu_pytorch_tanh": 1, "relu": 2}
 _COMPUTE = {"bf16": nat.SF_COMPUTE_BF16, "bfloat16": nat.SF_COMPUTE_BF16, torch.bfloat16: nat.SF_COMPUTE_BF16,
             "bf16x3": nat.SF_COMPUTE_BF16X3, "fp32": nat.SF_COMPUTE_BF16X3, "float32": nat.SF_COMPUTE_BF16X3,
             torch.float32: nat.SF_COMPUTE_BF16X3}
-_TORCH2SF = {torch.float32: nat.SF_F32, torch.bfloat16: nat.SF_BF16, torch.float16: nat.SF_F16,
+_TORCH2SF = {torch.uint8: nat.SF_U8, torch.float32: nat.SF_F32, torch.bfloat16: nat.SF_BF16, torch.float16: nat.SF_F16,
              torch.float64: nat.SF_F64}
 
 
@@ -196,6 +196,8 @@ class TimesformerMultiTaskingModelSigLIP:
         self._dirty = True
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
+        from .processing import TimesformerImageProcessor
+        self.image_processor = TimesformerImageProcessor(size=(config.image_size, config.image_size))
         self._init_default_weights()
         if device is not None:
             self.to(device)
@@ -412,6 +414,11 @@ class TimesformerMultiTaskingModelSigLIP:
             nat.check(nat.lib.sf_load_tensor(h, k.encode(), t.data_ptr(), _TORCH2SF[t.dtype], shape, t.dim()))
         with torch.cuda.device(self._device):
             nat.check(nat.lib.sf_finalize_weights(h, self._compute, 1, int(self._fuse)))
+        ip = self.image_processor           # uint8 frames: rescale + normalize fused into the patch kernel
+        nch = len(ip.image_mean)
+        mean = (nat.C.c_float * nch)(*ip.image_mean)
+        std = (nat.C.c_float * nch)(*ip.image_std)
+        nat.check(nat.lib.sf_set_pixel_normalization(h, mean, std, nch, ip.rescale_factor))
         self._dirty = False
 
     def _workspace(self, key: tuple, nbytes: int) -> torch.Tensor:
@@ -467,8 +474,10 @@ class TimesformerMultiTaskingModelSigLIP:
         self._sync()
         dev = self._device
         x = pixel_values.to(dev)
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             x = x.float()
+        if x.dtype == torch.uint8 and W % 8:
+            x = self.image_processor.normalize(x)       # byte path needs 8-pixel rows; fall back to fp32 frames
         x = x.contiguous()
         N = (H // c.patch_size) * (W // c.patch_size)
         D, L = c.hidden_size, c.num_hidden_layers
@@ -536,6 +545,7 @@ class TimesformerVisionTower:
         self.max_frames = max_frames or model.config.num_frames
         self.past_key_values: Optional[StreamCache] = None
         self.hidden_states: Optional[torch.Tensor] = None
+        self.image_processor = model.image_processor      # vqa_enc:1503-1505 keeps the processor on the tower
 
     def clear_cache(self) -> None:
         self.hidden_states = None

@@ -210,7 +210,7 @@ class StreamformerTrainer:
         x = pixel_values
         if x.device != self.device:
             raise RuntimeError("pixel_values must already be on the trainer's GPU")
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             x = x.float()
         x = x.contiguous()
         B, T, Cc, H, W = x.shape
@@ -222,7 +222,7 @@ class StreamformerTrainer:
         lhs = torch.empty(B, T, N, c.hidden_size, dtype=torch.float32, device=self.device)
         pool = torch.empty(B, T, c.hidden_size, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            nat.check(nat.lib.sf_trainer_forward(self._h, x.data_ptr(), nat.SF_BF16 if x.dtype == torch.bfloat16 else nat.SF_F32,
+            nat.check(nat.lib.sf_trainer_forward(self._h, x.data_ptr(), {torch.bfloat16: nat.SF_BF16, torch.uint8: nat.SF_U8}.get(x.dtype, nat.SF_F32),
                                                  B, T, lhs.data_ptr(), pool.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         self._lhs, self._pooler = lhs, pool
         return lhs, pool

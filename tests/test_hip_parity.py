@@ -381,3 +381,34 @@ def test_retrieval_multirank_negatives(sa, golden_dir):
         want.backward()
         loss, gp, _ = sa.heads.RetrievalHead().loss(pooler.cuda(), allt.cuda(), rank=rank)
         assert abs(float(loss) - float(want)) <= 2e-5 and maxabs(gp, p.grad) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_uint8_frames_fused_normalisation(golden_dir):
+    """uint8 frames through the byte path of the patch kernel (rescale + normalize fused) == the same frames
+    normalised by the image processor on the host (fixture F9 pins that against the reference)."""
+    import streamformer_amd as sa
+    f9 = load_npz(os.path.join(golden_dir, "f9_processor.npz"))
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=3)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="fp32")
+    m.load_state_dict(sd)
+    m.to("cuda")
+    clip = m.image_processor.preprocess(list(f9["frames_big"]) + [f9["frame_small"]])["pixel_values"]     # uint8 [4,3,48,48]
+    assert clip.dtype == torch.uint8
+    x_u8 = clip[None].cuda()
+    x_f = torch.from_numpy(f9["pixel_values"])[None].cuda()
+    a, b = m(x_u8), m(x_f)
+    assert maxabs(a.last_hidden_state, b.last_hidden_state) <= 1e-4 and maxabs(a.pooler_output, b.pooler_output) <= 1e-4
+    want = O.forward(sd, cfg, x_f.cpu())
+    assert maxabs(a.last_hidden_state, want["last_hidden_state"]) <= ACC_TOL
+    # a non-default normalisation is honoured by the kernel
+    m.image_processor.image_mean, m.image_processor.image_std = (0.4, 0.5, 0.6), (0.2, 0.25, 0.3)
+    m._dirty = True
+    c = m(x_u8)
+    d = m(m.image_processor.normalize(clip)[None].cuda())
+    assert maxabs(c.last_hidden_state, d.last_hidden_state) <= 1e-4
+    # streaming entry takes bytes too
+    cache = m.new_cache(1, 16)
+    s = m(x_u8[:, :2], use_cache=True, past_key_values=cache)
+    assert maxabs(s.last_hidden_state, c.last_hidden_state[:, :2]) <= 2e-4
