@@ -296,6 +296,184 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
   }
 }
 
+// ================================================================================================
+// spatial attention for N > 224 tokens per frame (higher-resolution inputs, modeling:380-411 resizes
+// the position table): block = (frame, head, block of 128 queries), 8 waves = one 16-query tile each;
+// keys stream through LDS in chunks of 128 (K rows + V^T, same images and swizzles as above) with the
+// online-softmax recurrence (running max m, running sum l, accumulators rescaled by 2^((m - m')c)).
+// The score layout keeps a lane on one query, so the rescale is lane-local.
+// ================================================================================================
+#define SL_KC 128                 // keys per chunk (= 4 tiles of 32; V^T rows are 256 B = 16 chunks, as vswz wants)
+
+template <bool ACC>
+__global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_large_kernel(SfAttnArgs p, int qblocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int VP = 2 * SL_KC;   // V^T row pitch in bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int qb = blockIdx.x % qblocks;
+  const int fh = blockIdx.x / qblocks;
+  const int frame = fh / p.heads, h = fh % p.heads;
+  const int N = p.N;
+  char* k_hi = smem;
+  char* k_lo = k_hi + (ACC ? SL_KC * 128 : 0);
+  char* v_hi = k_lo + SL_KC * 128;
+  char* v_lo = v_hi + (ACC ? HD * VP : 0);
+  char* o_st = v_lo + HD * VP + wave * (ACC ? 4096 : 2048);
+  const size_t row0 = (size_t)frame * N;
+  const int qt = qb * SP_WAVES + wave;                 // this wave's query tile
+  const bool active = qt * 16 < N;
+
+  bf16x8_t qh[2], ql[2];
+  {
+    int qi = qt * 16 + l15;
+    qi = qi < N ? qi : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) load_frag<ACC>(p.q, (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8, qh[ks], ql[ks]);
+  }
+  const float c = p.scale * 1.44269504088896340736f;
+  float m = -INFINITY, l = 0.f;                        // running max (raw scores) and sum, per query (lane l15, partial over g)
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int key0 = 0; key0 < N; key0 += SL_KC) {
+    __syncthreads();                                   // previous chunk fully consumed
+    for (int i = tid; i < SL_KC * 8; i += SP_WAVES * 64) {
+      const int key = i >> 3, ch = i & 7;
+      u32x4_t hv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+      if (key0 + key < N) {
+        bf16x8_t a, b;
+        load_frag<ACC>(p.k, (row0 + key0 + key) * p.row_pitch_kv + h * HD + ch * 8, a, b);
+        hv = __builtin_bit_cast(u32x4_t, a);
+        lv = __builtin_bit_cast(u32x4_t, b);
+      }
+      const int off = key * 128 + ((ch ^ kswz(key)) << 4);
+      *reinterpret_cast<u32x4_t*>(k_hi + off) = hv;
+      if (ACC) *reinterpret_cast<u32x4_t*>(k_lo + off) = lv;
+    }
+    for (int i = tid; i < (SL_KC >> 1) * 8; i += SP_WAVES * 64) {
+      const int kp = i >> 3, ch = i & 7;
+      float v0[8], v1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v0[j] = 0.f; v1[j] = 0.f; }
+      if (key0 + 2 * kp < N) load8<ACC>(p.v, (row0 + key0 + 2 * kp) * p.row_pitch_kv + h * HD + ch * 8, v0);
+      if (key0 + 2 * kp + 1 < N) load8<ACC>(p.v, (row0 + key0 + 2 * kp + 1) * p.row_pitch_kv + h * HD + ch * 8, v1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsigned int h0, l0, h1, l1;
+        split_bf(v0[j], h0, l0);
+        split_bf(v1[j], h1, l1);
+        const int d = ch * 8 + j;
+        const int off = d * VP + ((((kp >> 2) ^ vswz(d)) << 2) + (kp & 3)) * 4;
+        *reinterpret_cast<unsigned int*>(v_hi + off) = h0 | (h1 << 16);
+        if (ACC) *reinterpret_cast<unsigned int*>(v_lo + off) = l0 | (l1 << 16);
+      }
+    }
+    __syncthreads();
+    if (!active) continue;                             // wave-uniform; barriers stay outside
+
+    f32x4_t s[4][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 4; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
+        const int sw = kswz(key);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int off = key * 128 + (((ks * 4 + g) ^ sw) << 4);
+          const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(k_hi + off);
+          if (ACC) {
+            const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(k_lo + off);
+            acc = mfma16(kl, qh[ks], acc);
+            acc = mfma16(kh, ql[ks], acc);
+          }
+          acc = mfma16(kh, qh[ks], acc);
+        }
+        s[kt2][hh] = acc;
+      }
+    // lane: query l15; keys key0 + 32*kt2 + 8*g + 4*hh + r
+    float cm = -INFINITY;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 4; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (key0 + kt2 * 32 + g * 8 + hh * 4 + r >= N) s[kt2][hh][r] = -INFINITY;
+          cm = fmaxf(cm, s[kt2][hh][r]);
+        }
+    cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+    cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+    const float mn = fmaxf(m, cm);                     // finite: every chunk holds at least one valid key
+    const float alpha = ACC ? exp2f((m - mn) * c) : __builtin_amdgcn_exp2f((m - mn) * c);
+    const float mc = mn * c;
+    float add = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 4; ++kt2)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = fmaf(s[kt2][hh][r], c, -mc);
+          const float e = ACC ? exp2f(a) : __builtin_amdgcn_exp2f(a);
+          s[kt2][hh][r] = e;
+          add += e;
+        }
+    l = l * alpha + add;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 4; ++kt2) {
+      bf16x8_t ph, pl;
+      pack_p<ACC>(s[kt2][0], s[kt2][1], ph, pl);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + l15;
+        const int off = d * VP + (((kt2 * 4 + g) ^ vswz(d)) << 4);
+        const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(v_hi + off);
+        if (ACC) {
+          const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(v_lo + off);
+          o[dt] = mfma16(vl, ph, o[dt]);
+          o[dt] = mfma16(vh, pl, o[dt]);
+        }
+        o[dt] = mfma16(vh, ph, o[dt]);
+      }
+    }
+  }
+  if (!active) return;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    unsigned int hb[4], lb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf(o[dt][j] * inv, hb[j], lb[j]);
+    const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
+    *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+    if (ACC) *reinterpret_cast<u32x2_t*>(o_st + 2048 + off) = (u32x2_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = it * 64 + lane;
+    const int r = idx >> 3, ch = idx & 7;
+    const int qi = qt * 16 + r;
+    const int off = r * 128 + ((ch ^ (r & 7)) << 4);
+    if (qi < N) {
+      const size_t o_off = (row0 + qi) * p.D + h * HD + ch * 8;
+      *reinterpret_cast<u32x4_t*>(p.ctx_hi + o_off) = *reinterpret_cast<const u32x4_t*>(o_st + off);
+      if (ACC) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = *reinterpret_cast<const u32x4_t*>(o_st + 2048 + off);
+    }
+  }
+}
+
 static int vt_pitch(int nkp) {
   // bytes per V^T row: 2*nkp + pad with pitch % 256 in {32, 224}: the 16 d-rows of a ds_read_b128
   // lane group then fall on 16 distinct 16-byte slots ("LDS layouts").
@@ -309,7 +487,19 @@ static int vt_pitch(int nkp) {
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
   const int nkp = (a.N + 31) & ~31;
-  if (nkp > 32 * 7) return hipErrorInvalidValue;   // N <= 224 patches (16x16 patches of <= 224 px)
+  if (nkp > 32 * 7) {                               // more than 224 tokens per frame: streaming-key kernel
+    const int qblocks = (a.N + 127) / 128;
+    const size_t lds = (size_t)(SL_KC * 128 + HD * 2 * SL_KC + SP_WAVES * 2048) * (accurate ? 2 : 1);
+    static bool attr_l = false;
+    if (!attr_l) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_large_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_l = true;
+    }
+    const dim3 grid(a.frames * a.heads * qblocks), block(SP_WAVES * 64);
+    if (accurate) hipLaunchKernelGGL((sf_spatial_attn_large_kernel<true>), grid, block, lds, s, a, qblocks);
+    else hipLaunchKernelGGL((sf_spatial_attn_large_kernel<false>), grid, block, lds, s, a, qblocks);
+    return hipGetLastError();
+  }
   const int vp = (2 * nkp + 255) & ~255;          // V^T row pitch: whole groups of 16 chunks (vswz is 4-bit)
   const size_t lds = (size_t)(nkp * 128 + HD * vp + SP_WAVES * 2048) * (accurate ? 2 : 1);
   const dim3 grid(a.frames * a.heads), block(SP_WAVES * 64);

@@ -659,7 +659,7 @@ static int check_geometry(const sf_encoder* e, int B, int T, int H, int W, const
   const int P = e->cfg.patch_size;
   if (B <= 0 || T <= 0 || H < P || W < P) return set_err(SF_ERR_INVALID, "bad geometry B=%d T=%d H=%d W=%d", B, T, H, W);
   const int N = (H / P) * (W / P);
-  if (N > 224) return set_err(SF_ERR_INVALID, "%d patches per frame; the spatial attention kernel handles <= 224", N);
+  if (N > 2048) return set_err(SF_ERR_INVALID, "%d patches per frame; the attention kernels handle <= 2048", N);
   if (!pos_dev && !(N == e->N && H == W))
     return set_err(SF_ERR_INVALID, "input %dx%d differs from image_size %d: pass a resized position table (pos_dev)", H, W, e->cfg.image_size);
   if ((size_t)B * T * N > (size_t)1 << 30) return set_err(SF_ERR_INVALID, "too many token rows");

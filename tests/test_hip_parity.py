@@ -116,7 +116,8 @@ def _attn_ref(qkv, heads, mask=None):
     return O._mha(q, k, v, heads, mask)[0]
 
 
-@pytest.mark.parametrize("frames_,N,heads", [(3, 196, 12), (2, 9, 2), (1, 33, 1), (2, 224, 2), (4, 1, 2), (2, 16, 3)])
+@pytest.mark.parametrize("frames_,N,heads", [(3, 196, 12), (2, 9, 2), (1, 33, 1), (2, 224, 2), (4, 1, 2), (2, 16, 3),
+                                              (2, 225, 2), (1, 576, 3), (1, 1024, 1), (2, 400, 2)])   # > 224: streaming-key kernel
 @pytest.mark.parametrize("mode", [0, 1])
 def test_op_spatial_attention(sa, frames_, N, heads, mode):
     g = torch.Generator().manual_seed(N * 13 + heads)
@@ -412,3 +413,24 @@ def test_uint8_frames_fused_normalisation(golden_dir):
     cache = m.new_cache(1, 16)
     s = m(x_u8[:, :2], use_cache=True, past_key_values=cache)
     assert maxabs(s.last_hidden_state, c.last_hidden_state[:, :2]) <= 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol", [("fp32", ACC_TOL), ("bf16", BF16_LHS)])
+def test_forward_more_than_224_patches(mode, tol):
+    """384 x 384 frames = 576 patches per frame: spatial attention streams the keys (online softmax);
+    full clip and streamed frame by frame, against the oracle."""
+    import streamformer_amd as sa
+    cfg = small_cfg(image_size=384, num_frames=4)
+    sd = make_state_dict(cfg, seed=21)
+    x = frames(21, (1, 4, 3, 384, 384))
+    want = O.forward(sd, cfg, x)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    out = m(x.cuda())
+    assert maxabs(out.last_hidden_state, want["last_hidden_state"]) <= tol
+    assert maxabs(out.pooler_output, want["pooler_output"]) <= tol
+    cache = m.new_cache(1, 4)
+    outs = [m(x[:, t:t + 1].cuda(), use_cache=True, past_key_values=cache).last_hidden_state for t in range(4)]
+    assert maxabs(torch.cat(outs, 1), want["last_hidden_state"]) <= tol
