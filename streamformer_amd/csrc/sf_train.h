@@ -68,18 +68,13 @@ hipError_t sf_launch_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, fl
 // out[o, :] (+)= sum_{r < R} in[(o % n_a) * stride_a + (o / n_a) * stride_b + r * stride_r, :]  (fp32 rows of D)
 hipError_t sf_launch_sum_rows(const float* in, float* out, int n_out, int n_a, long stride_a, long stride_b,
                               int R, long stride_r, int D, int accumulate, hipStream_t s);
-// scatter-add rows: out[idx[t], :] += in[t, :]
-hipError_t sf_launch_scatter_add_rows(const float* in, float* out, const SfRowIndex& idx, int D, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // weights: fp32 master -> bf16 working copies
 // ------------------------------------------------------------------------------------------------
-// w_eff = scale * (w + lora_b * lora_a)  [N,K]  ->  w_bf [N,K] and wT_bf [K,N] (either may be null);
-// scale = tanh(*gate) when gate != nullptr.  bias_out = scale * bias (optional).
-hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const float* lora_b, int rank,
-                                 const float* gate, bf16_t* w_bf, bf16_t* wT_bf, const float* bias,
-                                 float* bias_out, int N, int K, hipStream_t s);
-// the same for a table of weights in one launch; offsets are floats from `base` (-1 = absent)
+// per weight: w_eff = scale * (w + lora_b * lora_a) [N,K] -> w_bf [N,K] and wT_bf [K,N] (either may be null);
+// scale = tanh(*gate) when a gate is given; bias_out = scale * bias.  All weights of the model go in ONE
+// launch through a job table; offsets are floats from `base` (-1 = absent)
 struct SfPrepJob {
   long w_off, la_off, lb_off, gate_off, bias_off;
   bf16_t* w_bf; bf16_t* wT_bf; float* bias_out;

@@ -299,7 +299,7 @@ hipError_t sf_launch_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32 row reductions (position / time embedding gradients) and row scatter-add
+// fp32 row reductions (position / time embedding gradients)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sf_sum_rows_kernel(const float* __restrict__ in, float* out, int n_a, long stride_a,
                                                           long stride_b, int R, long stride_r, int D, int accumulate) {
@@ -318,16 +318,6 @@ hipError_t sf_launch_sum_rows(const float* in, float* out, int n_out, int n_a, l
   if (n_out <= 0) return hipSuccess;
   if (D % 4 || n_a <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sf_sum_rows_kernel, dim3(n_out), dim3(256), 0, s, in, out, n_a, stride_a, stride_b, R, stride_r, D, accumulate);
-  return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void sf_scatter_add_rows_kernel(const float* __restrict__ in, float* out, SfRowIndex idx, int D) {
-  const int t = blockIdx.x;
-  for (int c = threadIdx.x; c < D; c += 256) out[(size_t)idx.idx[t] * D + c] += in[(size_t)t * D + c];
-}
-hipError_t sf_launch_scatter_add_rows(const float* in, float* out, const SfRowIndex& idx, int D, hipStream_t s) {
-  if (idx.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(sf_scatter_add_rows_kernel, dim3(idx.n), dim3(256), 0, s, in, out, idx, D);
   return hipGetLastError();
 }
 
@@ -368,22 +358,6 @@ SF_DEVICE void prep_tile(const float* __restrict__ w, const float* __restrict__ 
     const int n = n0 + threadIdx.x;
     if (n < N) bias_out[n] = bias ? scale * bias[n] : 0.f;
   }
-}
-
-__global__ __launch_bounds__(256) void sf_prep_weight_kernel(const float* __restrict__ w, const float* __restrict__ la,
-                                                             const float* __restrict__ lb, int rank, const float* gate,
-                                                             bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out,
-                                                             int N, int K) {
-  __shared__ float tile[32][33];
-  prep_tile(w, la, lb, rank, gate, w_bf, wT_bf, bias, bias_out, N, K, blockIdx.x, blockIdx.y, tile);
-}
-
-hipError_t sf_launch_prep_weight(const float* w, const float* lora_a, const float* lora_b, int rank, const float* gate,
-                                 bf16_t* w_bf, bf16_t* wT_bf, const float* bias, float* bias_out, int N, int K,
-                                 hipStream_t s) {
-  hipLaunchKernelGGL(sf_prep_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, s, w, lora_a, lora_b, rank,
-                     gate, w_bf, wT_bf, bias, bias_out, N, K);
-  return hipGetLastError();
 }
 
 // every weight of the model in ONE launch: workgroup -> (job, tile) through the jobs' tile prefix sums

@@ -232,6 +232,8 @@ class StreamformerTrainer:
         dp = d_pooler.to(torch.float32).contiguous()
         dl = None if d_last_hidden is None else d_last_hidden.to(torch.float32).contiguous()
         ws = self._ws
+        if ws is None or self._pooler is None:
+            raise RuntimeError("backward() needs a preceding forward() (its saved activations live in the workspace)")
         works = []
         nst = len(self.stage_ranges)
         with torch.cuda.device(self.device):

@@ -237,7 +237,7 @@ def test_streaming_f4(sa, golden_dir, mode, tag, nf):
         got = torch.cat(outs, 1)
         assert maxabs(got, want) <= lt
         # streamed == full clip on the same device path, to fp32 re-ordering noise
-        assert maxabs(got, full) <= (1e-4 if mode == "fp32" else 2e-2)
+        assert maxabs(got, full) <= (1e-4 if mode == "fp32" else 2e-2)   # same kernels serve both at these sizes
     with pytest.raises(Exception):                        # past the time-embedding rows / cache capacity
         m(x[:, :1], use_cache=True, past_key_values=cache)
     cache.reset()

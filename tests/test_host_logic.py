@@ -193,3 +193,18 @@ def test_allreduce_bucket_plan():
     assert all(a[1] == c[0] for a, c in zip(covered, covered[1:]))      # contiguous, disjoint, complete
     one = bucket_ranges(stages, 10**9)
     assert one == [(5, 0, 1000)]
+
+
+def test_trainer_refuses_to_run_without_a_gpu():
+    """No CPU fallback on the training path either: constructing the trainer without an AMD GPU raises."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    import pytest
+    from streamformer_amd.configuration import StreamformerConfig
+    from streamformer_amd.training import StreamformerTrainer
+    cfg = StreamformerConfig(image_size=48, patch_size=16, num_frames=16, hidden_size=128, num_hidden_layers=2,
+                             num_attention_heads=2, intermediate_size=256)
+    with pytest.raises(RuntimeError, match="GPU"):
+        StreamformerTrainer(cfg, {}, ["retrieval"])

@@ -373,3 +373,31 @@ def test_two_rank_allreduced_gradients_equal_the_big_batch():
     torch.cuda.synchronize()
     # mean over 4 clips == average of the two ranks' means over 2 clips; only summation order differs
     assert rel_l2(ret["grads"], tr.grads.cpu()) < 2e-3
+
+
+def test_trainer_rejects_what_it_cannot_do():
+    import streamformer_amd._native as nat
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    dev = _dev()
+    cfg = small_cfg(add_lora_spatial=True)
+    sd = make_state_dict(cfg, seed=8, lora=True)
+    tr = StreamformerTrainer(cfg, sd, ["retrieval"], device=dev)
+    with pytest.raises(ValueError):                       # wrong resolution
+        tr.forward(torch.zeros(1, 4, 3, 64, 64, device=dev))
+    with pytest.raises(nat.NativeError):                  # more frames than time-embedding rows
+        tr.forward(torch.zeros(1, 17, 3, 48, 48, device=dev))
+    with pytest.raises(RuntimeError):                     # backward without a forward
+        tr.backward(torch.zeros(1, 4, cfg.hidden_size, device=dev))
+    with pytest.raises(KeyError):                         # frozen parameters have no gradient slot
+        tr.grad("encoder.layer.0.attention.attention.qkv.weight")
+    sd2 = dict(sd)
+    sd2.pop("head.probe")
+    with pytest.raises(KeyError):
+        StreamformerTrainer(cfg, sd2, ["retrieval"], device=dev)
+    # state_dict round trip keeps the reference key names and the head scalars
+    out = tr.state_dict()
+    assert {k for k in sd if not k.endswith(".mask")} <= set(out) and "task_heads.retrieval.logit_scale" in out   # masks: unused buffers
+    assert abs(float(out["task_heads.retrieval.logit_scale"]) - math.log(10.0)) < 1e-6
+    for k in ("embeddings.position_embeddings", "encoder.layer.1.output.dense.weight"):
+        assert torch.equal(out[k].cpu(), sd[k].float())
