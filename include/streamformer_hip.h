@@ -101,6 +101,14 @@ int sf_forward(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, 
                float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
                const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 
+/* same, additionally returning the spatial attention probabilities of every layer
+ * (output_attentions=True, modeling:703-716, 1052-1057): attentions_dev fp32 [L, B*T, heads, N, N];
+ * N <= 224 patches per frame.                                                                     */
+int sf_forward_attentions(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, int T, int H, int W,
+                          float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
+                          float* attentions_dev, const float* pos_dev, void* workspace_dev,
+                          size_t workspace_bytes, sf_stream stream);
+
 /* ---- streaming forward with a temporal KV-cache ----------------------------------------------
  * replaces forward(..., past_key_values, use_cache=True) of the VideoQA copy
  * (reference downstream/VideoQA/llava/model/multimodal_encoder/timesformer_encoder.py:1316-1392;

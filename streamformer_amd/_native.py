@@ -47,6 +47,7 @@ SIGNATURES = {
     "sf_set_pixel_normalization": (_I, [_P, _P, _P, _I, _F]),
     "sf_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "sf_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sf_forward_attentions": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_cache_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
     "sf_cache_reset": (_I, [_P]),
     "sf_cache_length": (_I, [_P]),

@@ -242,6 +242,21 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
     // ---- softmax over keys (lane: query l15; keys 32*kt2 + 8*g + 4*hh + r) ------------------------
     const float sum = softmax_tiles<ACC, MAXNT2>(s, nt2, g, p.scale, N >> 5, [&](int, int key) { return key < N; });
     const float inv = 1.0f / sum;
+    if (p.probs) {          // output_attentions: the probabilities leave as fp32 rows (wave-uniform branch)
+      const int qi = qt * 16 + l15;
+      if (qi < N) {
+        float* prow = p.probs + (((size_t)frame * p.heads + h) * N + qi) * N;
+#pragma unroll
+        for (int kt2 = 0; kt2 < MAXNT2; ++kt2)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt2 * 32 + g * 8 + hh * 4 + r;
+              if (kt2 < nt2 && key < N) prow[key] = s[kt2][hh][r] * inv;
+            }
+      }
+    }
 
     // ---- O^T = V^T P^T ----------------------------------------------------------------------------
     f32x4_t o[4];
@@ -488,6 +503,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
   const int nkp = (a.N + 31) & ~31;
   if (nkp > 32 * 7) {                               // more than 224 tokens per frame: streaming-key kernel
+    if (a.probs) return hipErrorInvalidValue;       // probabilities are only materialised by the all-keys-in-LDS kernel
     const int qblocks = (a.N + 127) / 128;
     const size_t lds = (size_t)(SL_KC * 128 + HD * 2 * SL_KC + SP_WAVES * 2048) * (accurate ? 2 : 1);
     static bool attr_l = false;

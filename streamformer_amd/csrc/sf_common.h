@@ -190,6 +190,8 @@ struct SfAttnArgs {
   int B, Tq, Tk, Tcap, t_past, causal, Tq_cap, q_t0;
   bf16_t* ctx_hi; bf16_t* ctx_lo;     // [rows, D] output (lo only in accurate mode)
   int D;
+  float* probs;                       // spatial only, optional: softmax probabilities [frames, heads, N, N] fp32
+                                      // (output_attentions=True, modeling:703-716); N <= 224
 };
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);

@@ -556,7 +556,7 @@ static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfR
 static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
                        float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
                        const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
-                       hipStream_t s) {
+                       hipStream_t s, float* attentions = nullptr) {
   const sf_config& c = e->cfg;
   const int P = c.patch_size, D = e->D, heads = c.num_attention_heads;
   const int N = (H / P) * (W / P);
@@ -628,6 +628,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.q = ws.qkv; a.k = (char*)ws.qkv + (size_t)D * esz; a.v = (char*)ws.qkv + (size_t)2 * D * esz;
       a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
+      a.probs = attentions ? attentions + (size_t)li * F * heads * N * N : nullptr;
       HIP_TRY(sf_launch_spatial_attention(a, acc, s));
     }
     HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
@@ -678,9 +679,9 @@ extern "C" int sf_workspace_bytes(sf_encoder* e, int B, int T, int H, int W, siz
   return SF_OK;
 }
 
-extern "C" int sf_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
-                          float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
-                          void* workspace, size_t workspace_bytes, sf_stream stream) {
+static int forward_common(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W, float* last_hidden,
+                          float* pooler, float* hidden_states, float* attentions, const float* pos_dev, void* workspace,
+                          size_t workspace_bytes, sf_stream stream) {
   int N;
   int rc = check_geometry(e, B, T, H, W, pos_dev, &N);
   if (rc) return rc;
@@ -688,10 +689,26 @@ extern "C" int sf_forward(sf_encoder* e, const void* pixels, int pixel_dtype, in
   if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
   if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8) return set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8");
   if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per clip");
+  if (attentions && N > 224)
+    return set_err(SF_ERR_INVALID, "attention probabilities are materialised for <= 224 patches per frame (got %d)", N);
   Workspace ws = carve(e, workspace, B, T, N, true);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
   return run_forward(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, pos_dev, ws, nullptr, T, 0,
-                     false, (hipStream_t)stream);
+                     false, (hipStream_t)stream, attentions);
+}
+
+extern "C" int sf_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
+                          float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
+                          void* workspace, size_t workspace_bytes, sf_stream stream) {
+  return forward_common(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, nullptr, pos_dev, workspace,
+                        workspace_bytes, stream);
+}
+
+extern "C" int sf_forward_attentions(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
+                                     float* last_hidden, float* pooler, float* hidden_states, float* attentions,
+                                     const float* pos_dev, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  return forward_common(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, attentions, pos_dev, workspace,
+                        workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

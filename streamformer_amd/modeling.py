@@ -463,9 +463,8 @@ class TimesformerMultiTaskingModelSigLIP:
         output_attentions = c.output_attentions if output_attentions is None else output_attentions
         output_hidden_states = c.output_hidden_states if output_hidden_states is None else output_hidden_states
         return_dict = c.use_return_dict if return_dict is None else return_dict
-        if output_attentions:
-            raise NotImplementedError("output_attentions=True: the fused attention kernels never materialise "
-                                      "the [B*T, heads, N, N] probability tensor (modeling:703-705)")
+        if output_attentions and (use_cache or past_key_values is not None):
+            raise NotImplementedError("output_attentions with use_cache")
         if pixel_values.dim() != 5:
             raise ValueError(f"pixel_values must be (B, T, C, H, W), got {tuple(pixel_values.shape)}")
         B, T, C_, H, W = pixel_values.shape
@@ -510,15 +509,24 @@ class TimesformerMultiTaskingModelSigLIP:
             hs = torch.empty(L + 1, B, T, N, D, dtype=torch.float32, device=dev) if output_hidden_states else None
             nat.check(nat.lib.sf_workspace_bytes(self._handle, B, T, H, W, nat.C.byref(nbytes)))
             ws = self._workspace(("f", B, T, H, W, skey), nbytes.value)
-            nat.check(nat.lib.sf_forward(self._handle, x.data_ptr(), _TORCH2SF[x.dtype], B, T, H, W, lhs.data_ptr(),
-                                         pool.data_ptr(), nat.ptr(hs), nat.ptr(pos), ws.data_ptr(), ws.numel(), stream))
+            att = None
+            if output_attentions:
+                # the reference materialises these anyway (modeling:703-705); here only on request
+                att = torch.empty(L, B * T, c.num_attention_heads, N, N, dtype=torch.float32, device=dev)
+                nat.check(nat.lib.sf_forward_attentions(self._handle, x.data_ptr(), _TORCH2SF[x.dtype], B, T, H, W,
+                                                        lhs.data_ptr(), pool.data_ptr(), nat.ptr(hs), att.data_ptr(),
+                                                        nat.ptr(pos), ws.data_ptr(), ws.numel(), stream))
+            else:
+                nat.check(nat.lib.sf_forward(self._handle, x.data_ptr(), _TORCH2SF[x.dtype], B, T, H, W, lhs.data_ptr(),
+                                             pool.data_ptr(), nat.ptr(hs), nat.ptr(pos), ws.data_ptr(), ws.numel(), stream))
         hidden = None
         if hs is not None:
             # the reference hands back patch-major (B, N*T, D) tensors (modeling:1352): permuted views
             hidden = tuple(hs[i].permute(0, 2, 1, 3).reshape(B, N * T, D) for i in range(L + 1))
+        attentions = tuple(att[i] for i in range(L)) if att is not None else None    # spatial probabilities per layer
         if not return_dict:
-            return (lhs,) + ((hidden,) if hidden is not None else ())     # modeling:1347-1348
-        return BaseModelOutputWithPooling(lhs, pool, hidden_states=hidden, attentions=None)
+            return (lhs,) + ((hidden,) if hidden is not None else ()) + ((attentions,) if attentions is not None else ())
+        return BaseModelOutputWithPooling(lhs, pool, hidden_states=hidden, attentions=attentions)
 
     __call__ = forward
 

@@ -434,3 +434,36 @@ def test_forward_more_than_224_patches(mode, tol):
     cache = m.new_cache(1, 4)
     outs = [m(x[:, t:t + 1].cuda(), use_cache=True, past_key_values=cache).last_hidden_state for t in range(4)]
     assert maxabs(torch.cat(outs, 1), want["last_hidden_state"]) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_output_attentions(golden_dir, mode, tol):
+    """output_attentions=True (modeling:703-716): per-layer spatial probabilities [B*T, heads, N, N] vs the
+    reference's own (fixture F10); same hidden states as without the flag; tuple form; SigLIP-base shape."""
+    import streamformer_amd as sa
+    f = load_npz(os.path.join(golden_dir, "f10_attentions.npz"))
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=10)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    x = frames(10, (2, 5, 3, 48, 48)).cuda()
+    out = m(x, output_attentions=True)
+    assert len(out.attentions) == cfg.num_hidden_layers and tuple(out.attentions[0].shape) == (10, 2, 9, 9)
+    got = torch.stack(list(out.attentions)).cpu()
+    assert maxabs(got, f["attentions"]) <= tol
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-5
+    assert torch.equal(out.last_hidden_state, m(x).last_hidden_state)
+    tup = m(x, output_attentions=True, output_hidden_states=True, return_dict=False)
+    assert len(tup) == 3 and len(tup[2]) == cfg.num_hidden_layers
+    with pytest.raises(NotImplementedError):
+        m(x[:, :1], output_attentions=True, use_cache=True)
+    if mode == "bf16":      # N = 196, 12 heads: rows sum to one, softmax of what the kernel's own context used
+        big = siglip_base(num_hidden_layers=1)
+        mb = sa.TimesformerMultiTaskingModelSigLIP(big, compute_dtype="bf16")
+        mb.load_state_dict(make_state_dict(big, seed=2))
+        mb.to("cuda")
+        ob = mb(frames(3, (1, 2, 3, 224, 224)).cuda(), output_attentions=True)
+        a = ob.attentions[0]
+        assert tuple(a.shape) == (2, 12, 196, 196) and float((a.sum(-1) - 1).abs().max()) < 1e-5 and float(a.min()) >= 0
