@@ -109,6 +109,25 @@ int sf_forward_attentions(sf_encoder* enc, const void* pixels_dev, int pixel_dty
                           float* attentions_dev, const float* pos_dev, void* workspace_dev,
                           size_t workspace_bytes, sf_stream stream);
 
+/* ---- the forward in three stages, for callers that interleave their own modules ------------------
+ * (reference sub-module users: `blk(x, T, output_attentions=False)[0]` over encoder.layer in the
+ * ViT-Adapter interaction blocks, models/modeling_timesformer_siglip_adapter.py:424-425; the
+ * embeddings -> encoder -> post_layernorm -> head sequence of the video classifier,
+ * downstream/AR/models/modeling_timesformer_video_classification.py:121-134).
+ * hidden_dev: the caller's residual stream, fp32 FRAME-major [B,T,N,D] (the reference's patch-major
+ * (B, N*T, D) is a permuted view of it); sf_layers updates it in place.
+ * attentions_dev (optional): fp32 [layer_end-layer_begin, B*T, heads, N, N].  Workspace: sf_workspace_bytes. */
+int sf_embed(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, int T, int H, int W,
+             float* hidden_out_dev, const float* pos_dev, void* workspace_dev, size_t workspace_bytes,
+             sf_stream stream);                                         /* TimesformerEmbeddingsSigLIP.forward, modeling:413-457 */
+int sf_layers(sf_encoder* enc, float* hidden_dev, int B, int T, int H, int W, int layer_begin, int layer_end,
+              float* attentions_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+                                                                        /* TimesformerLayerSigLIP.forward x (end-begin), modeling:934-1004 */
+int sf_post_head(sf_encoder* enc, float* hidden_dev, int B, int T, int H, int W, float* last_hidden_dev,
+                 float* pooler_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+                                                                        /* post_layernorm + head, modeling:1330-1340, 1141-1154;
+                                                                           last_hidden_dev == NULL: head alone on normalised tokens */
+
 /* ---- streaming forward with a temporal KV-cache ----------------------------------------------
  * replaces forward(..., past_key_values, use_cache=True) of the VideoQA copy
  * (reference downstream/VideoQA/llava/model/multimodal_encoder/timesformer_encoder.py:1316-1392;

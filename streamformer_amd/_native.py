@@ -48,6 +48,9 @@ SIGNATURES = {
     "sf_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "sf_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_forward_attentions": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sf_embed": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "sf_layers": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    "sf_post_head": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "sf_cache_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
     "sf_cache_reset": (_I, [_P]),
     "sf_cache_length": (_I, [_P]),

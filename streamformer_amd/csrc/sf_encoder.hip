@@ -556,7 +556,11 @@ static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfR
 static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
                        float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
                        const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
-                       hipStream_t s, float* attentions = nullptr) {
+                       hipStream_t s, float* attentions = nullptr, int stages = 7, int la = 0, int lb = -1) {
+  // stages: 1 = embeddings -> ws.resid, 2 = layers [la, lb) on ws.resid, 4 = post-LayerNorm + pooling head,
+  // 8 = pooling head alone on already-normalised tokens in ws.resid
+  // (the sub-module entry points run them one at a time on a caller-owned residual stream)
+  if (lb < 0) lb = e->L;
   const sf_config& c = e->cfg;
   const int P = c.patch_size, D = e->D, heads = c.num_attention_heads;
   const int N = (H / P) * (W / P);
@@ -566,6 +570,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const size_t esz = acc ? 4 : 2;
   const float scale = 1.0f / sqrtf(64.0f);
 
+  if (stages & 1) {
   SfRowIndex idx;
   int rc = time_rows(e, t_past, T, streaming, &idx);
   if (rc) return rc;
@@ -584,14 +589,15 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     g.out_f32 = ws.resid; g.ldc = D;
     HIP_TRY(sf_launch_gemm(g, acc, s));
   }
+  }
   const size_t hs_stride = (size_t)M * D;
   // LN folding (bf16 mode, BASELINE-sized M): xn_hi holds bf16(residual), ln_stats the row sums; the
   // three per-layer LayerNorm launches disappear into the neighbouring GEMM epilogues.
   const bool fold = ln_fold_ok(e, M) && !streaming;
   bf16_t* fold_hi = fold ? ws.xn_hi : nullptr;
   float* fold_st = fold ? ws.ln_stats : nullptr;
-  if (fold) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
-  for (int li = 0; li < e->L; ++li) {
+  if (fold && (stages & 2)) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
+  for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];
     if (hidden_states)
       HIP_TRY(hipMemcpyAsync(hidden_states + li * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
@@ -628,7 +634,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.q = ws.qkv; a.k = (char*)ws.qkv + (size_t)D * esz; a.v = (char*)ws.qkv + (size_t)2 * D * esz;
       a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
-      a.probs = attentions ? attentions + (size_t)li * F * heads * N * N : nullptr;
+      a.probs = attentions ? attentions + (size_t)(li - la) * F * heads * N * N : nullptr;
       HIP_TRY(sf_launch_spatial_attention(a, acc, s));
     }
     HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
@@ -640,10 +646,14 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
                        0, 0, 0, 0, nullptr, fold_st));
   }
-  if (hidden_states)
+  if (hidden_states && (stages & 2) && lb == e->L)
     HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
+  if (!(stages & 12)) return SF_OK;
   // ---- post LayerNorm + pooling head (modeling:1330-1340, 1141-1154) -------------------------------
-  HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+  if (stages & 4)
+    HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+  else      // stage 8: the head alone on tokens the caller has already normalised (model.head(x))
+    HIP_TRY(sf_launch_split(ws.resid, ws.xn_hi, acc ? ws.xn_lo : nullptr, (size_t)M * D, s));
   if (pooler) {
     HIP_TRY(run_linear(e, e->head_kv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
     HIP_TRY(sf_launch_pool_attention(e->head_q, ws.qkv, acc, 2 * D, ws.pc_hi, ws.pc_lo, F, N, heads, D, s));
@@ -709,6 +719,53 @@ extern "C" int sf_forward_attentions(sf_encoder* e, const void* pixels, int pixe
                                      const float* pos_dev, void* workspace, size_t workspace_bytes, sf_stream stream) {
   return forward_common(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, attentions, pos_dev, workspace,
                         workspace_bytes, stream);
+}
+
+// ---- sub-module entry points: the reference's model.embeddings / model.encoder.layer[i] / post_layernorm + head
+// called one at a time (adapter and classification users, modeling_timesformer_siglip_adapter.py:424-425,
+// downstream/AR/models/modeling_timesformer_video_classification.py:121-134).  hidden is the caller's
+// residual stream, fp32 frame-major [B,T,N,D], updated in place by sf_layers.
+static int stage_common(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W, float* hidden,
+                        float* last_hidden, float* pooler, float* attentions, const float* pos_dev, void* workspace,
+                        size_t workspace_bytes, sf_stream stream, int stages, int la, int lb) {
+  int N;
+  int rc = check_geometry(e, B, T, H, W, pos_dev, &N);
+  if (rc) return rc;
+  if (!e->finalized) return set_err(SF_ERR_STATE, "sf_finalize_weights has not run");
+  if (!hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
+  if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per clip");
+  if ((stages & 2) && (la < 0 || lb > e->L || la > lb)) return set_err(SF_ERR_INVALID, "layer range [%d, %d) outside [0, %d)", la, lb, e->L);
+  if (attentions && N > 224) return set_err(SF_ERR_INVALID, "attention probabilities need <= 224 patches per frame");
+  Workspace ws = carve(e, workspace, B, T, N, true);
+  if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
+  ws.resid = hidden;                       // the caller's tensor IS the residual stream
+  return run_forward(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, nullptr, pos_dev, ws, nullptr, T, 0, false,
+                     (hipStream_t)stream, attentions, stages, la, lb);
+}
+
+extern "C" int sf_embed(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W, float* hidden_out,
+                        const float* pos_dev, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  if (!pixels) return set_err(SF_ERR_INVALID, "null pixels");
+  if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8) return set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8");
+  return stage_common(e, pixels, pixel_dtype, B, T, H, W, hidden_out, nullptr, nullptr, nullptr, pos_dev, workspace, workspace_bytes,
+                      stream, 1, 0, 0);
+}
+
+extern "C" int sf_layers(sf_encoder* e, float* hidden, int B, int T, int H, int W, int layer_begin, int layer_end,
+                         float* attentions, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  // geometry only sizes the workspace here: a non-null table pointer passes the resolution check
+  const float* pos_ok = e ? e->pos : nullptr;
+  return stage_common(e, nullptr, SF_F32, B, T, H, W, hidden, nullptr, nullptr, attentions, pos_ok, workspace, workspace_bytes, stream,
+                      2, layer_begin, layer_end);
+}
+
+extern "C" int sf_post_head(sf_encoder* e, float* hidden, int B, int T, int H, int W, float* last_hidden, float* pooler,
+                            void* workspace, size_t workspace_bytes, sf_stream stream) {
+  // last_hidden != NULL: post_layernorm(hidden) -> last_hidden, then the head on it -> pooler (may be NULL);
+  // last_hidden == NULL: `hidden` is already normalised, the head alone -> pooler
+  if (!last_hidden && !pooler) return set_err(SF_ERR_INVALID, "nothing to compute");
+  return stage_common(e, nullptr, SF_F32, B, T, H, W, hidden, last_hidden, pooler, nullptr, e ? e->pos : nullptr, workspace,
+                      workspace_bytes, stream, last_hidden ? 4 : 8, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -530,6 +530,62 @@ class TimesformerMultiTaskingModelSigLIP:
 
     __call__ = forward
 
+
+    # -------------------------------------------------------------------------------- sub-modules
+    # The reference's users that drive the encoder piecewise (ViT-Adapter interaction blocks:
+    # `blk(x, T, output_attentions=False)[0]`, modeling_timesformer_siglip_adapter.py:424-425; the video
+    # classifier: embeddings -> encoder -> post_layernorm -> head, downstream/AR/...:121-134) keep their
+    # call shapes: tensors cross this surface in the reference's PATCH-major (B, N*T, D) order and are
+    # permuted to the library's frame-major layout around each native call.
+    def _stage_ws(self, B: int, T: int, H: int, W: int):
+        self._sync()
+        n = nat.C.c_size_t()
+        nat.check(nat.lib.sf_workspace_bytes(self._handle, B, T, H, W, nat.C.byref(n)))
+        return self._workspace(("f", B, T, H, W, int(nat.current_stream_handle(self._device) or 0)), n.value)
+
+    def _grid(self, n_tokens: int, T: int) -> Tuple[int, int]:
+        """(H, W) of a frame whose patch grid has n_tokens / T cells (square, or the config's aspect)."""
+        N = n_tokens // T
+        P = self.config.patch_size
+        side = int(round(N ** 0.5))
+        if side * side != N or N * T != n_tokens:
+            raise ValueError(f"{n_tokens} tokens do not form {T} frames of a square patch grid")
+        return side * P, side * P
+
+    @property
+    def embeddings(self):
+        return _Embeddings(self)
+
+    @property
+    def encoder(self):
+        return _Encoder(self)
+
+    def post_layernorm(self, x: torch.Tensor) -> torch.Tensor:
+        """nn.LayerNorm(D, eps) with the post_layernorm weights (modeling:1251, 1330), any leading shape."""
+        self._sync()
+        dev = self._device
+        xf = x.to(dev, torch.float32).contiguous()
+        y = torch.empty_like(xf)
+        g = self._sd["post_layernorm.weight"].to(dev, torch.float32).contiguous()
+        b = self._sd["post_layernorm.bias"].to(dev, torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            nat.check(nat.lib.sf_op_layernorm(xf.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), xf.numel() // xf.shape[-1],
+                                              xf.shape[-1], float(self.config.layer_norm_eps), nat.current_stream_handle(dev)))
+        return y
+
+    def head(self, x: torch.Tensor) -> torch.Tensor:
+        """TimesformerSiglipMultiheadAttentionPoolingHead.forward (modeling:1141-1154): x (F, N, D) -> (F, D)."""
+        Fr, N, D = x.shape
+        H, W = self._grid(N, 1)
+        ws = self._stage_ws(Fr, 1, H, W)
+        dev = self._device
+        xf = x.to(dev, torch.float32).contiguous()
+        pool = torch.empty(Fr, D, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(nat.lib.sf_post_head(self._handle, xf.data_ptr(), Fr, 1, H, W, None, pool.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           nat.current_stream_handle(dev)))
+        return pool
+
     def forward_features(self, pixel_values: torch.Tensor, pooling_method: str = "last") -> torch.Tensor:
         """StreamformerForMultiTaskingSigLIP.forward_features (modeling:1525-1536)."""
         out = self.forward(pixel_values)
@@ -538,6 +594,95 @@ class TimesformerMultiTaskingModelSigLIP:
         if pooling_method in ("mean", "avg"):
             return out.pooler_output.mean(dim=1)
         raise ValueError(pooling_method)
+
+
+
+def _to_frame_major(x: torch.Tensor, T: int) -> torch.Tensor:
+    """reference (B, N*T, D), token = n*T + t  ->  [B, T, N, D] contiguous fp32"""
+    B, NT, D = x.shape
+    return x.reshape(B, NT // T, T, D).permute(0, 2, 1, 3).contiguous().float()
+
+
+def _to_patch_major(h: torch.Tensor) -> torch.Tensor:
+    B, T, N, D = h.shape
+    return h.permute(0, 2, 1, 3).reshape(B, N * T, D)
+
+
+class _Embeddings:
+    """``model.embeddings(pixel_values) -> (B, N*T, D)`` (TimesformerEmbeddingsSigLIP.forward, modeling:413-457)."""
+
+    def __init__(self, model: "TimesformerMultiTaskingModelSigLIP"):
+        self.model = model
+
+    def __call__(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        B, T, _, H, W = pixel_values.shape
+        ws = m._stage_ws(B, T, H, W)
+        dev = m._device
+        x = pixel_values.to(dev)
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
+            x = x.float()
+        x = x.contiguous()
+        c = m.config
+        N = (H // c.patch_size) * (W // c.patch_size)
+        h = torch.empty(B, T, N, c.hidden_size, dtype=torch.float32, device=dev)
+        pos = m._pos_table(H, W)
+        with torch.cuda.device(dev):
+            nat.check(nat.lib.sf_embed(m._handle, x.data_ptr(), _TORCH2SF[x.dtype], B, T, H, W, h.data_ptr(), nat.ptr(pos),
+                                       ws.data_ptr(), ws.numel(), nat.current_stream_handle(dev)))
+        return _to_patch_major(h)
+
+
+class _Layer:
+    """``model.encoder.layer[i](hidden_states, T, output_attentions=False) -> (hidden_states[, attn])``
+    (TimesformerLayerSigLIP.forward, modeling:934-1004), patch-major in and out."""
+
+    def __init__(self, model: "TimesformerMultiTaskingModelSigLIP", index: int):
+        self.model, self.index = model, index
+
+    def __call__(self, hidden_states: torch.Tensor, T: int, output_attentions: bool = False):
+        out = self.model.encoder._run(hidden_states, T, self.index, self.index + 1, output_attentions)
+        return (out[0],) + ((out[1][0],) if output_attentions else ())
+
+
+class _Encoder:
+    """``model.encoder(hidden_states, num_frames=T, ...)`` (TimesformerEncoder.forward, modeling:1019-1063)."""
+
+    def __init__(self, model: "TimesformerMultiTaskingModelSigLIP"):
+        self.model = model
+        self.layer = [_Layer(model, i) for i in range(model.config.num_hidden_layers)]
+
+    def _run(self, hidden_states: torch.Tensor, T: int, la: int, lb: int, want_attn: bool):
+        m = self.model
+        B, NT, D = hidden_states.shape
+        H, W = m._grid(NT, T)
+        ws = m._stage_ws(B, T, H, W)
+        dev = m._device
+        h = _to_frame_major(hidden_states.to(dev), T)
+        N = NT // T
+        att = torch.empty(lb - la, B * T, m.config.num_attention_heads, N, N, dtype=torch.float32, device=dev) if want_attn else None
+        with torch.cuda.device(dev):
+            nat.check(nat.lib.sf_layers(m._handle, h.data_ptr(), B, T, H, W, la, lb, nat.ptr(att), ws.data_ptr(), ws.numel(),
+                                        nat.current_stream_handle(dev)))
+        return _to_patch_major(h), (tuple(att[i] for i in range(lb - la)) if want_attn else None)
+
+    def __call__(self, hidden_states: torch.Tensor, num_frames: int, output_attentions: bool = False,
+                 output_hidden_states: bool = False, return_dict: bool = True):
+        L = self.model.config.num_hidden_layers
+        hs, atts = ((hidden_states,) if output_hidden_states else None), (() if output_attentions else None)
+        x = hidden_states
+        if output_hidden_states:                      # layer by layer: every intermediate is an output
+            for i in range(L):
+                x, a = self._run(x, num_frames, i, i + 1, output_attentions)
+                hs = hs + (x,)
+                if output_attentions:
+                    atts = atts + a
+        else:
+            x, a = self._run(x, num_frames, 0, L, output_attentions)
+            atts = a
+        if not return_dict:
+            return tuple(v for v in (x, hs, atts) if v is not None)
+        return ModelOutput(last_hidden_state=x, hidden_states=hs, attentions=atts)
 
 
 class TimesformerVisionTower:
