@@ -15,6 +15,7 @@
 // phase after its last read (>= the retiring lgkmcnt + one barrier for both halves), and read one
 // phase after the vmcnt that retires it.
 #include "sf_common.h"
+#include <cstdlib>
 
 #define P_THREADS 512
 #define P_NT 3
@@ -36,7 +37,7 @@ SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
 }
 
 template <int P_MT>
-__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles) {
+__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -45,6 +46,13 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
   const int l15 = lane & 15, g = lane >> 4;
   const int K = p.K;
   const int nkt = K >> 5;
+  if (stagger_ticks > 0) {      // phase stagger, see sf_gemm256.hip
+    const int grp = (blockIdx.x >> 4) % 3;
+    if (grp) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)grp * (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   // tile = (row panel, column half); the two halves of a row panel sit on the same XCD (b, b+8)
   for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
   const int panel = (bid >> 4) * 8 + (bid & 7), nh = (bid >> 3) & 1;
@@ -256,13 +264,18 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
 #undef SF_PATTR
     attr_set = true;
   }
+  // Phase stagger (see sf_gemm256.hip): three groups 3.5 us apart spread the read-heavy main loops and the
+  // residual read + store bursts of the epilogues.  Box-dependent: -3.3 % on the whole forward on one MI355X,
+  // neutral on another; never slower in the sweeps (tools/stagger_sweep.py).  SF_PANEL_STAGGER_NS overrides.
+  int stagger = ntiles >= cus ? 350 : 0;
+  if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = atoi(e) / 10;
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
   switch (pl.mt) {
-    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles); break;
-    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles); break;
-    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles); break;
-    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles); break;
+    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
   }
   return hipGetLastError();
 }
