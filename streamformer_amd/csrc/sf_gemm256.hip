@@ -395,6 +395,9 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
       stagger = (int)(tile_ns * pct / 100.0 / 10.0);
     }
   }
+  if (const char* only = getenv("SF_G256_STAGGER_ONLY")) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs
+    if (a.epi != atoi(only)) stagger = 0;
+  }
   const bool lnf = a.ln_stats != nullptr;
   if (lnf && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return hipErrorInvalidValue;
   switch (a.epi) {
