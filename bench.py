@@ -17,6 +17,8 @@ Extra objects on that line:
   accurate_mode frames/s of the fp32-accurate (bf16x3) mode on the same workload
   cpu_baseline  the CPU oracle (a restatement pinned against the reference, kind "port") timed on the
                 host cores on a bounded sample: B=1 clips of the same shape
+  streaming     BASELINE configs[4]: per-frame latency (p50 / p99) of the KV-cached streaming path, 64-frame online
+                clip at B = 1, and the achieved HBM rate against the algorithmic bytes of a frame
   train_step    BASELINE configs[2]: frames/s of one multitask pre-training step (forward + loss + backward +
                 AdamW) on the same clip shape, with its own CPU baseline; `--mode train` makes that step THE
                 timed step (configs[2] at N=1, configs[3] with the gradient all-reduce at N>1)
@@ -188,6 +190,38 @@ def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
     return res
 
 
+def streaming_bench(dev):
+    """Per-frame latency of the streaming path: num_frames = 64, B = 1, one frame per
+    call, cache reset between repeats; p50 / p99 over the frames of 3 timed repeats, and the achieved HBM rate
+    against the algorithmic bytes of a frame (weights 255 MB + KV read 7.225 MB x (t+1) + KV write + activations)."""
+    import streamformer_amd as sa
+    cfg = sa.siglip_base(num_frames=64)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
+    m.load_state_dict(sa.make_state_dict(cfg, seed=0))
+    m.to(dev)
+    x = torch.randn(1, 64, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(64)).to(dev)
+    cache = m.new_cache(1, 64)
+    lat = []
+    for rep in range(4):
+        cache.reset()
+        for t in range(64):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m(x[:, t:t + 1], use_cache=True, past_key_values=cache)
+            torch.cuda.synchronize()
+            if rep:
+                lat.append(time.perf_counter() - t0)
+    lat.sort()
+    mean = sum(lat) / len(lat)
+    gb = (255.0 + 7.225 * (64 + 1) / 2 + 7.225 + 12.0) / 1e3          # mean algorithmic GB per frame over t = 0..63
+    del m, cache
+    torch.cuda.empty_cache()
+    return {"p50_ms": round(1e3 * lat[len(lat) // 2], 3), "p99_ms": round(1e3 * lat[int(len(lat) * 0.99)], 3),
+            "mean_ms": round(1e3 * mean, 3), "frames_per_s": round(1.0 / mean, 1), "algorithmic_GB_per_frame": round(gb, 3),
+            "GBps": round(gb / mean, 1), "frac_of_hbm_peak": round(gb / mean / PEAK_HBM_GBS, 4),
+            "config": "SigLIP-base, num_frames=64, B=1, one 224^2 frame per call, bf16 mode, KV-cache of 64 frames"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -354,6 +388,12 @@ def main():
                                              f"(median {med:.3f}s, best {ts[0]:.3f}s), fp32 eager torch {torch.__version__}",
                                    "cpu": cpu_model, "best": round(T / ts[0], 2)}
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        if world == 1 and not args.profile:
+            # BASELINE configs[4]: 64-frame online clip, one frame per call through the KV-cache (B = 1)
+            try:
+                out["streaming"] = streaming_bench(dev)
+            except Exception as e:
+                out["streaming"] = {"error": repr(e)}
         if world == 1 and not args.no_train:
             # BASELINE configs[2]: the multitask pre-training step on the same clip shape (short measurement;
             # `--mode train` times it under the full contract, also at N > 1)
