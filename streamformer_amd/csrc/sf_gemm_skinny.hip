@@ -15,6 +15,7 @@
 //   * A is re-read by the N/32 column workgroups from L2 (it is 0.3-1.2 MB), W by the M/32 row groups.
 // SPLIT = the fp32-accurate bf16x3 mode (hi/lo planes of both operands, three MFMAs per fragment pair).
 #include "sf_common.h"
+#include <cstdlib>
 
 #define SK_BM 32
 #define SK_BN 32
@@ -148,6 +149,151 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K-parallel variant for the N = 768 projections of the streaming step (168 workgroups at one frame: every
+// workgroup has a CU to itself, and what bounds it is the number of SEQUENTIAL K-tiles — 12 at K = 768,
+// 48 at K = 3072 for the MLP down-projection).  KG groups of 4 waves split the K range, each with its own
+// 4-stage ring; the groups iterate in lock-step on one barrier per step (a quarter / half as many steps),
+// then groups 1.. hand their partial 16x16 tiles to group 0 through LDS (fixed order: deterministic) and
+// group 0 runs the usual fused epilogue.  KG = 4 (bf16, 1024 threads), KG = 2 (bf16x3, 512 threads).
+// ------------------------------------------------------------------------------------------------
+#define SKG_STAGES 4
+
+template <bool SPLIT, int EPI, int KG>
+__global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGemmArgs p) {
+  constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);
+  constexpr int RING = SKG_STAGES * STAGE;
+  constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // per thread of a group = 2
+  constexpr int PER = LOADS * (SPLIT ? 2 : 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kgrp = wave >> 2, w4 = wave & 3, tid_g = tid & (SK_THREADS - 1);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
+  const int nkt = p.K / SK_BK;
+  const int per_grp = (nkt + KG - 1) / KG;              // K-tiles of a group (the last group may own fewer)
+  const int kt_base = kgrp * per_grp;
+  const int mine = max(0, min(per_grp, nkt - kt_base));
+
+  const bf16_t* src_hi[LOADS];
+  const bf16_t* src_lo[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int c = i * SK_THREADS + tid_g;
+    const int row = c >> 3, slot = c & 7;
+    const int kc = slot ^ ((row >> 1) & 7);
+    if (row < SK_BM) {
+      int gr = m0 + row;
+      gr = gr < p.M ? gr : p.M - 1;
+      src_hi[i] = p.a_hi + (size_t)gr * p.K + kc * 8;
+      src_lo[i] = SPLIT ? p.a_lo + (size_t)gr * p.K + kc * 8 : nullptr;
+    } else {
+      int gr = n0 + row - SK_BM;
+      gr = gr < p.N ? gr : p.N - 1;
+      src_hi[i] = p.w_hi + (size_t)gr * p.K + kc * 8;
+      src_lo[i] = SPLIT ? p.w_lo + (size_t)gr * p.K + kc * 8 : nullptr;
+    }
+  }
+  char* ring = smem + kgrp * RING;
+  auto issue = [&](int j) {                              // j = K-tile index inside the group's range
+    char* dst = ring + (j % SKG_STAGES) * STAGE + w4 * 1024;
+    const int kt = kt_base + j;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
+      if (SPLIT) __builtin_amdgcn_global_load_lds((gptr_t)(src_lo[i] + kt * SK_BK), (lptr_t)(dst + SK_PLANE + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int mt = w4 & 1, nt = w4 >> 1;
+  for (int j = 0; j < SKG_STAGES - 1 && j < mine; ++j) issue(j);
+  for (int j = 0; j < per_grp; ++j) {                    // every group runs per_grp steps: one barrier domain
+    const int later = min(mine - 1 - j, SKG_STAGES - 2);
+    if (later >= 2) sk_wait<2 * PER>(); else if (later == 1) sk_wait<PER>(); else sk_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if (j + SKG_STAGES - 1 < mine) issue(j + SKG_STAGES - 1);
+    if (j < mine) {
+      const char* img = ring + (j % SKG_STAGES) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = ks * 4 + g;
+        const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
+        const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
+        if (SPLIT) {
+          const char* lo = img + SK_PLANE;
+          const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
+          const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
+          acc = sk_mfma(wl, af, acc);
+          acc = sk_mfma(wf, al, acc);
+        }
+        acc = sk_mfma(wf, af, acc);
+      }
+    }
+  }
+  // ---- cross-group reduction through the (now idle) ring of group 0 ------------------------------------
+  __builtin_amdgcn_s_barrier();
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
+  if (kgrp > 0) red[((kgrp - 1) * 4 + w4) * 64 + lane] = acc;
+  __syncthreads();
+  if (kgrp > 0) return;
+#pragma unroll
+  for (int k = 1; k < KG; ++k) acc += red[((k - 1) * 4 + w4) * 64 + lane];
+
+  const int n = n0 + nt * 16 + g * 4;
+  const int m = m0 + mt * 16 + l15;
+  if (n >= p.N || m >= p.M) return;
+  f32x4_t bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+  size_t orow = (size_t)m;
+  if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+  f32x4_t v = acc + bias;
+  const size_t o = orow * (size_t)p.ldc + n;
+  if (EPI == SF_EPI_F32) {
+    *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+  } else if (EPI == SF_EPI_RESID_F32) {
+    const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.resid + o);
+    v = r + p.alpha * v;
+    *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+  } else {
+    if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_fast(v[j], p.act);
+    }
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf(v[j], h[j], l[j]);
+    *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    if (p.out_lo) *reinterpret_cast<u32x2_t*>(p.out_lo + o) = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+  }
+}
+
+template <bool SPLIT, int KG>
+static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
+  const size_t lds = (size_t)KG * SKG_STAGES * SK_PLANE * (SPLIT ? 2 : 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+#define SKG_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<SPLIT, E, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SKG_ATTR(SF_EPI_F32) SKG_ATTR(SF_EPI_BF16) SKG_ATTR(SF_EPI_ACT_BF16) SKG_ATTR(SF_EPI_RESID_F32)
+#undef SKG_ATTR
+    attr_set = true;
+  }
+#define SKG_CASE(E)                                                                                              \
+  case E:                                                                                                        \
+    hipLaunchKernelGGL((sf_gemm_skinny_kg_kernel<SPLIT, E, KG>), grid, dim3(SK_THREADS * KG), lds, s, a);        \
+    break;
+  switch (a.epi) {
+    SKG_CASE(SF_EPI_F32)
+    SKG_CASE(SF_EPI_BF16)
+    SKG_CASE(SF_EPI_ACT_BF16)
+    SKG_CASE(SF_EPI_RESID_F32)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef SKG_CASE
+  return hipGetLastError();
+}
+
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
   if (a.M <= 0 || a.M > 512 || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
   if (a.ln_stats || a.ln_stats_out) return false;
@@ -178,6 +324,9 @@ static hipError_t sk_launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipS
 hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s) {
   if (!sf_gemm_skinny_supported(a, split)) return hipErrorInvalidValue;
   const dim3 grid((a.N + SK_BN - 1) / SK_BN, (a.M + SK_BM - 1) / SK_BM);
+  // every workgroup gets its own CU and the K loop is long: the K-parallel variant
+  if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !getenv("SF_SKINNY_NO_KG"))
+    return split ? skg_launch<true, 2>(a, grid, s) : skg_launch<false, 4>(a, grid, s);
   const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
   static bool attr_set = false;
   if (!attr_set) {
