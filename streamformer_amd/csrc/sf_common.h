@@ -140,6 +140,8 @@ struct SfGemmArgs {
   int aux_mode;
   bf16_t* aux;                              // [*, ldc], same row remap as the output
 };
+// nanoseconds -> ticks of wall_clock64() on the current device (s_memrealtime: 100 MHz on MI355X; queried once)
+int sf_wall_clock_ticks(int ns);
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches skinny / panel / 256^2 / 128^2
 hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   // sf_gemm.hip
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split);                      // sf_gemm256.hip

@@ -221,6 +221,16 @@ static hipError_t launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStre
   return hipGetLastError();
 }
 
+int sf_wall_clock_ticks(int ns) {
+  static int khz = 0;
+  if (!khz) {
+    int dev = 0, rate = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, dev) == hipSuccess && rate > 0) khz = rate;
+    else khz = 100000;
+  }
+  return (int)((long long)ns * khz / 1000000);
+}
+
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
   if (a.aux_mode) return sf_gemm256_aux_supported(a) && !split ? sf_launch_gemm256(a, s) : hipErrorInvalidValue;
   if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);

@@ -376,7 +376,7 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const dim3 grid(g256_grid()), block(G_THREADS);
-  // stagger = one third of the estimated tile period (wall clock ticks of 10 ns), only when the launch runs
+  // stagger as wall_clock64() ticks (sf_wall_clock_ticks), only when the launch runs
   // several rounds of tiles per CU; SF_G256_STAGGER_NS overrides (0 disables) for A/B measurements
   // Phase stagger (see the kernel): `sgroups` groups, each delayed by one more step; step = a fraction of the
   // estimated tile period (MFMA time at ~1 PF + the store burst).  Only when every CU runs >= 3 tiles.
@@ -389,10 +389,10 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
     double pct = 21.0;
     if (const char* pe = getenv("SF_G256_STAGGER_PCT")) pct = atof(pe);
     const char* env = getenv("SF_G256_STAGGER_NS");
-    if (env) stagger = atoi(env) / 10;
+    if (env) stagger = sf_wall_clock_ticks(atoi(env));
     else if (rounds >= 3) {
       const double tile_ns = 2.0 * BM * 256.0 * a.K / 3.9e3 + 6500.0;     // flops / (3.9 TF per CU) + store burst
-      stagger = (int)(tile_ns * pct / 100.0 / 10.0);
+      stagger = sf_wall_clock_ticks((int)(tile_ns * pct / 100.0));
     }
   }
   if (const char* only = getenv("SF_G256_STAGGER_ONLY")) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs

@@ -267,8 +267,8 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   // Phase stagger (see sf_gemm256.hip): three groups 3.5 us apart spread the read-heavy main loops and the
   // residual read + store bursts of the epilogues.  Box-dependent: -3.3 % on the whole forward on one MI355X,
   // neutral on another; never slower in the sweeps (tools/stagger_sweep.py).  SF_PANEL_STAGGER_NS overrides.
-  int stagger = (ntiles >= cus && pl.mt == 13) ? 350 : 0;      // full-height tiles only: small tiles finish before a step elapses
-  if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = atoi(e) / 10;
+  int stagger = (ntiles >= cus && pl.mt == 13) ? sf_wall_clock_ticks(3500) : 0;      // full-height tiles only: small tiles finish before a step elapses
+  if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = sf_wall_clock_ticks(atoi(e));
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
   switch (pl.mt) {
