@@ -295,7 +295,8 @@ static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
 }
 
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
-  if (a.M <= 0 || a.M > 512 || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
+  // few rows, or few output columns (the rank-32 LoRA projections of the training step: A streams once)
+  if (a.M <= 0 || (a.M > 512 && a.N > 64) || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
   if (a.ln_stats || a.ln_stats_out) return false;
   if (a.epi == SF_EPI_RESID_F32 && a.out_hi) return false;         // LayerNorm-fold producer: panel kernel only
   if (split && (!a.a_lo || !a.w_lo)) return false;
