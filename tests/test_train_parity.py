@@ -401,3 +401,24 @@ def test_trainer_rejects_what_it_cannot_do():
     assert abs(float(out["task_heads.retrieval.logit_scale"]) - math.log(10.0)) < 1e-6
     for k in ("embeddings.position_embeddings", "encoder.layer.1.output.dense.weight"):
         assert torch.equal(out[k].cpu(), sd[k].float())
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """End-to-end sanity of forward + backward + AdamW + weight refresh: 40 optimizer steps on one fixed batch
+    drive both task losses down (the oracle does the same in tests of its own trajectory, fixture F8)."""
+    from oracle import train_oracle as TO
+    cfg = small_cfg(add_lora_spatial=True)
+    tr, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True, lr=2e-3, wd=0.0)
+    dev = tr.device
+    sched = TO.schedule(cfg, B=4)
+    batches = [(sched[0][0], sched[0][1].to(dev), _to_dev(sched[0][2], dev)), (sched[1][0], sched[1][1].to(dev), _to_dev(sched[1][2], dev))]
+    first, last = {}, {}
+    for it in range(40):
+        task, x, ti = batches[it % 2]
+        loss = float(tr.micro_step(task, x, ti))
+        assert math.isfinite(loss)
+        first.setdefault(task, loss)
+        last[task] = loss
+    assert last["retrieval"] < 0.5 * first["retrieval"], (first, last)
+    assert last["localization"] < 0.7 * first["localization"], (first, last)
+    assert float(tr.grad_norm()) == 0.0          # gradients cleared after the optimizer step
