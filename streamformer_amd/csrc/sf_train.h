@@ -58,8 +58,8 @@ hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_
 // also as a bf16 copy (the A operand of the next input-gradient GEMM);
 // d_gamma += sum_rows dy * xhat, d_beta += sum_rows dy.   partial: >= sf_ln_bwd_partial_floats(D)
 size_t sf_ln_bwd_partial_floats(int D);
-hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* g_out,
-                            bf16_t* g_out_bf, float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
+hipError_t sf_launch_ln_bwd(const float* x, const void* dy /* fp32 or bf16 [rows, D] */, int dy_is_bf16, const float* gamma,
+                            const float* g_in, float* g_out, bf16_t* g_out_bf, float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
                             hipStream_t s);
 // out[c] += alpha * sum_r x[r, c]   (bias gradients); partial >= sf_colsum_partial_floats(cols)
 size_t sf_colsum_partial_floats(int cols);

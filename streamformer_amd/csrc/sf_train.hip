@@ -378,6 +378,7 @@ struct TWs {
   bf16_t *xn, *kv, *pc, *hn, *hm_pre, *hm;
   float* attn_out;
   // backward scratch
+  bf16_t* d_ln_bf;
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
   bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
   float *gh, *d_hn, *d_pc, *dq_frames, *dq_total;
@@ -410,6 +411,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   w.hm_pre = c.take<bf16_t>(F * I); w.hm = c.take<bf16_t>(F * I);
   // scratch
   w.g = c.take<float>(M * D); w.d_ln = c.take<float>(M * D);
+  w.d_ln_bf = reinterpret_cast<bf16_t*>(w.d_ln);          // per-layer LayerNorm input gradients travel as bf16
   w.g_bf = c.take<bf16_t>(M * D);
   w.d_wide = c.take<bf16_t>(M * max_sz(I, 3 * D));
   w.d_ctx = c.take<bf16_t>(M * D); w.d_tout = c.take<bf16_t>(M * D);
@@ -644,7 +646,7 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   HIP_TRY(sf_launch_gelu_bwd(ws.d_hm, ws.hm_pre, (size_t)F * I, s));
   HIP_TRY(lin_dgrad(t->fc1, ws.d_hm, F, s, ws.d_hn, nullptr));
   HIP_TRY(lin_wgrad(c, t->fc1, ws.d_hm, ws.hn, F));
-  HIP_TRY(sf_launch_ln_bwd(ws.attn_out, ws.d_hn, PP(t, P0, t->hln_g), d_pooler, ws.gh, ws.gh_bf, GG(t, c.grads, t->hln_g), GG(t, c.grads, t->hln_b),
+  HIP_TRY(sf_launch_ln_bwd(ws.attn_out, ws.d_hn, 0, PP(t, P0, t->hln_g), d_pooler, ws.gh, ws.gh_bf, GG(t, c.grads, t->hln_g), GG(t, c.grads, t->hln_b),
                            ws.ln_partial, F, D, eps, s));
   // attn_out = out_proj(ctx)   (gh_bf = bf16(gh) written by the LayerNorm backward)
   HIP_TRY(lin_dgrad(t->head_out, ws.gh_bf, F, s, ws.d_pc, nullptr));
@@ -659,7 +661,7 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   HIP_TRY(lin_dgrad(t->head_kv, d_kv, M, s, ws.d_ln, nullptr));
   if (d_lhs) HIP_TRY(sf_launch_sum_rows(d_lhs, ws.d_ln, M, M, 1, 0, 1, 0, D, 1, s));
   // post_layernorm: g = dLN(h_L)
-  HIP_TRY(sf_launch_ln_bwd(ws.h[t->L], ws.d_ln, PP(t, P0, t->post_g), nullptr, ws.g, ws.g_bf, GG(t, c.grads, t->post_g), GG(t, c.grads, t->post_b),
+  HIP_TRY(sf_launch_ln_bwd(ws.h[t->L], ws.d_ln, 0, PP(t, P0, t->post_g), nullptr, ws.g, ws.g_bf, GG(t, c.grads, t->post_g), GG(t, c.grads, t->post_b),
                            ws.ln_partial, M, D, eps, s));
   return SF_OK;
 }
@@ -679,9 +681,9 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
   HIP_TRY(lin_dgrad_dgelu(l.down, ws.g_bf, M, s, ws.d_wide, sv.pre));            // d pre = (g W_down) * gelu'(pre)  [M,I]
   HIP_TRY(lin_wgrad(c, l.down, ws.g_bf, sv.act, M));
-  HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, ws.d_ln, nullptr));
+  HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
   HIP_TRY(lin_wgrad(c, l.up, ws.d_wide, sv.ln_a, M));
-  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
+  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln_bf, 1, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- spatial: h2 = h1 + out(attn(qkv(LN_b(h1)))) ---------------------------------------------------------
   HIP_TRY(lin_dgrad(l.s_out, ws.g_bf, M, s, nullptr, ws.d_ctx));
@@ -694,8 +696,8 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     HIP_TRY(sf_launch_spatial_attention_bwd(a, s));
   }
   HIP_TRY(lin_wgrad(c, l.s_qkv, ws.d_wide, sv.ln_b, M));
-  HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide, M, s, ws.d_ln, nullptr));
-  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
+  HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
+  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln_bf, 1, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- temporal: h1 = h + tanh(gate) * dense(out(attn(qkv(LN_t(h))))) ----------------------------------------
   HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
@@ -722,8 +724,8 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     HIP_TRY(sf_launch_temporal_attention_bwd(a, s));
   }
   HIP_TRY(lin_wgrad(c, l.t_qkv, ws.d_wide, sv.ln_t, M));
-  HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide, M, s, ws.d_ln, nullptr));
-  HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
+  HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
+  HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln_bf, 1, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
                            ws.ln_partial, M, D, eps, s));
   return SF_OK;
 }
@@ -827,7 +829,7 @@ extern "C" int sf_op_layernorm_bwd(const float* x, const float* dy, const float*
   if (!x || !dy || !gamma || !dx) return sf_set_err(SF_ERR_INVALID, "null argument");
   float* partial = nullptr;
   HIP_TRY(hipMalloc(&partial, sf_ln_bwd_partial_floats(D) * sizeof(float)));
-  hipError_t e = sf_launch_ln_bwd(x, dy, gamma, g_in, dx, nullptr, d_gamma, d_beta, partial, rows, D, eps, (hipStream_t)stream);
+  hipError_t e = sf_launch_ln_bwd(x, dy, 0, gamma, g_in, dx, nullptr, d_gamma, d_beta, partial, rows, D, eps, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(partial);
   if (e != hipSuccess) return sf_set_err(SF_ERR_HIP, "sf_op_layernorm_bwd: %s", hipGetErrorString(e));

@@ -75,8 +75,8 @@ hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_
 // ------------------------------------------------------------------------------------------------
 #define LN_BWD_MAX_BLOCKS 512
 
-template <int MAXV>
-__global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int MAXV, bool DYB>
+__global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy,
                                                         const float* __restrict__ gamma, const float* g_in,
                                                         float* g_out, bf16_t* __restrict__ g_out_bf,
                                                         float* __restrict__ partial, int rows, int D, float eps) {
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
   const float inv_d = 1.0f / (float)D;
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D);
-    const f32x4_t* dr = reinterpret_cast<const f32x4_t*>(dy + (size_t)row * D);
+    const f32x4_t* dr = reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(dy) + (size_t)row * D);
+    const u32x2_t* db = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(dy) + (size_t)row * D);
     f32x4_t v[MAXV], d[MAXV];
     float s = 0.f;
 #pragma unroll
@@ -101,7 +102,12 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
       const int c = i * 64 + lane;
       if (c < nv) {
         v[i] = xr[c];
-        d[i] = dr[c];
+        if (DYB) {
+          const u32x2_t t = db[c];
+          d[i] = (f32x4_t){bf2f(t[0] & 0xffffu), bf2f(t[0] >> 16), bf2f(t[1] & 0xffffu), bf2f(t[1] >> 16)};
+        } else {
+          d[i] = dr[c];
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
       } else {
         v[i] = d[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(1024) void sf_ln_bwd_finish_kernel(const float* __r
 
 size_t sf_ln_bwd_partial_floats(int D) { return (size_t)LN_BWD_MAX_BLOCKS * 2 * D; }
 
-hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma, const float* g_in, float* g_out,
+hipError_t sf_launch_ln_bwd(const float* x, const void* dy, int dy_is_bf16, const float* gamma, const float* g_in, float* g_out,
                             bf16_t* g_out_bf, float* d_gamma, float* d_beta, float* partial, int rows, int D, float eps,
                             hipStream_t s) {
   if (rows <= 0) return hipSuccess;
@@ -219,7 +225,11 @@ hipError_t sf_launch_ln_bwd(const float* x, const float* dy, const float* gamma,
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   const size_t lds = (size_t)3 * 2 * D * sizeof(float);
   const int nv = (D / 4 + 63) / 64;
-#define SF_LNB(MV) hipLaunchKernelGGL(sf_ln_bwd_kernel<MV>, dim3(blocks), dim3(256), lds, s, x, dy, gamma, g_in, g_out, g_out_bf, partial, rows, D, eps)
+#define SF_LNB(MV)                                                                                                                     \
+  do {                                                                                                                               \
+    if (dy_is_bf16) hipLaunchKernelGGL((sf_ln_bwd_kernel<MV, true>), dim3(blocks), dim3(256), lds, s, x, dy, gamma, g_in, g_out, g_out_bf, partial, rows, D, eps); \
+    else hipLaunchKernelGGL((sf_ln_bwd_kernel<MV, false>), dim3(blocks), dim3(256), lds, s, x, dy, gamma, g_in, g_out, g_out_bf, partial, rows, D, eps);           \
+  } while (0)
   if (nv <= 1) SF_LNB(1);
   else if (nv <= 3) SF_LNB(3);
   else SF_LNB(8);
