@@ -17,6 +17,8 @@ Extra objects on that line:
   accurate_mode frames/s of the fp32-accurate (bf16x3) mode on the same workload
   cpu_baseline  the CPU oracle (a restatement pinned against the reference, kind "port") timed on the
                 host cores on a bounded sample: B=1 clips of the same shape
+  h2d_inclusive frames/s with the host -> device copy of the batch inside every step (pinned memory), for fp32 frames
+                and for raw uint8 frames (normalisation fused into the patch kernel); never the headline `value`
   streaming     BASELINE configs[4]: per-frame latency (p50 / p99) of the KV-cached streaming path, 64-frame online
                 clip at B = 1, and the achieved HBM rate against the algorithmic bytes of a frame
   train_step    BASELINE configs[2]: frames/s of one multitask pre-training step (forward + loss + backward +
@@ -389,6 +391,30 @@ def main():
                                    "cpu": cpu_model, "best": round(T / ts[0], 2)}
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         if world == 1 and not args.profile:
+            # host -> device copy inside the step ("report H2D-inclusive number separately"): the batch
+            # comes from pinned host memory every step, as normalised fp32 frames and as raw uint8 frames (the patch
+            # kernel fuses the image processor's rescale + normalize); same model, same K steps, no overlap tricks
+            try:
+                mh = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
+                mh.load_state_dict(sd)
+                mh.to(dev).eval()
+                h2d = {}
+                for name, host in (("fp32_frames", x.cpu().pin_memory()),
+                                   ("uint8_frames", ((x.cpu().clamp(-1, 1) * 127.5 + 127.5).round().to(torch.uint8)).pin_memory())):
+                    for _ in range(3):
+                        mh(host.to(dev, non_blocking=True))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        mh(host.to(dev, non_blocking=True))
+                    torch.cuda.synchronize()
+                    dth = time.perf_counter() - t0
+                    h2d[name] = {"value": round(B * T * args.steps / dth, 1), "ms_per_step": round(1e3 * dth / args.steps, 3),
+                                 "MB_per_step": round(host.numel() * host.element_size() / 1e6, 1)}
+                out["h2d_inclusive"] = h2d
+                del mh
+            except Exception as e:
+                out["h2d_inclusive"] = {"error": repr(e)}
             # BASELINE configs[4]: 64-frame online clip, one frame per call through the KV-cache (B = 1)
             try:
                 out["streaming"] = streaming_bench(dev)
