@@ -390,6 +390,14 @@ def main():
                                              f"(median {med:.3f}s, best {ts[0]:.3f}s), fp32 eager torch {torch.__version__}",
                                    "cpu": cpu_model, "best": round(T / ts[0], 2)}
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            try:        # scaling context: the same forward on ONE host thread, one timed call
+                torch.set_num_threads(1)
+                t0 = time.perf_counter()
+                O.forward(sd, cfg, x1)
+                t1 = time.perf_counter() - t0
+                out["cpu_baseline"]["one_thread"] = {"value": round(T / t1, 2), "unit": "frames/s", "sample": "1 forward of one clip"}
+            finally:
+                torch.set_num_threads(cores)
         if world == 1 and not args.profile:
             # host -> device copy inside the step ("report H2D-inclusive number separately"): the batch
             # comes from pinned host memory every step, as normalised fp32 frames and as raw uint8 frames (the patch
