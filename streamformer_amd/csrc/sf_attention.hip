@@ -144,11 +144,14 @@ SF_DEVICE void store_ctx(bf16_t* ctx_hi, bf16_t* ctx_lo, size_t off, const f32x4
 #define SP_QT 2     // query tiles per wave: 16 * SP_WAVES * SP_QT = 256 >= 224 queries
 
 template <bool ACC, int MAXNT2>
-__global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnArgs p, int vpitch) {
+__global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnArgs p, int vpitch, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int frame = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+  // qsplit = 2 (few frames in flight, e.g. the per-frame streaming step): two workgroups per (frame, head), each
+  // stages K / V^T and takes one of the two query-tile rounds, so twice as many CUs share the work
+  const int fhq = blockIdx.x / qsplit, qs = blockIdx.x % qsplit;
+  const int frame = fhq / p.heads, h = fhq % p.heads;
   const int N = p.N;
   const int nkp = (N + 31) & ~31;
   const int nt2 = nkp >> 5;
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
   bf16x8_t qh[SP_QT][2], ql[SP_QT][2];
 #pragma unroll
   for (int u = 0; u < SP_QT; ++u) {
+    if (qsplit > 1 && u != qs) continue;
     int qi = (wave + u * SP_WAVES) * 16 + l15;
     qi = qi < N ? qi : N - 1;
 #pragma unroll
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
 
 #pragma unroll
   for (int u = 0; u < SP_QT; ++u) {
+    if (qsplit > 1 && u != qs) continue;
     const int qt = wave + u * SP_WAVES;
     if (qt >= nqt) break;
 
@@ -518,15 +523,16 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   }
   const int vp = (2 * nkp + 255) & ~255;          // V^T row pitch: whole groups of 16 chunks (vswz is 4-bit)
   const size_t lds = (size_t)(nkp * 128 + HD * vp + SP_WAVES * 2048) * (accurate ? 2 : 1);
-  const dim3 grid(a.frames * a.heads), block(SP_WAVES * 64);
+  const int qsplit = (a.frames * a.heads <= 128 && a.N > 128 && !a.probs) ? 2 : 1;
+  const dim3 grid(a.frames * a.heads * qsplit), block(SP_WAVES * 64);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  if (accurate) hipLaunchKernelGGL((sf_spatial_attn_kernel<true, 7>), grid, block, lds, s, a, vp);
-  else hipLaunchKernelGGL((sf_spatial_attn_kernel<false, 7>), grid, block, lds, s, a, vp);
+  if (accurate) hipLaunchKernelGGL((sf_spatial_attn_kernel<true, 7>), grid, block, lds, s, a, vp, qsplit);
+  else hipLaunchKernelGGL((sf_spatial_attn_kernel<false, 7>), grid, block, lds, s, a, vp, qsplit);
   return hipGetLastError();
 }
 
