@@ -422,3 +422,30 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     assert last["retrieval"] < 0.5 * first["retrieval"], (first, last)
     assert last["localization"] < 0.7 * first["localization"], (first, last)
     assert float(tr.grad_norm()) == 0.0          # gradients cleared after the optimizer step
+
+
+def test_grad_norm_and_clipping_follow_torch():
+    """grad_norm() == torch's global L2 norm over the trainable gradients; clip_grad scales the AdamW input exactly
+    like torch.nn.utils.clip_grad_norm_ (coefficient max_norm / (norm + 1e-6), only when norm > max_norm)."""
+    from oracle import train_oracle as TO
+    cfg = small_cfg(add_lora_spatial=True)
+    task, x, ti, _ = TO.schedule(cfg)[0]
+    results = []
+    for clip in (None, 0.05):
+        tr, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True, lr=1e-3, wd=0.0)
+        dev = tr.device
+        _, pooler = tr.forward(x.to(dev))
+        _, gp, gs = tr.loss_and_grad(task, pooler, _to_dev(ti, dev))
+        tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+        tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+        tr.backward(gp)
+        g = tr.grads.clone()
+        norm = float(tr.grad_norm())
+        assert abs(norm - float(g.double().norm())) < 1e-4 * norm and norm > 0.05
+        p0, m0 = tr.params[: tr.n_train].clone(), None
+        tr.optimizer_step(clip_grad=clip)
+        # first Adam step from zero moments: exp_avg = (1 - beta1) * coef * g
+        coef = 1.0 if clip is None else min(1.0, clip / (norm + 1e-6))
+        assert rel_max(tr.exp_avg, 0.1 * coef * g) < 1e-5
+        results.append((p0 - tr.params[: tr.n_train]).abs().max().item())
+    assert results[0] > 0 and results[1] > 0
