@@ -59,6 +59,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    # the C++ host example of the C ABI (no Python / torch in that process); tests/test_c_host.py runs it on a GPU
+    ex_src = os.path.join(os.path.dirname(HERE), "examples", "host_forward.cpp")
+    ex_bin = os.path.join(os.path.dirname(HERE), "examples", "host_forward")
+    if os.path.exists(ex_src) and (force or _stale(ex_bin, [ex_src, LIB] + headers)):
+        cmd = [hipcc, "--offload-arch=gfx950", "-O2", ex_src, "-I" + os.path.join(os.path.dirname(HERE), "include"), "-L" + HERE,
+               "-lstreamformer_hip", "-Wl,-rpath,$ORIGIN/../streamformer_amd", "-o", ex_bin]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB
 
 

@@ -71,3 +71,26 @@ def load_training_checkpoint(path: str) -> "OrderedDict[str, torch.Tensor]":
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
     return normalize_checkpoint_keys(sd)
+
+
+def dump_for_c_host(config, state_dict: Dict[str, torch.Tensor], path: str) -> None:
+    """Write the weight file ``examples/host_forward.cpp`` reads (config ints, eps, then name / shape / fp32 data per
+    tensor): the hand-off format for a host that binds the C ABI without Python."""
+    import struct
+    acts = {"gelu": 0, "gelu_new": 1, "gelu_pytorch_tanh": 1, "relu": 2}
+    c = config
+    with open(path, "wb") as f:
+        f.write(struct.pack("<12i", c.image_size, c.patch_size, c.num_channels, c.num_frames, c.hidden_size, c.num_hidden_layers,
+                            c.num_attention_heads, c.intermediate_size, acts[c.hidden_act], int(c.qkv_bias),
+                            int(c.enable_causal_temporal), int(c.add_lora_spatial)))
+        f.write(struct.pack("<f", float(c.layer_norm_eps)))
+        items = [(k, v) for k, v in state_dict.items() if not k.endswith(".mask")]
+        f.write(struct.pack("<i", len(items)))
+        for k, v in items:
+            t = v.detach().to(torch.float32).contiguous().cpu()
+            name = k.encode()
+            f.write(struct.pack("<i", len(name)))
+            f.write(name)
+            f.write(struct.pack("<i", t.dim()))
+            f.write(struct.pack(f"<{t.dim()}q", *t.shape) if t.dim() else b"")
+            f.write(t.numpy().tobytes())
