@@ -121,7 +121,8 @@ struct SfGemmArgs {
   int epi;
   int act;                                  // SF_EPI_ACT_BF16: 0 erf-gelu, 1 tanh-gelu, 2 relu
   float alpha;                              // SF_EPI_RESID_F32
-  const float* resid;                       // [M,N] fp32
+  const float* resid;                       // [M,N] fp32 ([resid_mod,N] when resid_mod > 0: row m reads resid[m % resid_mod],
+  int resid_mod;                            //  the position + time embedding table of the patch-embedding GEMM; panel kernel)
   const float* pos; const float* time_rows; // SF_EPI_EMBED_F32: [Np,N], [Tn,N]
   int Np, Tn;
   float* out_f32;                           // [*,ldc]
@@ -167,6 +168,8 @@ hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi
 hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
 hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s);
+// out[t*N + n, :] = pos[n, :] + time_rows[t, :]   (the additive table of the embeddings, modeling:413-457)
+hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, float* out, int T, int N, int D, hipStream_t s);
 // gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)
 struct SfRowIndex { int n; int idx[256]; };
 hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s);

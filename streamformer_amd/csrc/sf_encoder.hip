@@ -443,6 +443,8 @@ struct Carver {
 
 struct Workspace {
   float* resid; float* te_rows; float* ln_stats;
+  float* embed_tab; bf16_t* patch_buf;  // pos + time table [T*N, D]; patch matrix [M, Kp] when the embedding GEMM runs on the
+                                        // panel kernel (its bf16 output goes to xn_hi, so the A operand needs its own buffer)
   bf16_t *xn_hi, *xn_lo, *ctx_hi, *ctx_lo, *tmp_hi, *tmp_lo, *mid_hi, *mid_lo;
   void* qkv;          // spatial qkv / head kv; fast: bf16 [M,3D], accurate: fp32 [M,3D]
   void* tqkv;         // temporal qkv of the current layer when no cache is used
@@ -461,6 +463,8 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.resid = c.take<float>(M * D);
   w.te_rows = c.take<float>((size_t)T * D);
   w.ln_stats = c.take<float>(M * 4);
+  w.embed_tab = (!acc && M >= 2048) ? c.take<float>((size_t)T * N * D) : nullptr;
+  w.patch_buf = (!acc && M >= 2048) ? c.take<bf16_t>(M * (size_t)e->Kp) : nullptr;
   w.xn_hi = c.take<bf16_t>(M * wide);
   w.xn_lo = acc ? c.take<bf16_t>(M * wide) : nullptr;
   w.ctx_hi = c.take<bf16_t>(M * D);
@@ -570,24 +574,41 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const size_t esz = acc ? 4 : 2;
   const float scale = 1.0f / sqrtf(64.0f);
 
+  bool embed_emitted_stats = false;
   if (stages & 1) {
   SfRowIndex idx;
   int rc = time_rows(e, t_past, T, streaming, &idx);
   if (rc) return rc;
   HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s));
-  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), ws.xn_hi, ws.xn_lo, F, c.num_channels, H, W, P, s,
+  // LN folding (decided here because the folded path lets the embedding GEMM emit bf16(x) + row statistics itself:
+  // panel kernel, out = table[m % (T N)] + patches W^T + b with table = pos + time rows)
+  bool embed_panel = false;
+  if (ln_fold_ok(e, M) && !streaming && (stages & 2) && ws.embed_tab && ws.patch_buf && e->Kp % 32 == 0 && e->Kp >= 128 && D == 768 &&
+      !getenv("SF_EMBED_VIA_GEMM128"))
+    embed_panel = true;
+  bf16_t* patches = embed_panel ? ws.patch_buf : ws.xn_hi;
+  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), patches, ws.xn_lo, F, c.num_channels, H, W, P, s,
                              &e->pixel_norm));
   {
     SfGemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.a_hi = ws.xn_hi; g.a_lo = acc ? ws.xn_lo : nullptr;
+    g.a_hi = patches; g.a_lo = acc ? ws.xn_lo : nullptr;
     g.w_hi = e->patch.w_hi; g.w_lo = acc ? e->patch.w_lo : nullptr;
     g.bias = e->patch.bias;
     g.M = M; g.N = D; g.K = e->Kp;
-    g.epi = SF_EPI_EMBED_F32;
-    g.pos = pos_dev ? pos_dev : e->pos; g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
     g.out_f32 = ws.resid; g.ldc = D;
-    HIP_TRY(sf_launch_gemm(g, acc, s));
+    SfGemmArgs gp = g;
+    gp.epi = SF_EPI_RESID_F32; gp.alpha = 1.f; gp.resid = ws.embed_tab; gp.resid_mod = T * N;
+    gp.out_hi = ws.xn_hi; gp.ln_stats_out = ws.ln_stats;
+    if (embed_panel && sf_gemm_panel_supported(gp, false)) {
+      HIP_TRY(sf_launch_pos_time_table(pos_dev ? pos_dev : e->pos, ws.te_rows, ws.embed_tab, T, N, D, s));
+      HIP_TRY(sf_launch_gemm_panel(gp, s));
+      embed_emitted_stats = true;
+    } else {
+      g.epi = SF_EPI_EMBED_F32;
+      g.pos = pos_dev ? pos_dev : e->pos; g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
+      HIP_TRY(sf_launch_gemm(g, acc, s));
+    }
   }
   }
   const size_t hs_stride = (size_t)M * D;
@@ -596,7 +617,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const bool fold = ln_fold_ok(e, M) && !streaming;
   bf16_t* fold_hi = fold ? ws.xn_hi : nullptr;
   float* fold_st = fold ? ws.ln_stats : nullptr;
-  if (fold && (stages & 2)) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
+  if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
   for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];
     if (hidden_states)

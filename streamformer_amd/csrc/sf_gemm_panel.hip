@@ -157,7 +157,8 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     for (int j = 0; j < kRows; ++j) {
       const int m = m0 + grp * 64 + wave + 8 * j;
       const bool ok = j < rows_w && m < m_end && p.resid != nullptr;     // no residual: plain F32 / BF16 output
-      const float* rp = p.resid + (size_t)m * (size_t)p.ldc + n0;
+      const int mr = p.resid_mod > 0 ? m % p.resid_mod : m;          // embedding table: one row per (frame slot, patch)
+      const float* rp = p.resid + (size_t)mr * (size_t)p.ldc + n0;
       res[j][0] = ok ? *reinterpret_cast<const f32x4_t*>(rp + elane * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       res[j][1] = (ok && elane < 32) ? *reinterpret_cast<const f32x4_t*>(rp + 256 + elane * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }

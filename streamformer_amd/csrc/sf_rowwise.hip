@@ -214,3 +214,25 @@ hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowInde
   hipLaunchKernelGGL(sf_gather_rows_kernel, dim3(idx.n), dim3(256), 0, s, table, out, idx, D);
   return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// position + time embedding table: out[(t, n), :] = pos[n, :] + time_rows[t, :]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_pos_time_table_kernel(const float* __restrict__ pos, const float* __restrict__ te,
+                                                                float* __restrict__ out, int T, int N, int D4) {
+  const size_t total = (size_t)T * N * D4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % D4);
+    const size_t row = i / D4;
+    const int n = (int)(row % N), t = (int)(row / N);
+    reinterpret_cast<f32x4_t*>(out)[i] = reinterpret_cast<const f32x4_t*>(pos)[(size_t)n * D4 + c] + reinterpret_cast<const f32x4_t*>(te)[(size_t)t * D4 + c];
+  }
+}
+hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, float* out, int T, int N, int D, hipStream_t s) {
+  if (D % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)T * N * (D / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sf_pos_time_table_kernel, dim3(blocks), dim3(256), 0, s, pos, time_rows, out, T, N, D / 4);
+  return hipGetLastError();
+}
