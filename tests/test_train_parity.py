@@ -449,3 +449,41 @@ def test_grad_norm_and_clipping_follow_torch():
         assert rel_max(tr.exp_avg, 0.1 * coef * g) < 1e-5
         results.append((p0 - tr.params[: tr.n_train]).abs().max().item())
     assert results[0] > 0 and results[1] > 0
+
+
+def test_full_size_training_step_properties():
+    """BASELINE configs[2] size (SigLIP-base, LoRA recipe, 8 clips x 16 x 224^2): too big for the CPU oracle, so
+    size-independent properties: finite, bit-reproducible, and batch additivity of the mean loss — the gradient of
+    8 clips equals the average of the gradients of the two halves (different tile plans, same mathematics)."""
+    from streamformer_amd.configuration import siglip_base
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    dev = _dev()
+    cfg = siglip_base(add_lora_spatial=True)
+    sd = make_state_dict(cfg, seed=0, lora=True)
+    tr = StreamformerTrainer(cfg, sd, ["localization"], freeze_spatial=True, device=dev)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(8, 16, 3, 224, 224, generator=g).to(dev)
+    lab = torch.randn(20, 768, generator=g)
+    lab = (lab / lab.norm(dim=-1, keepdim=True)).to(dev)
+    labels = torch.randint(-1, 20, (8, 16), generator=g).to(dev)
+
+    def grads_of(sl):
+        tr.zero_grad()
+        _, pooler = tr.forward(x[sl])
+        loss, gp, gs = tr.loss_and_grad("localization", pooler, {"kind": "localization", "label_emb": lab, "labels": labels[sl]})
+        tr.grad("task_heads.localization.logit_scale").add_(gs[0])
+        tr.grad("task_heads.localization.logit_bias").add_(gs[1])
+        tr.backward(gp)
+        torch.cuda.synchronize()
+        return float(loss), tr.grads.clone()
+
+    l8, g8 = grads_of(slice(0, 8))
+    l8b, g8b = grads_of(slice(0, 8))
+    assert math.isfinite(l8) and bool(torch.isfinite(g8).all())
+    assert l8 == l8b and torch.equal(g8, g8b)
+    la, ga = grads_of(slice(0, 4))
+    lb, gb = grads_of(slice(4, 8))
+    assert abs(l8 - 0.5 * (la + lb)) < 1e-3 * abs(l8)
+    avg = 0.5 * (ga + gb)
+    assert rel_l2(g8, avg) < 2e-2 and cosine(g8, avg) > 0.9995
