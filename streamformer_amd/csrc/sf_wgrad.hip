@@ -238,17 +238,19 @@ __global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradArgs p, 
   }
 }
 
-// dbias[n1] += alpha * sum_s bias_partial[s][n1]
-__global__ __launch_bounds__(256) void sf_wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int N1, float alpha, float* dbias) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N1) return;
-  float t = 0.f;
-  for (int s = 0; s < nsplit; ++s) t += bp[(size_t)s * N1 + n];
-  dbias[n] += alpha * t;
-}
-
+// out (+)= alpha * sum_s partial[s]; the trailing workgroups of the same launch reduce the bias partials
+// (dbias[n1] += alpha * sum_s bias_partial[s][n1]) when the tile kernel produced them
 __global__ __launch_bounds__(256) void sf_wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t n12, int N2,
-                                                              float alpha, float* out, int ldo, int accumulate) {
+                                                              float alpha, float* out, int ldo, int accumulate, int main_blocks,
+                                                              const float* __restrict__ bias_partial, int N1, float* dbias) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int n = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (n >= N1) return;
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += bias_partial[(size_t)s * N1 + n];
+    dbias[n] += alpha * t;
+    return;
+  }
   const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i4 * 4 >= n12) return;
   f32x4_t t = {0.f, 0.f, 0.f, 0.f};
@@ -317,11 +319,13 @@ hipError_t sf_launch_wgrad(const SfWgradArgs& a, hipStream_t s) {
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (a.out)
-    hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3((unsigned)((n12 / 4 + 255) / 256)), dim3(256), 0, s, a.partial, pl.nsplit, n12, a.N2,
-                       a.alpha, a.out, a.ldo, a.accumulate);
-  if (bias_done)
-    hipLaunchKernelGGL(sf_wgrad_bias_reduce_kernel, dim3((a.N1 + 255) / 256), dim3(256), 0, s, bias_partial, pl.nsplit, a.N1, a.alpha, a.dbias);
+  {
+    const int main_blocks = a.out ? (int)((n12 / 4 + 255) / 256) : 0;
+    const int bias_blocks = bias_done ? (a.N1 + 255) / 256 : 0;
+    if (main_blocks + bias_blocks > 0)
+      hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3((unsigned)(main_blocks + bias_blocks)), dim3(256), 0, s, a.partial, pl.nsplit, n12, a.N2,
+                         a.alpha, a.out, a.ldo, a.accumulate, main_blocks, bias_partial, a.N1, a.dbias);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.dbias && !bias_done)      // small-tile path: separate column-sum kernel (scratch after the tile partials)
