@@ -83,7 +83,8 @@ SF_DEVICE void pack_p(const f32x4_t& a, const f32x4_t& b, bf16x8_t& hi, bf16x8_t
 // a key takes part.  The scale (> 0) is folded into the exponent: p = 2^((s - max s) * scale * log2 e),
 // one FMA + v_exp_f32 per element; tiles known to be fully valid skip the mask.  Returns sum(p).
 template <bool ACC, int MAXNT2, typename Valid>
-SF_DEVICE float softmax_tiles(f32x4_t (&s)[MAXNT2][2], int nt2, int g, float scale, int first_masked_tile, Valid valid) {
+SF_DEVICE float softmax_tiles(f32x4_t (&s)[MAXNT2][2], int nt2, int g, float scale, int first_masked_tile, Valid valid,
+                              float* max2_out = nullptr) {
   float mx = -INFINITY;
 #pragma unroll
   for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
@@ -104,6 +105,7 @@ SF_DEVICE float softmax_tiles(f32x4_t (&s)[MAXNT2][2], int nt2, int g, float sca
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   const float c = scale * 1.44269504088896340736f;
   const float mc = mx * c;
+  if (max2_out) *max2_out = mc;         // row maximum in the base-2 exponent domain
   float sum = 0.f;
 #pragma unroll
   for (int kt2 = 0; kt2 < MAXNT2; ++kt2) {
@@ -245,8 +247,13 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
       }
     }
     // ---- softmax over keys (lane: query l15; keys 32*kt2 + 8*g + 4*hh + r) ------------------------
-    const float sum = softmax_tiles<ACC, MAXNT2>(s, nt2, g, p.scale, N >> 5, [&](int, int key) { return key < N; });
+    float max2;
+    const float sum = softmax_tiles<ACC, MAXNT2>(s, nt2, g, p.scale, N >> 5, [&](int, int key) { return key < N; }, &max2);
     const float inv = 1.0f / sum;
+    if (p.lse2_out && g == 0) {
+      const int qi = qt * 16 + l15;
+      if (qi < N) p.lse2_out[((size_t)frame * p.heads + h) * N + qi] = max2 + __log2f(sum);
+    }
     if (p.probs) {          // output_attentions: the probabilities leave as fp32 rows (wave-uniform branch)
       const int qi = qt * 16 + l15;
       if (qi < N) {

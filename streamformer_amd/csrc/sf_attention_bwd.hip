@@ -352,7 +352,11 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   w.q = iq; w.k = ik; w.v = iv; w.d_o = ig; w.lse2 = lse2; w.delta = delta; w.patch = patch;
   w.L = L; w.causal = a.causal; w.scale = a.scale; w.sl2 = a.scale * LOG2E;
 
-  for (int it = wave; it < 2 * nb; it += 8) phase_a_tile<true>(w, it, nt, lane);
+  if (a.lse2) {       // statistics saved by the forward kernel: padding queries get +big so that p = 0
+    for (int i = tid; i < rows_pad; i += SB_THREADS) lse2[i] = i < L ? a.lse2[((size_t)f * a.heads + h) * L + i] : -NEG_BIG;
+  } else {
+    for (int it = wave; it < 2 * nb; it += 8) phase_a_tile<true>(w, it, nt, lane);
+  }
   __syncthreads();
 
   bf16_t* dqkv = a.d_qkv + h * 64;

@@ -195,6 +195,8 @@ struct SfAttnArgs {
   int B, Tq, Tk, Tcap, t_past, causal, Tq_cap, q_t0;
   bf16_t* ctx_hi; bf16_t* ctx_lo;     // [rows, D] output (lo only in accurate mode)
   int D;
+  float* lse2_out;                    // spatial only, optional: base-2 log-sum-exp of the scaled scores per query,
+                                      // [frames, heads, N] fp32 (kept by the training forward for the backward kernel)
   float* probs;                       // spatial only, optional: softmax probabilities [frames, heads, N, N] fp32
                                       // (output_attentions=True, modeling:703-716); N <= 224
 };

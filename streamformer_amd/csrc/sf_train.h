@@ -39,6 +39,8 @@ struct SfAttnBwdArgs {
   int nseq;                        // spatial: frames; temporal: B * N sequences
   int seq_rows;                    // temporal only: N (token row of (b, t, n) = (b*L + t)*N + n)
   int causal;
+  const float* lse2;               // spatial, optional: [nseq, heads, L] log-sum-exp (base 2) saved by the forward kernel;
+                                   // without it the backward recomputes the row statistics (phase A)
 };
 hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);    // L <= 224
 hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);   // L <= 32

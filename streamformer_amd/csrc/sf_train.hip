@@ -369,6 +369,7 @@ struct TCarver {
 struct TSavedLayer {
   float *h1, *h2;
   bf16_t *ln_t, *tqkv, *ctx_t, *t_out, *ln_b, *sqkv, *ctx_s, *ln_a, *pre, *act;
+  float* lse_s;      // spatial attention log-sum-exp [F, heads, N]
 };
 struct TWs {
   // saved by the forward
@@ -405,6 +406,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
     s.t_out = c.take<bf16_t>(M * D);
     s.ln_b = c.take<bf16_t>(M * D); s.sqkv = c.take<bf16_t>(M * 3 * D); s.ctx_s = c.take<bf16_t>(M * D);
     s.ln_a = c.take<bf16_t>(M * D); s.pre = c.take<bf16_t>(M * I); s.act = c.take<bf16_t>(M * I);
+    s.lse_s = c.take<float>(F * (size_t)t->heads * N);
   }
   w.xn = c.take<bf16_t>(M * D); w.kv = c.take<bf16_t>(M * 2 * D); w.pc = c.take<bf16_t>(F * D);
   w.attn_out = c.take<float>(F * D); w.hn = c.take<bf16_t>(F * D);
@@ -566,7 +568,7 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
       memset(&a, 0, sizeof(a));
       a.q = sv.sqkv; a.k = sv.sqkv + D; a.v = sv.sqkv + 2 * D;
       a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
-      a.N = N; a.frames = F; a.ctx_hi = sv.ctx_s; a.D = D;
+      a.N = N; a.frames = F; a.ctx_hi = sv.ctx_s; a.D = D; a.lse2_out = sv.lse_s;
       HIP_TRY(sf_launch_spatial_attention(a, false, s));
     }
     HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_RESID_F32, s, sv.h2, nullptr, sv.h1));
@@ -693,6 +695,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     memset(&a, 0, sizeof(a));
     a.qkv = sv.sqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_s; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide;
     a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = N; a.nseq = F; a.seq_rows = 1; a.causal = 0;
+    a.lse2 = sv.lse_s;
     HIP_TRY(sf_launch_spatial_attention_bwd(a, s));
   }
   HIP_TRY(lin_wgrad(c, l.s_qkv, ws.d_wide, sv.ln_b, M));
