@@ -500,3 +500,27 @@ def test_submodule_calls_compose_to_the_forward(mode, tol):
     assert maxabs(pooled, want["pooler_output"]) <= tol
     full = m(x.cuda())
     assert maxabs(full.pooler_output, pooled) <= (1e-4 if mode == "fp32" else 3e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_streaming_is_bit_reproducible_at_base_size(mode):
+    """Race screen for the small-M kernels (skinny / K-parallel GEMM, query-split spatial attention, temporal
+    attention over the cache): the same 24-frame stream twice, SigLIP-base shape, bit-identical outputs; and the
+    streamed frames agree with the full-clip forward (different kernels serve the two)."""
+    import streamformer_amd as sa
+    cfg = siglip_base(num_hidden_layers=4, num_frames=32)
+    sd = make_state_dict(cfg, seed=17)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    x = frames(17, (1, 24, 3, 224, 224)).cuda()
+    runs = []
+    for rep in range(2):
+        cache = m.new_cache(1, 32)
+        outs = [m(x[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(24)]
+        runs.append((torch.cat([o.last_hidden_state for o in outs], 1), torch.cat([o.pooler_output for o in outs], 1)))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    full = m(x)
+    tol = 2e-4 if mode == "fp32" else BF16_LHS
+    assert maxabs(runs[0][0], full.last_hidden_state) <= tol and maxabs(runs[0][1], full.pooler_output) <= tol
