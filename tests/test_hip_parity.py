@@ -524,3 +524,37 @@ def test_streaming_is_bit_reproducible_at_base_size(mode):
     full = m(x)
     tol = 2e-4 if mode == "fp32" else BF16_LHS
     assert maxabs(runs[0][0], full.last_hidden_state) <= tol and maxabs(runs[0][1], full.pooler_output) <= tol
+
+
+@pytest.mark.gpu
+def test_feature_extraction_harness():
+    """features.py against the reference's extraction loops restated on the oracle: sliding 6-frame windows with the
+    clamped tail (extract_oad_feature.py:34-35, 122-136), last-frame pooled feature per window; long-video per-frame
+    features in num_frames clips with tail padding (modeling:1551-1621)."""
+    import streamformer_amd as sa
+    from streamformer_amd.features import long_video_features, sliding_window_features, window_starts
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=19)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="fp32")
+    m.load_state_dict(sd)
+    m.to("cuda")
+    video = frames(19, (27, 3, 48, 48))                                  # 27 frames -> 4 windows, the last start == 27 (clamped)
+    got = sliding_window_features(m, video, batch_windows=3)
+    want = []
+    for s in window_starts(27):
+        q = video[27 - 6:] if s + 6 > 27 else video[s:s + 6]
+        want.append(O.forward(sd, cfg, q[None])["pooler_output"][:, -1])
+    want = torch.cat(want)
+    assert got.shape == (4, 128) and got.dtype == np.float32
+    assert maxabs(torch.from_numpy(got), want) <= ACC_TOL
+    long = frames(20, (1, 40, 3, 48, 48))                                # 40 frames: 16 + 16 + 8 (padded to 16)
+    feats = long_video_features(m, long, window_size=32)
+    ref = []
+    for i in range(0, 40, 16):
+        clip = long[:, i:i + 16]
+        n = clip.shape[1]
+        if n < 16:
+            clip = torch.cat([clip, torch.zeros(1, 16 - n, 3, 48, 48)], 1)
+        ref.append(O.forward(sd, cfg, clip)["pooler_output"][:, :n])
+    assert tuple(feats.shape) == (1, 40, 128)
+    assert maxabs(feats, torch.cat(ref, 1)) <= ACC_TOL
