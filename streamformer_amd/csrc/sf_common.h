@@ -86,7 +86,7 @@ SF_DEVICE float gelu_fast(float x) {
   poly = fmaf(poly, t, -0.142248368f);
   poly = fmaf(poly, t, 0.127414796f);
   const float h = poly * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044f);     // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
-  return x * (x >= 0.f ? 1.0f - h : h);
+  return fmaf(-ax, h, fmaxf(x, 0.f));     // x >= 0: x (1 - h);  x < 0: x h = -|x| h   (h = Phi(-|x|))
 }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x), Phi through the same A&S erf
 SF_DEVICE float gelu_grad_fast(float x) {
