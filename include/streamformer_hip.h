@@ -139,9 +139,13 @@ int sf_cache_length(const sf_cache* cache);     /* DynamicCache.get_seq_length()
 size_t sf_cache_bytes(const sf_cache* cache);
 void sf_cache_destroy(sf_cache* cache);
 int sf_stream_workspace_bytes(sf_encoder* enc, const sf_cache* cache, int T_new, size_t* out);
+/* hidden_states_dev: NULL, or fp32 [L+1, B, T_new, N, D] — the new frames' input to every layer + the last output
+ * (output_hidden_states=True together with use_cache=True: the vision tower's call form, vqa_enc:1536).
+ * A cache is tied to the weight packing it was created against: after another sf_finalize_weights on the same
+ * handle (or a new handle at a recycled address) sf_forward_stream returns SF_ERR_STATE instead of touching it. */
 int sf_forward_stream(sf_encoder* enc, sf_cache* cache, const void* pixels_dev, int pixel_dtype,
-                      int T_new, float* last_hidden_dev, float* pooler_dev, const float* pos_dev,
-                      void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+                      int T_new, float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
+                      const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 
 /* ---- single operators (each is one kernel of the path; used by the parity tests) ----------- */
 /* nn.LayerNorm(D, eps) rows (modeling:860-865,878-880,1251): x fp32 [rows,D] -> y fp32 [rows,D] */
@@ -170,15 +174,22 @@ size_t sf_op_attention_workspace_bytes(int groups, int L, int heads, int head_di
  * pooler fp32 [B,T,D]; text fp32 [Bt,D] (un-normalised); label_emb fp32 [L,D]; labels int32 [B,T]
  * (-1 = background).  pos_offset: column of `text` that is row 0's positive (rank*B when `text` is
  * the all-gathered [world*B, D] table, modeling:250-280; -1 = negatives only).
+ * logit_scale_dev / logit_bias_dev: DEVICE pointers to one fp32 each (the heads' parameters, modeling:1363-1364;
+ * in a training step they point into the flat parameter buffer, so no host round trip sits between
+ * forward and backward).  workspace_dev: caller-owned scratch of sf_loss_workspace_bytes(B, T) bytes
+ * (per-row partial sums, reduced in a fixed order: the losses are bit-reproducible).
+ * There is no limit on Bt (the text table is walked in chunks); D <= 2048, L <= 4096 (SF_ERR_CAPACITY).
  * Outputs: loss_dev fp32 [1]; grad_pooler_dev fp32 [B,T,D] or NULL;
  * grad_scalars_dev fp32 [2] = d loss / d (logit_scale, logit_bias) or NULL.                     */
+size_t sf_loss_workspace_bytes(int B, int T);
 int sf_retrieval_loss(const float* pooler_dev, const float* text_dev, int B, int T, int D, int Bt,
-                      int pos_offset, float logit_scale, float logit_bias, float* loss_dev,
-                      float* grad_pooler_dev, float* grad_scalars_dev, sf_stream stream);
+                      int pos_offset, const float* logit_scale_dev, const float* logit_bias_dev,
+                      float* loss_dev, float* grad_pooler_dev, float* grad_scalars_dev,
+                      void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 int sf_localization_loss(const float* pooler_dev, const float* label_emb_dev, const int32_t* labels_dev,
-                         int B, int T, int D, int L, float logit_scale, float logit_bias,
+                         int B, int T, int D, int L, const float* logit_scale_dev, const float* logit_bias_dev,
                          float* loss_dev, float* grad_pooler_dev, float* grad_scalars_dev,
-                         sf_stream stream);
+                         void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 
 /* ---- training step (BASELINE configs #3 / #4) ------------------------------
  * Replaces, for one micro-batch: the autograd graph of TimesformerMultiTaskingModelSigLIP.forward
@@ -227,10 +238,15 @@ int sf_trainer_backward(sf_trainer* tr, const float* d_pooler_dev, const float* 
                         float* grads_dev, int stage_first, int stage_last, void* workspace_dev,
                         size_t workspace_bytes, sf_stream stream);
 /* torch.optim.AdamW update of the trainable prefix; `step` counts from 1; grad_scale multiplies
- * the gradient first (1/world for averaging, clip coefficient, ...).                             */
-int sf_trainer_adamw_step(sf_trainer* tr, float* params_dev, const float* grads_dev, float* exp_avg_dev,
+ * the gradient first (1/world for averaging).  grad_sumsq_dev (optional, DEVICE pointer to the
+ * output of sf_trainer_grad_sumsq): torch.nn.utils.clip_grad_norm_(max_norm = clip_norm) applied
+ * inside the kernel — total_norm = sqrt(sum) * grad_scale, coefficient min(1, clip_norm / (total_norm + 1e-6)) —
+ * so clipping needs no host synchronisation.  zero_grads != 0: grads_dev is cleared by the same pass
+ * (optimizer.zero_grad(), tools/finetune_tools.py:566).                                            */
+int sf_trainer_adamw_step(sf_trainer* tr, float* params_dev, float* grads_dev, float* exp_avg_dev,
                           float* exp_avg_sq_dev, int step, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, float grad_scale, sf_stream stream);
+                          float weight_decay, float grad_scale, const float* grad_sumsq_dev, float clip_norm,
+                          int zero_grads, sf_stream stream);
 /* out_dev[0] = sum of squares of the trainable gradient prefix (for clip_grad_norm_)             */
 int sf_trainer_grad_sumsq(sf_trainer* tr, const float* grads_dev, float* out_dev, sf_stream stream);
 

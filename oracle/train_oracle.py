@@ -83,7 +83,9 @@ class OracleTrainer:
         out = O.forward_graph(self.sd, self.cfg, pixels)
         h = self.heads[task]
         if task_input["kind"] == "retrieval":
-            return O.retrieval_loss(out["pooler_output"], task_input["text"], h["logit_scale"], h["logit_bias"])
+            # other_rank_text: the other ranks' caption features, negatives only (distributed SigLipLoss, modeling:239-297)
+            return O.retrieval_loss(out["pooler_output"], task_input["text"], h["logit_scale"], h["logit_bias"],
+                                    other_rank_text=task_input.get("other_rank_text"))
         return O.localization_loss(out["pooler_output"], task_input["label_emb"], task_input["labels"],
                                    h["logit_scale"], h["logit_bias"])
 

@@ -57,14 +57,15 @@ SIGNATURES = {
     "sf_cache_bytes": (_SZ, [_P]),
     "sf_cache_destroy": (None, [_P]),
     "sf_stream_workspace_bytes": (_I, [_P, _P, _I, C.POINTER(_SZ)]),
-    "sf_forward_stream": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "sf_forward_stream": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sf_op_linear": (_I, [_P, _P, _P, _P, _F, _I, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "sf_op_linear_workspace_bytes": (_SZ, [_I, _I, _I]),
     "sf_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sf_op_attention_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "sf_retrieval_loss": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
-    "sf_localization_loss": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "sf_loss_workspace_bytes": (_SZ, [_I, _I]),
+    "sf_retrieval_loss": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sf_localization_loss": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_trainer_create": (_I, [C.POINTER(SfConfig), _I, _I, _I, C.POINTER(_P)]),
     "sf_trainer_destroy": (None, [_P]),
     "sf_trainer_num_params": (_I, [_P]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     "sf_trainer_workspace_bytes": (_I, [_P, _I, _I, C.POINTER(_SZ)]),
     "sf_trainer_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "sf_trainer_backward": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
-    "sf_trainer_adamw_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P]),
+    "sf_trainer_adamw_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P, _F, _I, _P]),
     "sf_trainer_grad_sumsq": (_I, [_P, _P, _P, _P]),
     "sf_op_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     "sf_op_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

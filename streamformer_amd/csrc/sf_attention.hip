@@ -518,10 +518,9 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
     if (a.probs) return hipErrorInvalidValue;       // probabilities are only materialised by the all-keys-in-LDS kernel
     const int qblocks = (a.N + 127) / 128;
     const size_t lds = (size_t)(SL_KC * 128 + HD * 2 * SL_KC + SP_WAVES * 2048) * (accurate ? 2 : 1);
-    static bool attr_l = false;
-    if (!attr_l) {
+    static SfPerDeviceOnce attr_l;
+    if (attr_l.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_large_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      attr_l = true;
     }
     const dim3 grid(a.frames * a.heads * qblocks), block(SP_WAVES * 64);
     if (accurate) hipLaunchKernelGGL((sf_spatial_attn_large_kernel<true>), grid, block, lds, s, a, qblocks);
@@ -532,11 +531,10 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   const size_t lds = (size_t)(nkp * 128 + HD * vp + SP_WAVES * 2048) * (accurate ? 2 : 1);
   const int qsplit = (a.frames * a.heads <= 128 && a.N > 128 && !a.probs) ? 2 : 1;
   const dim3 grid(a.frames * a.heads * qsplit), block(SP_WAVES * 64);
-  static bool attr = false;
-  if (!attr) {
+  static SfPerDeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   if (accurate) hipLaunchKernelGGL((sf_spatial_attn_kernel<true, 7>), grid, block, lds, s, a, vp, qsplit);
   else hipLaunchKernelGGL((sf_spatial_attn_kernel<false, 7>), grid, block, lds, s, a, vp, qsplit);
@@ -717,11 +715,10 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
   const dim3 grid((ntasks + waves - 1) / waves), block(waves * 64);
 #define SF_TL(ACCV, NT)                                                                              \
   do {                                                                                               \
-    static bool attr = false;                                                                        \
-    if (!attr) {                                                                                     \
+    static SfPerDeviceOnce attr;                                                                        \
+    if (attr.first()) {                                                                                     \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_kernel<ACCV, NT>),   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
-      attr = true;                                                                                   \
     }                                                                                                \
     hipLaunchKernelGGL((sf_temporal_attn_kernel<ACCV, NT>), grid, block, lds, s, a, vp, ntasks);     \
   } while (0)

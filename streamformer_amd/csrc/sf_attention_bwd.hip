@@ -380,10 +380,9 @@ hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s
   if (a.L <= 0 || a.L > SB_ROWS || a.nseq <= 0 || a.D != a.heads * 64) return hipErrorInvalidValue;
   if ((a.ld_qkv % 8) || (a.ld_o % 8)) return hipErrorInvalidValue;
   const size_t lds = 4 * SB_IMG + 2 * SB_ROWS * 4 + 8 * 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, a);
   return hipGetLastError();
@@ -460,10 +459,9 @@ hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t 
     hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<16>, grid, block, lds, s, a, nprob);
   } else {
     const size_t lds = 4 * (size_t)(5 * 32 * 128 + 2 * 32 * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static SfPerDeviceOnce attr_set;
+    if (attr_set.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
     }
     hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<32>, grid, block, lds, s, a, nprob);
   }

@@ -31,6 +31,19 @@ SF_DEVICE void split_bf(float x, unsigned int& hi, unsigned int& lo) {
   lo = f2bf(x - bf2f(hi));
 }
 
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) is a per-DEVICE setting: run the set-up once for every device a
+// process launches on, not once per process.
+struct SfPerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 SF_DEVICE float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -210,9 +223,11 @@ hipError_t sf_launch_pool_attention(const float* q, const void* kv, int kv_is_f3
 // ------------------------------------------------------------------------------------------------
 // loss heads
 // ------------------------------------------------------------------------------------------------
+// logit_scale / logit_bias: device pointers (one float each); partial: caller scratch of sf_loss_partial_bytes(rows)
+size_t sf_loss_partial_bytes(int rows);
 hipError_t sf_launch_retrieval_loss(const float* pooler, const float* text, int B, int T, int D, int Bt,
-                                    int pos_offset, float logit_scale, float logit_bias,
-                                    float* loss, float* grad_pooler, float* grad_scalars, hipStream_t s);
+                                    int pos_offset, const float* logit_scale, const float* logit_bias,
+                                    float* loss, float* grad_pooler, float* grad_scalars, float* partial, hipStream_t s);
 hipError_t sf_launch_localization_loss(const float* pooler, const float* label_emb, const int* labels,
-                                       int B, int T, int D, int L, float logit_scale, float logit_bias,
-                                       float* loss, float* grad_pooler, float* grad_scalars, hipStream_t s);
+                                       int B, int T, int D, int L, const float* logit_scale, const float* logit_bias,
+                                       float* loss, float* grad_pooler, float* grad_scalars, float* partial, hipStream_t s);

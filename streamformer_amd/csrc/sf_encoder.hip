@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 static const int kLoraRank = 32;  // modeling:1280-1281
 
 // ------------------------------------------------------------------------------------------------
@@ -85,11 +85,13 @@ struct sf_encoder {
   DevLinear head_kv, head_out, head_fc1, head_fc2;
   float* head_q = nullptr;    // [D] probe query, projected and scaled
   size_t weight_bytes = 0;
+  uint64_t generation = 0;    // process-unique id of this handle's current weight packing (bumped by every finalize)
   SfPixelNorm pixel_norm = {{1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f}, {-1.f, -1.f, -1.f, -1.f}};
 };
 
 struct sf_cache {
   sf_encoder* enc = nullptr;
+  uint64_t enc_generation = 0;   // packing of the encoder this cache was sized for (element size, device, weights)
   int B = 0, cap = 0, H = 0, W = 0, N = 0, len = 0;
   std::vector<void*> qkv;   // per layer [B, cap, N, 3D] (bf16 or fp32 by compute mode)
   size_t bytes = 0;
@@ -174,6 +176,11 @@ extern "C" int sf_create(const sf_config* cfg, int device, sf_encoder** out) {
   build_expected(e);
   *out = e;
   return SF_OK;
+}
+
+static uint64_t next_generation() {
+  static uint64_t g = 0;      // a handle is used from one thread at a time; creation from several threads is serialised by the caller
+  return ++g;
 }
 
 static void free_device(sf_encoder* e) {
@@ -422,6 +429,7 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
   TRY(upload_linear(e, H("head.mlp.fc2.weight"), Hopt("head.mlp.fc2.bias"), D, I, &e->head_fc2));
 #undef TRY
   e->finalized = true;
+  e->generation = next_generation();   // caches created against an earlier packing are refused from here on
   return SF_OK;
 }
 
@@ -801,7 +809,7 @@ extern "C" int sf_cache_create(sf_encoder* e, int B, int max_frames, int H, int 
   if (!e->finalized) return set_err(SF_ERR_STATE, "sf_finalize_weights has not run");
   HIP_TRY(hipSetDevice(e->device));
   sf_cache* c = new sf_cache();
-  c->enc = e; c->B = B; c->cap = max_frames; c->H = H; c->W = W; c->N = N;
+  c->enc = e; c->enc_generation = e->generation; c->B = B; c->cap = max_frames; c->H = H; c->W = W; c->N = N;
   const size_t per = (size_t)B * max_frames * N * 3 * e->D * (e->compute == SF_COMPUTE_BF16X3 ? 4 : 2);
   for (int i = 0; i < e->L; ++i) {
     void* p = nullptr;
@@ -831,13 +839,18 @@ extern "C" void sf_cache_destroy(sf_cache* c) {
 }
 extern "C" int sf_stream_workspace_bytes(sf_encoder* e, const sf_cache* c, int T_new, size_t* out) {
   if (!e || !c || !out || T_new <= 0) return set_err(SF_ERR_INVALID, "bad argument");
+  if (c->enc != e || c->enc_generation != e->generation) return set_err(SF_ERR_STATE, "cache does not belong to this encoder's current weight packing");
   *out = carve(e, nullptr, c->B, T_new, c->N, false).bytes;
   return SF_OK;
 }
 extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels, int pixel_dtype, int T_new,
-                                 float* last_hidden, float* pooler, const float* pos_dev, void* workspace,
+                                 float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev, void* workspace,
                                  size_t workspace_bytes, sf_stream stream) {
   if (!e || !c || c->enc != e) return set_err(SF_ERR_INVALID, "cache does not belong to this encoder");
+  // a handle address can be reused after sf_destroy, and sf_finalize_weights may have changed the compute mode (cache element
+  // size) or the device: the generation stamp tells a cache of an earlier packing from a current one
+  if (c->enc_generation != e->generation)
+    return set_err(SF_ERR_STATE, "cache was created for an earlier weight packing of this encoder (sf_finalize_weights ran since): create a new cache");
   int N;
   int rc = check_geometry(e, c->B, T_new, c->H, c->W, pos_dev, &N);
   if (rc) return rc;
@@ -847,7 +860,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     return set_err(SF_ERR_CAPACITY, "cache holds %d of %d frames; %d more do not fit", c->len, c->cap, T_new);
   Workspace ws = carve(e, workspace, c->B, T_new, N, false);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
-  rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws,
+  rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,
                    c->qkv.data(), c->cap, c->len, true, (hipStream_t)stream);
   if (rc == SF_OK) c->len += T_new;
   return rc;
@@ -948,20 +961,32 @@ extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, 
 // ------------------------------------------------------------------------------------------------
 // loss heads
 // ------------------------------------------------------------------------------------------------
+extern "C" size_t sf_loss_workspace_bytes(int B, int T) {
+  return sf_loss_partial_bytes(B > 0 && T > 0 ? B * T : 1);
+}
 extern "C" int sf_retrieval_loss(const float* pooler, const float* text, int B, int T, int D, int Bt, int pos_offset,
-                                 float logit_scale, float logit_bias, float* loss, float* grad_pooler,
-                                 float* grad_scalars, sf_stream stream) {
-  if (!pooler || !text || !loss) return set_err(SF_ERR_INVALID, "null buffer");
+                                 const float* logit_scale, const float* logit_bias, float* loss, float* grad_pooler,
+                                 float* grad_scalars, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  if (!pooler || !text || !loss || !logit_scale || !logit_bias || !workspace) return set_err(SF_ERR_INVALID, "sf_retrieval_loss: null buffer");
+  if (B <= 0 || Bt <= 0 || T <= 0 || D <= 0) return set_err(SF_ERR_INVALID, "sf_retrieval_loss: bad shape B=%d Bt=%d T=%d D=%d", B, Bt, T, D);
+  if (D > 2048) return set_err(SF_ERR_CAPACITY, "sf_retrieval_loss: feature width %d > 2048 (256 threads x 8 features)", D);
+  if (pos_offset >= 0 && pos_offset + B > Bt)
+    return set_err(SF_ERR_INVALID, "sf_retrieval_loss: positives %d..%d fall outside the %d text rows", pos_offset, pos_offset + B - 1, Bt);
+  if (workspace_bytes < sf_loss_partial_bytes(B)) return set_err(SF_ERR_WORKSPACE, "loss workspace %zu < %zu bytes", workspace_bytes, sf_loss_partial_bytes(B));
   HIP_TRY(sf_launch_retrieval_loss(pooler, text, B, T, D, Bt, pos_offset, logit_scale, logit_bias, loss, grad_pooler,
-                                   grad_scalars, (hipStream_t)stream));
+                                   grad_scalars, (float*)workspace, (hipStream_t)stream));
   return SF_OK;
 }
 extern "C" int sf_localization_loss(const float* pooler, const float* label_emb, const int32_t* labels, int B, int T,
-                                    int D, int L, float logit_scale, float logit_bias, float* loss, float* grad_pooler,
-                                    float* grad_scalars, sf_stream stream) {
-  if (!pooler || !label_emb || !labels || !loss) return set_err(SF_ERR_INVALID, "null buffer");
+                                    int D, int L, const float* logit_scale, const float* logit_bias, float* loss,
+                                    float* grad_pooler, float* grad_scalars, void* workspace, size_t workspace_bytes,
+                                    sf_stream stream) {
+  if (!pooler || !label_emb || !labels || !loss || !logit_scale || !logit_bias || !workspace) return set_err(SF_ERR_INVALID, "sf_localization_loss: null buffer");
+  if (B <= 0 || T <= 0 || D <= 0 || L <= 0) return set_err(SF_ERR_INVALID, "sf_localization_loss: bad shape B=%d T=%d D=%d L=%d", B, T, D, L);
+  if (L > 4096) return set_err(SF_ERR_CAPACITY, "sf_localization_loss: %d label classes > 4096 (one LDS row of similarities per frame)", L);
+  if (workspace_bytes < sf_loss_partial_bytes(B * T)) return set_err(SF_ERR_WORKSPACE, "loss workspace %zu < %zu bytes", workspace_bytes, sf_loss_partial_bytes(B * T));
   HIP_TRY(sf_launch_localization_loss(pooler, label_emb, labels, B, T, D, L, logit_scale, logit_bias, loss, grad_pooler,
-                                      grad_scalars, (hipStream_t)stream));
+                                      grad_scalars, (float*)workspace, (hipStream_t)stream));
   return SF_OK;
 }
 

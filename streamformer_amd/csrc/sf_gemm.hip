@@ -245,8 +245,8 @@ hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s) {
   if (split && (!a.a_lo || !a.w_lo)) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const size_t lds = 2 * (size_t)BM * 64 * 2 * 2;   // 64 KB: two stages of 32 KB in both modes
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     // > 48 KB of dynamic LDS needs the opt-in attribute once per kernel
 #define SF_ATTR(S, E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_kernel<S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(false, SF_EPI_F32) SF_ATTR(false, SF_EPI_BF16) SF_ATTR(false, SF_EPI_ACT_BF16)
@@ -254,7 +254,6 @@ hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s) {
     SF_ATTR(true, SF_EPI_F32) SF_ATTR(true, SF_EPI_BF16) SF_ATTR(true, SF_EPI_ACT_BF16)
     SF_ATTR(true, SF_EPI_RESID_F32) SF_ATTR(true, SF_EPI_EMBED_F32)
 #undef SF_ATTR
-    attr_set = true;
   }
   return split ? launch_epi<true>(a, dim3(tiles), lds, s) : launch_epi<false>(a, dim3(tiles), lds, s);
 }

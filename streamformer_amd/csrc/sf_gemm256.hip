@@ -367,13 +367,12 @@ template <int BM>
 static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / 256);
   const size_t lds = 8 * PIECE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
 #define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
     SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true) SF_ATTR(G256_EPI_BF16_AUX, false)
 #undef SF_ATTR
-    attr_set = true;
   }
   const dim3 grid(g256_grid()), block(G_THREADS);
   // stagger as wall_clock64() ticks (sf_wall_clock_ticks), only when the launch runs

@@ -258,12 +258,11 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   if (!pl.ok) return hipErrorInvalidValue;
   const int cus = panel_cus();
   const int ntiles = pl.panels * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
 #define SF_PATTR(MT) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_panel_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P_SLOT_BYTES);
     SF_PATTR(2) SF_PATTR(4) SF_PATTR(7) SF_PATTR(13)
 #undef SF_PATTR
-    attr_set = true;
   }
   // Phase stagger (see sf_gemm256.hip): three groups 3.5 us apart spread the read-heavy main loops and the
   // residual read + store bursts of the epilogues.  Box-dependent: -3.3 % on the whole forward on one MI355X,

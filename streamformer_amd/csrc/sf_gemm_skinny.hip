@@ -271,12 +271,11 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
 template <bool SPLIT, int KG>
 static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
   const size_t lds = (size_t)KG * SKG_STAGES * SK_PLANE * (SPLIT ? 2 : 1);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
 #define SKG_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<SPLIT, E, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SKG_ATTR(SF_EPI_F32) SKG_ATTR(SF_EPI_BF16) SKG_ATTR(SF_EPI_ACT_BF16) SKG_ATTR(SF_EPI_RESID_F32)
 #undef SKG_ATTR
-    attr_set = true;
   }
 #define SKG_CASE(E)                                                                                              \
   case E:                                                                                                        \
@@ -329,15 +328,14 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s)
   if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !getenv("SF_SKINNY_NO_KG"))
     return split ? skg_launch<true, 2>(a, grid, s) : skg_launch<false, 4>(a, grid, s);
   const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
 #define SK_ATTR(S, E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
     SK_ATTR(false, SF_EPI_F32) SK_ATTR(false, SF_EPI_BF16) SK_ATTR(false, SF_EPI_ACT_BF16)
     SK_ATTR(false, SF_EPI_RESID_F32) SK_ATTR(false, SF_EPI_EMBED_F32)
     SK_ATTR(true, SF_EPI_F32) SK_ATTR(true, SF_EPI_BF16) SK_ATTR(true, SF_EPI_ACT_BF16)
     SK_ATTR(true, SF_EPI_RESID_F32) SK_ATTR(true, SF_EPI_EMBED_F32)
 #undef SK_ATTR
-    attr_set = true;
   }
   return split ? sk_launch_epi<true>(a, grid, lds, s) : sk_launch_epi<false>(a, grid, lds, s);
 }

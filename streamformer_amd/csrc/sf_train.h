@@ -101,7 +101,7 @@ hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, 
 // optimizer
 // ------------------------------------------------------------------------------------------------
 struct SfAdamWArgs {
-  float* p; const float* g; float* m; float* v;   // flat fp32 [n]
+  float* p; float* g; float* m; float* v;         // flat fp32 [n]
   size_t n;
   const int* seg_end;        // device: exclusive end offset of each segment (ascending), nseg entries
   const unsigned char* seg_decay;   // device: 1 = weight decay applies
@@ -109,7 +109,11 @@ struct SfAdamWArgs {
   int nseg;
   float lr, beta1, beta2, eps, weight_decay;
   float bias_correction1, bias_correction2;   // 1 - beta^t
-  float grad_scale;                            // g is multiplied by this first (clipping / averaging)
+  float grad_scale;                            // g is multiplied by this first (averaging: 1 / world)
+  // clip_grad_norm_ without a host round trip: when clip_sumsq != nullptr the kernel reads sum g^2 of the (summed)
+  // gradient from device memory, total_norm = sqrt(sum) * grad_scale, and multiplies g by min(1, clip_norm / (total_norm + 1e-6))
+  const float* clip_sumsq; float clip_norm;
+  int zero_grads;                              // 1: g is cleared by the same pass (optimizer.zero_grad fused)
 };
 hipError_t sf_launch_adamw(const SfAdamWArgs& a, hipStream_t s);
 // out[0] = sum g^2 (deterministic two-stage); partial >= 1024 floats

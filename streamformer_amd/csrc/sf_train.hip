@@ -771,8 +771,9 @@ extern "C" int sf_trainer_backward(sf_trainer* t, const float* d_pooler, const f
 // ------------------------------------------------------------------------------------------------
 // optimizer
 // ------------------------------------------------------------------------------------------------
-extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, const float* grads, float* m, float* v, int step, float lr,
-                                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, sf_stream stream) {
+extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, float* grads, float* m, float* v, int step, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                     const float* grad_sumsq_dev, float clip_norm, int zero_grads, sf_stream stream) {
   if (!t || !params || !grads || !m || !v) return sf_set_err(SF_ERR_INVALID, "null argument");
   if (step < 1) return sf_set_err(SF_ERR_INVALID, "step counts from 1");
   HIP_TRY(hipSetDevice(t->device));
@@ -783,6 +784,8 @@ extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, const float* 
   a.bias_correction1 = 1.0f - powf(beta1, (float)step);
   a.bias_correction2 = 1.0f - powf(beta2, (float)step);
   a.grad_scale = grad_scale;
+  a.clip_sumsq = grad_sumsq_dev; a.clip_norm = clip_norm; a.zero_grads = zero_grads;
+  if (grad_sumsq_dev && !(clip_norm > 0.f)) return sf_set_err(SF_ERR_INVALID, "clip_norm must be positive");
   HIP_TRY(sf_launch_adamw(a, (hipStream_t)stream));
   return SF_OK;
 }

@@ -490,6 +490,8 @@ hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sf_adamw_kernel(SfAdamWArgs a) {
   const size_t nv = a.n >> 2;
+  float gscale = a.grad_scale;
+  if (a.clip_sumsq) gscale *= fminf(1.0f, a.clip_norm / (sqrtf(a.clip_sumsq[0]) * a.grad_scale + 1e-6f));
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
     const size_t e = i << 2;                     // segments start on multiples of 64 elements
     int lo = 0, hi = a.nseg - 1;                 // first segment with seg_end > e
@@ -501,11 +503,12 @@ __global__ __launch_bounds__(256) void sf_adamw_kernel(SfAdamWArgs a) {
     const float wd = a.seg_decay[lo] ? a.weight_decay : 0.f;
     f32x4_t p = reinterpret_cast<f32x4_t*>(a.p)[i];
     f32x4_t g = reinterpret_cast<const f32x4_t*>(a.g)[i];
+    if (a.zero_grads) reinterpret_cast<f32x4_t*>(a.g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     f32x4_t m = reinterpret_cast<f32x4_t*>(a.m)[i];
     f32x4_t v = reinterpret_cast<f32x4_t*>(a.v)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gj = g[j] * a.grad_scale;
+      const float gj = g[j] * gscale;
       p[j] *= 1.0f - a.lr * wd;
       m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
       v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;

@@ -302,11 +302,10 @@ hipError_t sf_launch_wgrad(const SfWgradArgs& a, hipStream_t s) {
   const WgPlan pl = wg_plan(a.M, a.N1, a.N2);
   const size_t n12 = (size_t)a.N1 * a.N2;
   float* bias_partial = a.partial + (size_t)pl.nsplit * n12;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_wgrad256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_TILE_BYTES);
-    attr_set = true;
   }
   bool bias_done = false;
   if (pl.big) {

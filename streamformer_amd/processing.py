@@ -19,13 +19,20 @@ import torch
 
 class TimesformerImageProcessor:
     def __init__(self, image_mean: Sequence[float] = (0.5, 0.5, 0.5), image_std: Sequence[float] = (0.5, 0.5, 0.5),
-                 size=(384, 384), rescale_factor: float = 1 / 255, resample: str = "bicubic"):
+                 size=(384, 384), crop_size=None, resample: str = "bicubic", rescale_factor: float = 1 / 255,
+                 data_format: str = "channels_first"):
+        # argument order of the reference's constructor (vqa_enc:1400-1409)
         self.image_mean = tuple(float(m) for m in image_mean)
         self.image_std = tuple(float(s) for s in image_std)
         self.size = (size, size) if isinstance(size, int) else tuple(size)       # (height, width)
         self.rescale_factor = float(rescale_factor)
         self.resample = resample
-        self.crop_size = {"height": self.size[0], "width": self.size[1]}          # attribute the LLaVA glue reads
+        self.data_format = data_format
+        if crop_size is None:                                                     # vqa_enc:1410-1415 (read by the LLaVA glue only)
+            crop_size = {"height": 384, "width": 384}
+        elif isinstance(crop_size, int):
+            crop_size = {"height": crop_size, "width": crop_size}
+        self.crop_size = dict(crop_size)
 
     # ---- host side: RGB + resize ------------------------------------------------------------------------
     def _to_uint8_hwc(self, image) -> np.ndarray:

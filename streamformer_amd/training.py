@@ -80,13 +80,22 @@ class StreamformerTrainer:
 
     def __init__(self, config: StreamformerConfig, state_dict: Dict[str, torch.Tensor], task_heads: Sequence[str],
                  freeze_spatial: bool = True, device="cuda", lr: float = 1e-3, weight_decay: float = 0.05,
-                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0):
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0,
+                 grad_reduce_dtype: str = "fp32"):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamformerTrainer needs an AMD GPU: the training step runs only on the HIP library")
         if config.hidden_act not in _ACT:
             raise NotImplementedError(f"training supports hidden_act in {sorted(_ACT)}")
         if config.attention_type != "divided_space_time":
             raise NotImplementedError("only divided_space_time is implemented")
+        stochastic = {k: float(getattr(config, k, 0.0) or 0.0) for k in ("drop_path_rate", "hidden_dropout_prob", "attention_probs_dropout_prob")}
+        if any(v > 0 for v in stochastic.values()):
+            # the reference applies these in train mode (modeling:852-856, 605, 762); the shipped recipe sets all three
+            # to 0 (scripts/pretrain_streamformer.sh), which is the only configuration this step reproduces
+            raise NotImplementedError(f"stochastic regularisation is not implemented in the HIP training step: {stochastic}")
+        if grad_reduce_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_reduce_dtype must be 'fp32' or 'bf16'")
+        self.grad_reduce_dtype = grad_reduce_dtype
         self.config = config
         self.device = torch.device(device)
         if self.device.index is None:
@@ -159,6 +168,17 @@ class StreamformerTrainer:
         return [inv.get(k, k) for k, e in self.layout.items() if e["trainable"] or not trainable_only]
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Accepts encoder keys as well as wrapper / DDP checkpoints (``timesformer.`` / ``module.`` prefixes,
+        ``task_heads.<task>.logit_scale|logit_bias`` of this trainer's heads; other head entries are ignored)."""
+        from .modeling import normalize_checkpoint_keys
+        heads = {}
+        for k, v in sd.items():
+            kk = k[len("module."):] if k.startswith("module.") else k
+            if kk in self.extra_slot:
+                heads[kk] = v
+        sd = normalize_checkpoint_keys(sd)
+        for k, v in heads.items():
+            self._view(k).copy_(v.to(torch.float32).reshape(self._entry(k)["shape"]))
         missing = []
         for k, e in self.layout.items():
             if k.startswith("extra."):
@@ -244,24 +264,37 @@ class StreamformerTrainer:
                                                       ws.data_ptr(), ws.numel(), self._stream()))
                 first = last + 1
                 if reduce and self.world > 1:
-                    works.append(torch.distributed.all_reduce(self.grads[off: off + n], group=self.group, async_op=True))
-        for w in works:
+                    sl = self.grads[off: off + n]
+                    if self.grad_reduce_dtype == "bf16":
+                        # half the bytes on the xGMI links (204 MB instead of 407 MB per step for SigLIP-base);
+                        # the sum over <= 8 ranks is taken in bf16, the optimizer state stays fp32
+                        half = sl.to(torch.bfloat16)
+                        works.append((torch.distributed.all_reduce(half, group=self.group, async_op=True), sl, half))
+                    else:
+                        works.append((torch.distributed.all_reduce(sl, group=self.group, async_op=True), None, None))
+        for w, sl, half in works:
             w.wait()
+            if half is not None:
+                sl.copy_(half)
 
     def loss_and_grad(self, task: str, pooler: torch.Tensor, task_input: dict):
-        """Task-head loss (HIP kernels of heads.py) -> (loss [1], d loss/d pooler, d loss/d (scale, bias))."""
+        """Task-head loss (HIP kernels of heads.py) -> (loss [1], d loss/d pooler, d loss/d (scale, bias)).
+
+        The heads read ``logit_scale`` / ``logit_bias`` straight from the flat parameter buffer on the device:
+        nothing here synchronises with the host, so the next micro-step can be enqueued behind this one.
+        Retrieval with world > 1 uses every rank's captions as negatives (the reference's distributed SigLipLoss,
+        modeling:239-297) unless ``task_input["gather_negatives"]`` is False."""
         from .heads import LocalizationHead, RetrievalHead
         ls, lb = self._view(f"task_heads.{task}.logit_scale"), self._view(f"task_heads.{task}.logit_bias")
-        scal = torch.stack([ls.reshape(()), lb.reshape(())]).cpu().tolist()
         if task_input["kind"] == "retrieval":
-            text = task_input["text"]
+            text = task_input["text"].to(self.device)
             rank = 0
-            if task_input.get("gather_negatives") and self.world > 1:
+            if task_input.get("gather_negatives", True) and self.world > 1:
                 from .parallel import all_gather_rows
-                text = all_gather_rows(text, group=self.group)
+                text = all_gather_rows(text.contiguous(), group=self.group)
                 rank = self.rank
-            return RetrievalHead(*scal).loss(pooler, text, rank=rank)
-        return LocalizationHead(task_input["label_emb"], *scal).loss(pooler, task_input["labels"])
+            return RetrievalHead(ls, lb).loss(pooler, text, rank=rank)
+        return LocalizationHead(task_input["label_emb"], ls, lb).loss(pooler, task_input["labels"])
 
     def micro_step(self, task: str, pixel_values: torch.Tensor, task_input: dict, update_freq: int = 1,
                    lr: Optional[float] = None, weight_decay: Optional[float] = None,
@@ -287,19 +320,21 @@ class StreamformerTrainer:
 
     def optimizer_step(self, lr: Optional[float] = None, weight_decay: Optional[float] = None,
                        clip_grad: Optional[float] = None) -> None:
-        """AdamW on the trainable prefix, then refresh the bf16 working weights and clear the gradients."""
+        """AdamW on the trainable prefix (gradient cleared by the same kernel), then refresh the bf16 working
+        weights.  ``clip_grad``: torch.nn.utils.clip_grad_norm_ semantics, coefficient computed on the device."""
         self.step_count += 1
         scale = 1.0 / self.world                                  # all-reduce summed; DDP averages
-        if clip_grad is not None:                                  # torch.nn.utils.clip_grad_norm_ semantics
-            total = float(self.grad_norm())
-            scale *= min(1.0, clip_grad / (total + 1e-6))
+        sumsq = 0
         with torch.cuda.device(self.device):
+            if clip_grad is not None:
+                nat.check(nat.lib.sf_trainer_grad_sumsq(self._h, self.grads.data_ptr(), self._scratch.data_ptr(), self._stream()))
+                sumsq = self._scratch.data_ptr()
             nat.check(nat.lib.sf_trainer_adamw_step(
                 self._h, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                 self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
-                self.weight_decay if weight_decay is None else weight_decay, scale, self._stream()))
+                self.weight_decay if weight_decay is None else weight_decay, scale, sumsq,
+                float(clip_grad) if clip_grad is not None else 0.0, 1, self._stream()))
         self.sync_weights()
-        self.grads.zero_()
 
     def zero_grad(self) -> None:
         self.grads.zero_()

@@ -27,3 +27,54 @@ def maxabs(a, b):
 def load_npz(path):
     z = np.load(path, allow_pickle=False)
     return {k: z[k] for k in z.files}
+
+
+def _rank_entry(fn, rank, world, port, args, q):
+    """Child process of run_ranks: rendezvous on 127.0.0.1, run fn(rank, world, *args), report result or traceback."""
+    import os
+    import traceback
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        q.put((rank, "ok", fn(rank, world, *args)))
+    except BaseException:
+        q.put((rank, "error", traceback.format_exc()))
+    finally:
+        q.close()
+        q.join_thread()      # flush the result before leaving
+        os._exit(0)          # no destroy_process_group: a peer that died must not leave this rank waiting in a collective
+
+
+def run_ranks(fn, world, args=(), timeout=240):
+    """Run fn(rank, world, *args) in `world` spawned processes over gloo; returns [result of rank 0, 1, ...].
+    Never hangs: results are awaited with a deadline and every child is killed afterwards; a rank's exception is
+    re-raised here with its traceback."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_entry, args=(fn, r, world, port, args, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, err = {}, None
+    try:
+        for _ in range(world):
+            rank, status, payload = q.get(timeout=timeout)
+            if status == "error":
+                err = f"rank {rank} failed:\n{payload}"
+                break
+            out[rank] = payload
+    except Exception as e:       # queue.Empty: a rank hung
+        err = f"ranks did not finish within {timeout}s ({type(e).__name__}); finished: {sorted(out)}"
+    finally:
+        for p in procs:
+            p.join(5)
+            if p.is_alive():
+                p.kill()
+    assert err is None, err
+    return [out[r] for r in range(world)]

@@ -245,18 +245,157 @@ def test_streaming_f4(sa, golden_dir, mode, tag, nf):
     assert maxabs(o.last_hidden_state, want[:, :2]) <= lt
 
 
-def test_vision_tower_window(sa):
+class _TowerCfg:
+    """stand-in for LLaVA's model config object (vqa_enc:1494-1500 reads these with getattr)"""
+    streaming_mode = True
+    context_length = 6
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", ACC_CEIL), ("bf16", BF16_LHS)])
+def test_vision_tower_streams_against_the_oracle(sa, tmp_path, mode, tol):
+    """TimesformerVisionTower (vqa_enc:1462-1598) built the reference's way — checkpoint directory + config object — fed one
+    frame per call; every returned window is compared with the ORACLE's full-clip forward (causal => identical)."""
     cfg = small_cfg(num_frames=16)
-    m = build(sa, cfg, make_state_dict(cfg, seed=1), "fp32")
-    tower = sa.TimesformerVisionTower(m, context_length=6, max_frames=16)
-    x = frames(11, (1, 10, 3, 48, 48)).cuda()
-    full = m(x).last_hidden_state
+    sd = make_state_dict(cfg, seed=1)
+    build(sa, cfg, sd, mode).save_pretrained(str(tmp_path))
+    tower = sa.TimesformerVisionTower(str(tmp_path), _TowerCfg(), delay_load=True, compute_dtype=mode)
+    assert tower.is_loaded and tower.streaming_mode and tower.context_length == 6
+    assert tower.device.type == "cuda" and tower.dtype == torch.float32
+    assert (tower.hidden_size, tower.num_patches, tower.num_patches_per_side, tower.image_size) == (128, 9, 3, 48)
+    assert tower.dummy_feature.shape == (1, 128) and tower.dummy_feature.device.type == "cuda"
+    assert all(not p.requires_grad for p in tower.parameters())                    # vqa_enc:1524
+    assert tower.image_processor.size == (48, 48)
+    x = frames(11, (1, 10, 3, 48, 48))
+    want = O.forward(sd, cfg, x)["last_hidden_state"]
     for t in range(10):
-        feats = tower(x[:, t:t + 1])
-    assert feats.shape == (1, 6, 9, 128)
-    assert maxabs(feats, full[:, 4:10]) <= 1e-4
+        feats = tower(x[:, t:t + 1].cuda())
+        lo = max(0, t + 1 - 6)
+        assert feats.shape == (1, t + 1 - lo, 9, 128)
+        assert maxabs(feats, want[:, lo:t + 1]) <= tol
+    # a new stream after clear_cache (vqa_enc:1528-1530): K/V buffers recycled, results as from scratch
+    first = tower.past_key_values
     tower.clear_cache()
-    assert tower(x[:, :3]).shape == (1, 3, 9, 128)
+    assert tower.past_key_values is None and tower.hidden_states is None
+    y = frames(12, (1, 3, 3, 48, 48))
+    got = tower(y.cuda())
+    assert tower.past_key_values is first
+    assert maxabs(got, O.forward(sd, cfg, y)["last_hidden_state"]) <= tol
+    # the non-streaming branches: a clip tensor -> last_hidden_state, a list of clips -> last encoder hidden state
+    plain = sa.TimesformerVisionTower(tower.vision_tower, streaming_mode=False)
+    ow = O.forward(sd, cfg, y, output_hidden_states=True)
+    assert maxabs(plain(y.cuda()), ow["last_hidden_state"]) <= tol
+    lst = plain([y[0].cuda()])
+    assert len(lst) == 1 and maxabs(lst[0], ow["hidden_states"][-1]) <= (tol if mode == "fp32" else 0.25)
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", ACC_CEIL), ("bf16", 0.25)])
+def test_streaming_with_output_hidden_states(sa, mode, tol):
+    """The tower's literal call form (vqa_enc:1536): output_hidden_states=True with use_cache=True and cache_position=None.
+    hidden_states of the new frames (patch-major) against the oracle's for the same frames of the full clip.
+    bf16 tolerance: un-normalised residual stream values reach ~30, the bf16 operand error scales with them."""
+    cfg = small_cfg(num_frames=16)
+    sd = make_state_dict(cfg, seed=4)
+    m = build(sa, cfg, sd, mode)
+    x = frames(5, (2, 8, 3, 48, 48))
+    want = O.forward(sd, cfg, x, output_hidden_states=True)
+    N, D = 9, 128
+    cache, pos = None, 0
+    for c in (3, 1, 3):
+        o = m(x[:, pos:pos + c].cuda(), output_hidden_states=True, use_cache=True, past_key_values=cache, cache_position=None)
+        cache = o.past_key_values
+        assert len(o.hidden_states) == cfg.num_hidden_layers + 1
+        for li, h in enumerate(o.hidden_states):
+            assert h.shape == (2, N * c, D)
+            w = want["hidden_states"][li].reshape(2, N, 8, D)[:, :, pos:pos + c].reshape(2, N * c, D)     # token = n*T + t
+            assert maxabs(h, w) <= tol, (li, pos)
+        assert maxabs(o.last_hidden_state, want["last_hidden_state"][:, pos:pos + c]) <= (ACC_CEIL if mode == "fp32" else BF16_LHS)
+        pos += c
+    tup = m(x[:, pos:pos + 1].cuda(), output_hidden_states=True, use_cache=True, past_key_values=cache, return_dict=False)
+    assert len(tup) == 3 and tup[2] is cache and len(tup[1]) == cfg.num_hidden_layers + 1
+
+
+def test_module_protocol_on_the_gpu(sa):
+    """modeling:1362 holds the encoder as `self.timesformer = TimesformerMultiTaskingModelSigLIP(config)`; vqa_enc:1574-1581 read
+    device / dtype off its parameters.  A parent module moves it, saves it and reloads it through the plain nn.Module calls."""
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=6)
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.timesformer = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="fp32")
+            self.logit_scale = torch.nn.Parameter(torch.tensor(2.3))
+
+    w = Wrapper()
+    assert next(w.timesformer.parameters()).device.type == "cpu"
+    w.load_state_dict({**{"timesformer." + k: v for k, v in sd.items()}, "logit_scale": torch.tensor(1.0)})
+    w.to("cuda").eval()
+    p = next(w.timesformer.parameters())
+    assert p.device.type == "cuda" and p.dtype == torch.float32 and w.timesformer.device.type == "cuda"
+    x = frames(3, (1, 4, 3, 48, 48))
+    want = O.forward(sd, cfg, x)
+    assert maxabs(w.timesformer(x.cuda()).last_hidden_state, want["last_hidden_state"]) <= ACC_CEIL
+    saved = w.state_dict()
+    assert set(saved) == {"logit_scale"} | {"timesformer." + k for k in sd}
+    assert all(torch.equal(saved["timesformer." + k].cpu(), v.float()) for k, v in sd.items())
+    # in-place weight change through the parameter (what an optimizer does) is picked up by the next forward
+    sd2 = make_state_dict(cfg, seed=7)
+    with torch.no_grad():
+        for k, prm in w.timesformer.named_parameters():
+            prm.copy_(sd2[k])
+    assert maxabs(w.timesformer(x.cuda()).last_hidden_state, O.forward(sd2, cfg, x)["last_hidden_state"]) <= ACC_CEIL
+    # a half-precision module (vqa_enc:1536 casts the images to tower.dtype) answers in its dtype
+    w.to(torch.bfloat16)
+    assert w.timesformer.dtype == torch.bfloat16
+    o = w.timesformer(x.cuda().bfloat16())
+    assert o.last_hidden_state.dtype == torch.bfloat16
+    sdb = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in sd2.items()}
+    wantb = O.forward(sdb, cfg, x.bfloat16().float())["last_hidden_state"]
+    assert maxabs(o.last_hidden_state.float(), wantb) <= 4e-2          # bf16 output rounding of values up to ~6
+
+
+def test_stale_cache_is_refused(sa):
+    """a cache created before the weights were re-packed must not be written with another element size."""
+    nat = sa._native
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=1)
+    m = build(sa, cfg, sd, "bf16")
+    x = frames(2, (1, 3, 3, 48, 48)).cuda()
+    o = m(x[:, :1], use_cache=True)
+    cache = o.past_key_values
+    tower = sa.TimesformerVisionTower(m, streaming_mode=True, context_length=4)
+    tower(x[:, :1])
+    m.set_compute_dtype("fp32")
+    full = m(x).last_hidden_state                          # re-packs: every live cache is invalidated
+    assert not cache.valid
+    with pytest.raises(RuntimeError, match="start a new cache"):
+        m(x[:, 1:2], use_cache=True, past_key_values=cache)
+    got = tower(x[:, :2])                                  # the tower notices and starts a fresh stream
+    assert maxabs(got, full[:, :2]) <= 1e-4
+    # the same guard inside the C ABI: re-finalising a handle under a live cache
+    c2 = m.new_cache(1, 4)
+    nat.check(nat.lib.sf_finalize_weights(m._handle, nat.SF_COMPUTE_BF16, 1, 1))
+    n = nat.C.c_size_t()
+    assert nat.lib.sf_stream_workspace_bytes(m._handle, c2._h, 1, nat.C.byref(n)) == nat.SF_ERR_STATE
+    lhs = torch.empty(1, 1, 9, 128, device="cuda")
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device="cuda")
+    rc = nat.lib.sf_forward_stream(m._handle, c2._h, x.data_ptr(), nat.SF_F32, 1, lhs.data_ptr(), None, None, None, ws.data_ptr(),
+                                   ws.numel(), nat.current_stream_handle(lhs.device))
+    assert rc == nat.SF_ERR_STATE and b"earlier weight packing" in nat.lib.sf_last_error()
+    m.refresh_weights()
+
+
+def test_forward_features_pooling_methods(sa):
+    """modeling:1525-1536: "mean" is the default, "no_pooling" returns every frame, any other string the last frame."""
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=9)
+    m = build(sa, cfg, sd, "fp32")
+    x = frames(4, (2, 5, 3, 48, 48))
+    pooled = O.forward(sd, cfg, x)["pooler_output"]
+    assert maxabs(m.forward_features(x.cuda()), pooled.mean(1)) <= ACC_CEIL
+    assert maxabs(m.forward_features(x.cuda(), pooling_method="no_pooling"), pooled) <= ACC_CEIL
+    assert maxabs(m.forward_features(x.cuda(), pooling_method="last"), pooled[:, -1]) <= ACC_CEIL
+    assert maxabs(m.forward_features(x.cuda(), "anything else"), pooled[:, -1]) <= ACC_CEIL
 
 
 # ------------------------------------------------------------------------------------------------
@@ -404,8 +543,7 @@ def test_uint8_frames_fused_normalisation(golden_dir):
     want = O.forward(sd, cfg, x_f.cpu())
     assert maxabs(a.last_hidden_state, want["last_hidden_state"]) <= ACC_TOL
     # a non-default normalisation is honoured by the kernel
-    m.image_processor.image_mean, m.image_processor.image_std = (0.4, 0.5, 0.6), (0.2, 0.25, 0.3)
-    m._dirty = True
+    m.image_processor.image_mean, m.image_processor.image_std = (0.4, 0.5, 0.6), (0.2, 0.25, 0.3)   # picked up by the next call
     c = m(x_u8)
     d = m(m.image_processor.normalize(clip)[None].cuda())
     assert maxabs(c.last_hidden_state, d.last_hidden_state) <= 1e-4

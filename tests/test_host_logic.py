@@ -87,6 +87,43 @@ def test_lora_surface():
     assert "encoder.layer.0.attention.attention.qkv_lora_a.weight" in m.trainable_parameter_names()
 
 
+def test_module_protocol_without_a_gpu():
+    """The encoder is a torch.nn.Module with the reference's parameter names: a wrapper holds it (modeling:1362), its
+    state_dict carries the prefix, dtype moves with .to(), requires_grad follows frozen_spatial / add_lora_spatial."""
+    cfg = small_cfg()
+    sd = sa.make_state_dict(cfg, seed=3)
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.timesformer = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+
+    w = Wrapper()
+    assert isinstance(w.timesformer, torch.nn.Module)
+    assert set(w.state_dict()) == {"timesformer." + k for k in sd}             # masks included, like the reference
+    w.load_state_dict({"timesformer." + k: v for k, v in sd.items()})
+    m = w.timesformer
+    assert torch.equal(m.encoder.layer[1].temporal_attention_gating.data, sd["encoder.layer.1.temporal_attention_gating"])
+    assert torch.equal(m.head.attention.out_proj.weight.data, sd["head.attention.out_proj.weight"])
+    assert len(m.encoder.layer) == cfg.num_hidden_layers and m.encoder.layer[-1] is m.encoder.layer[cfg.num_hidden_layers - 1]
+    assert next(m.parameters()).device.type == "cpu" and m.dtype == torch.float32
+    w.to(torch.bfloat16)
+    assert m.dtype == torch.bfloat16 and next(w.parameters()).dtype == torch.bfloat16
+    m.frozen_spatial()
+    assert not m.encoder.layer[0].attention.attention.qkv.weight.requires_grad
+    assert m.encoder.layer[0].attention.output.dense.weight.requires_grad
+    m.add_lora_spatial()
+    assert m.encoder.layer[0].attention.attention.qkv_lora_a.weight.dtype == torch.bfloat16        # new factors follow the module
+    assert not m.encoder.layer[0].attention.output.dense.weight.requires_grad
+    m.requires_grad_(False)
+    assert m.trainable_parameter_names() == []
+    tower = sa.TimesformerVisionTower(m, streaming_mode=True, context_length=4)
+    assert (tower.hidden_size, tower.num_patches, tower.num_patches_per_side, tower.image_size) == (128, 9, 3, 48)
+    assert tower.device.type == "cpu" and tower.dtype == torch.bfloat16 and tower.is_loaded
+    with pytest.raises(OSError, match="no hub access"):
+        sa.TimesformerVisionTower("Go2Heart/StreamFormer-timesformer-siglip")
+
+
 def test_model_output_protocol():
     o = ModelOutput(last_hidden_state=1, pooler_output=2, hidden_states=None, attentions=None)
     assert o.last_hidden_state == 1 and o["pooler_output"] == 2 and o[0] == 1 and o[1] == 2

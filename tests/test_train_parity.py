@@ -319,48 +319,119 @@ def test_base_model_gradients_match_oracle():
 # ---------------------------------------------------------------------------------------------------
 # data parallel: 2 ranks (both on cuda:0, gloo) == one rank on the concatenated batch
 # ---------------------------------------------------------------------------------------------------
-def _dp_worker(rank, world, port, ret):
-    import torch.distributed as dist
+def _gn_worker(rank, world, reduce_dtype):
+    """One rank of the retrieval micro-step with cross-rank negatives, driven through StreamformerTrainer."""
     from oracle import train_oracle as TO
     from streamformer_amd.init_weights import make_state_dict
     from streamformer_amd.training import StreamformerTrainer
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        torch.cuda.set_device(0)
-        cfg = small_cfg(add_lora_spatial=True)
-        sd = make_state_dict(cfg, seed=8, lora=True)
-        tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device="cuda:0", bucket_mb=0.05)
-        assert len(tr.buckets) > 1
-        task, x, ti, _ = TO.schedule(cfg, B=4)[1]
+    torch.cuda.set_device(0)
+    cfg = small_cfg(add_lora_spatial=True)
+    sd = make_state_dict(cfg, seed=8, lora=True)
+    tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device="cuda:0", bucket_mb=0.05,
+                             grad_reduce_dtype=reduce_dtype)
+    task, x, ti, _ = TO.schedule(cfg, B=4)[0]
+    assert task == "retrieval"
+    lo, hi = rank * 2, rank * 2 + 2
+    # default: gather_negatives on when world > 1
+    _, pooler = tr.forward(x[lo:hi].cuda())
+    loss, gp, gs = tr.loss_and_grad(task, pooler, {"kind": "retrieval", "text": ti["text"][lo:hi].cuda()})
+    tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+    tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+    tr.backward(gp, reduce=True)
+    torch.cuda.synchronize()
+    grads = (tr.grads / world).cpu()
+    # the same through micro_step (forward + loss + backward + all-reduce + clipped AdamW): the whole enqueue path;
+    # lr = 0 keeps the parameters
+    tr.zero_grad()
+    l2 = tr.micro_step(task, x[lo:hi].cuda(), {"kind": "retrieval", "text": ti["text"][lo:hi].cuda()}, lr=0.0, weight_decay=0.0,
+                       clip_grad=1.0)
+    torch.cuda.synchronize()
+    assert abs(float(l2) - float(loss)) < 1e-6
+    assert float(tr.grads.abs().max()) == 0.0          # cleared by the optimizer kernel
+    return float(loss), grads.numpy()          # by value: tensors would travel as shared-memory handles of a process that exits
+
+
+@pytest.mark.parametrize("reduce_dtype", ["fp32", "bf16"])
+def test_two_rank_retrieval_step_with_gathered_negatives(reduce_dtype):
+    """The reference's distributed SigLipLoss (modeling:239-297): each rank's loss = its own block with positives +
+    every other rank's captions as negatives; DDP averages the gradients.  Driven through the trainer on 2 ranks
+    (gloo, both on cuda:0) and compared with the oracle's autograd on the same split."""
+    from oracle import train_oracle as TO
+    from tests.helpers import run_ranks
+    _dev()
+    res = run_ranks(_gn_worker, 2, (reduce_dtype,))
+    ret = {"loss0": res[0][0], "loss1": res[1][0], "grads": torch.from_numpy(res[0][1])}
+    cfg = small_cfg(add_lora_spatial=True)
+    tr, orc = _trainer_and_oracle(cfg, True, seed=8, lora=True)
+    task, x, ti, _ = TO.schedule(cfg, B=4)[0]
+    total = 0.0
+    for rank in range(2):
         lo, hi = rank * 2, rank * 2 + 2
-        ti_r = {"kind": "localization", "label_emb": ti["label_emb"].cuda(), "labels": ti["labels"][lo:hi].cuda()}
-        _, pooler = tr.forward(x[lo:hi].cuda())
-        _, gp, gs = tr.loss_and_grad(task, pooler, ti_r)
-        tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
-        tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
-        tr.backward(gp, reduce=True)
-        torch.cuda.synchronize()
-        if rank == 0:
-            ret["grads"] = (tr.grads / world).cpu()
-    finally:
-        dist.destroy_process_group()
+        olo, ohi = (1 - rank) * 2, (1 - rank) * 2 + 2
+        want = orc.loss(task, x[lo:hi], {"kind": "retrieval", "text": ti["text"][lo:hi], "other_rank_text": [ti["text"][olo:ohi]]})
+        assert abs(ret[f"loss{rank}"] - float(want)) < 2e-2 * abs(float(want)), (rank, ret[f"loss{rank}"], float(want))
+        (want / 2).backward()                                   # DDP: mean over ranks
+    og = orc.grads()
+    got_all = ret["grads"]
+    worst = 0.0
+    for n, want in og.items():
+        if want.numel() == 1 or float(want.abs().max()) == 0.0:
+            continue
+        e = tr._entry(n)
+        got = got_all[e["offset"]: e["offset"] + e["numel"]].view(e["shape"])
+        worst = max(worst, rel_l2(got, want))
+    assert worst < (GRAD_REL_L2 if reduce_dtype == "fp32" else 6e-2), worst
+
+
+def test_retrieval_loss_has_no_batch_limit():
+    """B * Bt > 4096 used to fail (32 clips x 8 ranks).  64 local clips against 1024 gathered captions."""
+    import streamformer_amd as sa
+    from oracle import streamformer_oracle as O
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, T, D, Bt, rank = 64, 3, 768, 1024 + 64, 5
+    pooler = torch.randn(B, T, D, generator=g)
+    text = torch.randn(Bt, D, generator=g)
+    ls, lb = torch.tensor(math.log(10.0)), torch.tensor(-2.0)
+    p = pooler.clone().requires_grad_(True)
+    lsr, lbr = ls.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+    others = [text[r * B:(r + 1) * B] for r in range(Bt // B) if r != rank]
+    want = O.retrieval_loss(p, text[rank * B:(rank + 1) * B], lsr, lbr, other_rank_text=others)
+    want.backward()
+    loss, gp, gs = sa.heads.RetrievalHead(ls.to(dev), lb.to(dev)).loss(pooler.to(dev), text.to(dev), rank=rank)
+    assert abs(float(loss) - float(want)) <= 1e-4 * abs(float(want))
+    assert float((gp.cpu() - p.grad).abs().max()) <= 1e-5 * float(p.grad.abs().max()) + 1e-8
+    assert abs(float(gs[0]) - float(lsr.grad)) <= 1e-4 * abs(float(lsr.grad)) and abs(float(gs[1]) - float(lbr.grad)) <= 1e-4 * abs(float(lbr.grad))
+    with pytest.raises(ValueError):
+        sa.heads.RetrievalHead().loss(pooler.to(dev), text[:32].to(dev), rank=1)
+
+
+def _dp_worker(rank, world):
+    from oracle import train_oracle as TO
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    torch.cuda.set_device(0)
+    cfg = small_cfg(add_lora_spatial=True)
+    sd = make_state_dict(cfg, seed=8, lora=True)
+    tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device="cuda:0", bucket_mb=0.05)
+    assert len(tr.buckets) > 1
+    task, x, ti, _ = TO.schedule(cfg, B=4)[1]
+    lo, hi = rank * 2, rank * 2 + 2
+    ti_r = {"kind": "localization", "label_emb": ti["label_emb"].cuda(), "labels": ti["labels"][lo:hi].cuda()}
+    _, pooler = tr.forward(x[lo:hi].cuda())
+    _, gp, gs = tr.loss_and_grad(task, pooler, ti_r)
+    tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+    tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+    tr.backward(gp, reduce=True)
+    torch.cuda.synchronize()
+    return (tr.grads / world).cpu().numpy()
 
 
 def test_two_rank_allreduced_gradients_equal_the_big_batch():
-    import torch.multiprocessing as mp
     from oracle import train_oracle as TO
+    from tests.helpers import run_ranks
     _dev()
-    ctx = mp.get_context("spawn")
-    mgr = ctx.Manager()
-    ret = mgr.dict()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, 29655, ret)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    ret = {"grads": torch.from_numpy(run_ranks(_dp_worker, 2)[0])}
     cfg = small_cfg(add_lora_spatial=True)
     tr, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True)
     task, x, ti, _ = TO.schedule(cfg, B=4)[1]
