@@ -1,0 +1,104 @@
+"""GPU tests of the shipped tools around the encoder: the feature-dump CLI with its
+list sharding, the SigLIP weight surgery on the HIP path, and the 2-rank dry run of the training bench."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import streamformer_oracle as O
+from streamformer_amd.init_weights import make_state_dict
+from tests.conftest import ROOT
+from tests.helpers import load_npz, maxabs, small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_feature_dump_cli_two_shards(tmp_path):
+    """python -m streamformer_amd.features on four decoded "videos", as two half-list shards
+    (scripts/downstream_extract_oad_feature.sh:29-50 runs eight); every saved [num_windows, D] float32 .npy against the
+    oracle on the same preprocessed frames (extract_oad_feature.py:34-35, 117-136)."""
+    import streamformer_amd as sa
+    from streamformer_amd import features as F
+    assert torch.cuda.is_available()
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=23)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="fp32")
+    m.load_state_dict(sd)
+    model_dir, vid_dir, out_dir = tmp_path / "model", tmp_path / "videos", tmp_path / "feats"
+    m.save_pretrained(str(model_dir))
+    vid_dir.mkdir()
+    rng = np.random.default_rng(5)
+    specs = [("a/v0.npy", 30, 60, 80, 24.0), ("v1.npy", 41, 70, 56, 30.0), ("v2.npy", 13, 48, 48, 24.0), ("b/v3.npy", 25, 50, 90, 12.0)]
+    lines = []
+    for name, n, H, W, fps in specs:
+        os.makedirs(os.path.dirname(vid_dir / name), exist_ok=True)
+        np.save(vid_dir / name, rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8))
+        lines.append(f"{name} {fps}")
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    for st, ed in ((0.0, 0.5), (0.5, 1.0)):
+        r = subprocess.run([sys.executable, "-m", "streamformer_amd.features", "--pretrained_model", str(model_dir), "--video_list",
+                            str(tmp_path / "list.txt"), "--data_path", str(vid_dir), "--save_path", str(out_dir), "--start_idx", str(st),
+                            "--end_idx", str(ed), "--compute_dtype", "fp32", "--batch_windows", "3"],
+                           env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "2 videos to extract" in r.stdout
+    for name, n, H, W, fps in specs:
+        got = np.load(out_dir / (os.path.basename(name).split(".")[0] + ".npy"))
+        frames_u8 = np.load(vid_dir / name)
+        clip = F.resize_center_crop(frames_u8[F.resample_indices(n, fps)], 48)
+        x = m.image_processor.normalize(clip)                      # the arithmetic the patch kernel fuses
+        nn = x.shape[0]
+        want = []
+        for s in F.window_starts(nn):
+            q = x[nn - 6:] if s + 6 > nn else x[s:s + 6]
+            want.append(O.forward(sd, cfg, q[None])["pooler_output"][:, -1])
+        want = torch.cat(want)
+        assert got.dtype == np.float32 and got.shape == tuple(want.shape), (name, got.shape, want.shape)
+        assert maxabs(torch.from_numpy(got), want) <= 1e-3, name
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 5e-4), ("bf16", 6e-2)])
+def test_siglip_surgery_on_the_hip_path(golden_dir, mode, tol):
+    """f-4 on the GPU: the converted encoder (gate 0 => per-frame SigLIP) against fixture F11 = HF SiglipVisionModel's
+    outputs; tanh-GELU (hidden_act code 1) through the GEMM epilogues."""
+    import streamformer_amd as sa
+    from oracle.make_golden_siglip import fixture_cfg
+    from oracle.siglip_fixture import make_siglip_state_dict
+    from streamformer_amd.convert import siglip_vision_to_streamformer
+    g = load_npz(os.path.join(golden_dir, "f11_siglip_surgery.npz"))
+    cfg = fixture_cfg()
+    sd = siglip_vision_to_streamformer(make_siglip_state_dict(cfg, seed=11), cfg, seed=0)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    out = m.to("cuda").eval()(torch.tensor(g["pixel_values"]).cuda())
+    assert maxabs(out.last_hidden_state, g["last_hidden_state"]) <= tol
+    assert maxabs(out.pooler_output, g["pooler_output"]) <= tol
+
+
+def test_train_bench_two_ranks_dry_run():
+    """bench.py --mode train as the driver launches it at N = 2 (torch.distributed.run, one rank per GPU), here with both
+    ranks on cuda:0 over gloo: the bucketed gradient all-reduce, cross-rank retrieval negatives, barriers and the
+    max-over-ranks timing all execute; rank 0 prints the one JSON line of the contract."""
+    port = 29500 + os.getpid() % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "train",
+           "--backend", "gloo", "--same-device", "--batch", "2"]
+    r = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2" and out["allreduce_buckets"] >= 2
+    assert all(np.isfinite(v) for v in out["losses_first_last"])
