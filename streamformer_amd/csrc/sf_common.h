@@ -148,6 +148,9 @@ struct SfGemmArgs {
   // (A = bf16(x), W' = W * gamma) finishes y = rstd * (acc - mean * ln_s[n]) + bias' in its epilogue.
   float* ln_stats_out;
   const float* ln_stats; const float* ln_s; float ln_eps;
+  // small-M variant of the fold (sf_gemm_skinny.hip): ln_inkernel = 1 -> the consumer derives mean / rstd of its rows from the
+  // A fragments it streams anyway (A = bf16(x), ln_s as above); no statistics buffer exists
+  int ln_inkernel;
   // training-step fusions on a bf16 output (256^2 kernel only; sf_gemm256_aux_supported):
   //   aux_mode 1: also write aux[row, col] = gelu(out)            (forward: pre-activation + activation)
   //   aux_mode 2: out *= gelu'(aux[row, col])                     (backward: d pre = d act * gelu'(pre))
@@ -179,6 +182,8 @@ hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi
                               int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr);
 // fp32 [n] -> bf16 hi (+lo)
 hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
+// two fp32 copies in one launch (b may be null): the streaming path's hand-over of graph-owned outputs to the caller's tensors
+hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s);
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
 hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s);
 // out[t*N + n, :] = pos[n, :] + time_rows[t, :]   (the additive table of the embeddings, modeling:413-457)

@@ -93,8 +93,20 @@ struct sf_cache {
   sf_encoder* enc = nullptr;
   uint64_t enc_generation = 0;   // packing of the encoder this cache was sized for (element size, device, weights)
   int B = 0, cap = 0, H = 0, W = 0, N = 0, len = 0;
+  bool warmed = false;      // one eager call has run on this cache (lazy kernel set-up done) -> captures may start
   std::vector<void*> qkv;   // per layer [B, cap, N, 3D] (bf16 or fp32 by compute mode)
   size_t bytes = 0;
+  // hipGraph of the per-call launch sequence, one per (frames cached, frames added): everything between the patch
+  // extraction (reads the caller's pixels) and the copy-out (writes the caller's outputs) is replayed as one graph launch
+  struct GraphEntry {
+    hipGraphExec_t exec = nullptr;
+    void* ws = nullptr;
+    const float* pos = nullptr;
+    bool pooler = false;
+  };
+  std::map<uint32_t, GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;   // captures are recorded on a private stream (the caller's may be the null stream, which
+                                      // cannot capture) and replayed on the caller's
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -458,6 +470,8 @@ struct Workspace {
   void* tqkv;         // temporal qkv of the current layer when no cache is used
   float* attn_out;    // head: [F, D]
   bf16_t *pc_hi, *pc_lo, *hn_hi, *hn_lo, *hm_hi, *hm_lo;
+  float *lhs_stage, *pool_stage;   // streaming only: graph-owned outputs, copied to the caller's tensors after the replay
+  bf16_t* res_bf;                  // small-M LayerNorm fold: bf16 copy of the residual stream (A operand of the folded Linears)
   size_t bytes;
 };
 
@@ -494,6 +508,9 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.hn_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
   w.hm_hi = c.take<bf16_t>(F * I);
   w.hm_lo = acc ? c.take<bf16_t>(F * I) : nullptr;
+  w.res_bf = (!acc && M <= 512) ? c.take<bf16_t>(M * D) : nullptr;
+  w.lhs_stage = !need_tqkv ? c.take<float>(M * D) : nullptr;       // streaming carve (the cache holds the temporal qkv)
+  w.pool_stage = !need_tqkv ? c.take<float>(F * D) : nullptr;
   w.bytes = (c.off + 255) & ~(size_t)255;
   return w;
 }
@@ -505,7 +522,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
                              int M, int epi, hipStream_t s, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
                              const float* resid = nullptr, float alpha = 1.f, int ldc = 0, int grp_rows = 0,
                              int grp_stride = 0, int grp_off = 0, const float* ln_stats = nullptr,
-                             float* ln_stats_out = nullptr) {
+                             float* ln_stats_out = nullptr, bool ln_inkernel = false) {
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   const bool split = e->compute == SF_COMPUTE_BF16X3;
@@ -520,6 +537,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   if (grp_rows > 0 && grp_stride == grp_rows && grp_off == 0) g.grp_rows = 0;   // identity remap (full clip)
   g.ln_stats = ln_stats; g.ln_s = ln_stats ? lin.ln_s : nullptr; g.ln_eps = e->cfg.layer_norm_eps;
   g.ln_stats_out = ln_stats_out;
+  if (ln_inkernel) { g.ln_inkernel = 1; g.ln_s = lin.ln_s; }
   if (epi == SF_EPI_RESID_F32) g.out_hi = out_hi;     // LN-fold producer: bf16 copy of the new residual rows
   return sf_launch_gemm(g, split, s);
 }
@@ -540,6 +558,25 @@ static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (!sf_gemm256_supported(g, false)) return false;
   g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
   return sf_gemm256_supported(g, false);
+}
+
+// Small-M variant (the per-frame streaming step): the skinny GEMM derives the row statistics itself from the A fragments
+// it reads anyway, every residual producer only adds the bf16 copy of its output rows.
+static bool ln_fold_small_ok(const sf_encoder* e, int M) {
+  if (e->compute != SF_COMPUTE_BF16 || M > 512) return false;
+  static const bool off = getenv("SF_DISABLE_STREAM_FOLD") != nullptr;
+  if (off) return false;
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.K = e->D; g.ldc = 3 * e->D; g.ln_inkernel = 1; g.ln_s = (const float*)1;
+  g.epi = SF_EPI_BF16; g.N = 3 * e->D;
+  if (!sf_gemm_skinny_supported(g, false)) return false;
+  g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.ldc = e->I;
+  if (!sf_gemm_skinny_supported(g, false)) return false;
+  g.ln_inkernel = 0; g.ln_s = nullptr; g.epi = SF_EPI_RESID_F32; g.N = e->D; g.ldc = e->D; g.out_hi = (bf16_t*)1;
+  if (!sf_gemm_skinny_supported(g, false)) return false;      // producers (they add the bf16 copy): K = D ...
+  g.K = e->I;
+  return sf_gemm_skinny_supported(g, false);                  // ... and K = I
 }
 
 static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfRowIndex* idx) {
@@ -568,7 +605,8 @@ static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfR
 static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
                        float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
                        const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
-                       hipStream_t s, float* attentions = nullptr, int stages = 7, int la = 0, int lb = -1) {
+                       hipStream_t s, float* attentions = nullptr, int stages = 7, int la = 0, int lb = -1,
+                       bool patches_ready = false) {
   // stages: 1 = embeddings -> ws.resid, 2 = layers [la, lb) on ws.resid, 4 = post-LayerNorm + pooling head,
   // 8 = pooling head alone on already-normalised tokens in ws.resid
   // (the sub-module entry points run them one at a time on a caller-owned residual stream)
@@ -595,8 +633,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       !getenv("SF_EMBED_VIA_GEMM128"))
     embed_panel = true;
   bf16_t* patches = embed_panel ? ws.patch_buf : ws.xn_hi;
-  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), patches, ws.xn_lo, F, c.num_channels, H, W, P, s,
-                             &e->pixel_norm));
+  if (!patches_ready)
+    HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), patches, ws.xn_lo, F, c.num_channels, H, W, P, s,
+                               &e->pixel_norm));
   {
     SfGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -615,6 +654,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     } else {
       g.epi = SF_EPI_EMBED_F32;
       g.pos = pos_dev ? pos_dev : e->pos; g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
+      if (ws.res_bf && ln_fold_small_ok(e, M) && (stages & 2)) g.out_hi = ws.res_bf;   // layer 0's folded qkv reads bf16(x)
       HIP_TRY(sf_launch_gemm(g, acc, s));
     }
   }
@@ -623,18 +663,23 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // LN folding (bf16 mode, BASELINE-sized M): xn_hi holds bf16(residual), ln_stats the row sums; the
   // three per-layer LayerNorm launches disappear into the neighbouring GEMM epilogues.
   const bool fold = ln_fold_ok(e, M) && !streaming;
-  bf16_t* fold_hi = fold ? ws.xn_hi : nullptr;
+  // sfold: the same algebra at small M (streamed frames), statistics computed inside the consumer GEMM
+  const bool sfold = !fold && ws.res_bf && ln_fold_small_ok(e, M);
+  bf16_t* fold_hi = fold ? ws.xn_hi : (sfold ? ws.res_bf : nullptr);
   float* fold_st = fold ? ws.ln_stats : nullptr;
+  const bf16_t* ln_in = sfold ? ws.res_bf : ws.xn_hi;       // A operand of the three LayerNorm'd Linears
+  const bool anyfold = fold || sfold;
   if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
+  if (sfold && (stages & 2) && !(stages & 1)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
   for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];
     if (hidden_states)
       HIP_TRY(hipMemcpyAsync(hidden_states + li * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
     // ---- temporal attention (modeling:937-958) ---------------------------------------------------
-    if (!fold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_t.g, l.ln_t.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_t.g, l.ln_t.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
     void* tq = layer_tqkv ? layer_tqkv[li] : ws.tqkv;
-    HIP_TRY(run_linear(e, fold ? l.t_qkv_f : l.t_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)tq, (bf16_t*)tq, nullptr, nullptr, 1.f,
-                       3 * D, T * N, cap * N, t_past * N, fold_st));
+    HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, qkv_epi, s, (float*)tq, (bf16_t*)tq, nullptr, nullptr, 1.f,
+                       3 * D, T * N, cap * N, t_past * N, fold_st, nullptr, sfold));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
@@ -654,9 +699,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
                          0, 0, 0, 0, nullptr, fold_st));
     }
     // ---- spatial attention (modeling:962-996) ------------------------------------------------------
-    if (!fold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, fold ? l.s_qkv_f : l.s_qkv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr,
-                       nullptr, 1.f, 0, 0, 0, 0, fold_st));
+    if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, anyfold ? l.s_qkv_f : l.s_qkv, ln_in, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr,
+                       nullptr, 1.f, 0, 0, 0, 0, fold_st, nullptr, sfold));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
@@ -669,9 +714,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
                        0, 0, 0, 0, nullptr, fold_st));
     // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
-    if (!fold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, fold ? l.up_f : l.up, ws.xn_hi, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
-                       0, 0, 0, 0, fold_st));
+    if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, anyfold ? l.up_f : l.up, ln_in, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
+                       0, 0, 0, 0, fold_st, nullptr, sfold));
     HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
                        0, 0, 0, 0, nullptr, fold_st));
   }
@@ -832,8 +877,15 @@ extern "C" int sf_cache_reset(sf_cache* c) {
 }
 extern "C" int sf_cache_length(const sf_cache* c) { return c ? c->len : 0; }
 extern "C" size_t sf_cache_bytes(const sf_cache* c) { return c ? c->bytes : 0; }
+static void drop_graphs(sf_cache* c) {
+  for (auto& kv : c->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  c->graphs.clear();
+}
 extern "C" void sf_cache_destroy(sf_cache* c) {
   if (!c) return;
+  drop_graphs(c);
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   for (void* q : c->qkv) (void)hipFree(q);
   delete c;
 }
@@ -860,10 +912,64 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     return set_err(SF_ERR_CAPACITY, "cache holds %d of %d frames; %d more do not fit", c->len, c->cap, T_new);
   Workspace ws = carve(e, workspace, c->B, T_new, N, false);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
-  rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,
-                   c->qkv.data(), c->cap, c->len, true, (hipStream_t)stream);
-  if (rc == SF_OK) c->len += T_new;
-  return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // ---- graph replay (the per-frame sequence is ~100 dependent launches of a few microseconds) -----------------
+  // Not when the caller wants the per-layer hidden states (memcpy nodes to caller memory), is capturing the stream
+  // itself, or asked for eager launches.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  static const bool graphs_off = getenv("SF_DISABLE_STREAM_GRAPH") != nullptr;
+  const bool use_graph = !graphs_off && !hidden_states && cap == hipStreamCaptureStatusNone && T_new < 256 && c->len < 65536;
+  if (!use_graph) {
+    rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,
+                     c->qkv.data(), c->cap, c->len, true, s);
+    if (rc == SF_OK) c->len += T_new;
+    return rc;
+  }
+  const int F = c->B * T_new, M = F * N;
+  const uint32_t key = ((uint32_t)c->len << 8) | (uint32_t)T_new;
+  sf_cache::GraphEntry& g = c->graphs[key];
+  if (g.exec && (g.ws != workspace || g.pos != pos_dev || g.pooler != (pooler != nullptr))) {
+    (void)hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+  }
+  // patch extraction reads the caller's frames: outside the graph
+  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels,
+                             c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm));
+  if (!g.exec) {
+    if (!c->warmed) {
+      // first call of this cache: run eagerly once so that every lazy per-kernel set-up (hipFuncSetAttribute, device
+      // queries) has happened before a capture is opened
+      rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws, c->qkv.data(),
+                       c->cap, c->len, true, s, nullptr, 7, 0, -1, true);
+      if (rc == SF_OK) { c->len += T_new; c->warmed = true; }
+      c->graphs.erase(key);
+      return rc;
+    }
+    hipGraph_t graph = nullptr;
+    if (!c->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
+                     ws, c->qkv.data(), c->cap, c->len, true, c->cap_stream, nullptr, 7, 0, -1, true);
+    hipError_t ce = hipStreamEndCapture(c->cap_stream, &graph);
+    if (rc != SF_OK || ce != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      c->graphs.erase(key);
+      if (rc != SF_OK) return rc;
+      return set_err(SF_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    }
+    hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) {
+      c->graphs.erase(key);
+      return set_err(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+    }
+    g.ws = workspace; g.pos = pos_dev; g.pooler = pooler != nullptr;
+  }
+  HIP_TRY(hipGraphLaunch(g.exec, s));
+  HIP_TRY(sf_launch_copy2(ws.lhs_stage, last_hidden, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, pooler, (size_t)F * e->D, s));
+  c->len += T_new;
+  return SF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

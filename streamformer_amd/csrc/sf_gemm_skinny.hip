@@ -38,7 +38,36 @@ SF_DEVICE bf16x8_t sk_frag(const char* img, int row, int kc) {
 template <int N>
 SF_DEVICE void sk_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool SPLIT, int EPI>
+// LayerNorm folded into the consumer at small M (LNF): A = bf16(x) of the residual stream, W' = W * gamma.  The wave adds
+// up sum x and sum x^2 of its 16 rows from the very A fragments it feeds to the MFMAs (v_dot2c_f32_bf16: two VALU ops
+// per 4 products; lane (l15, g) sees the k-chunks g, g+4 of row l15), the four k-groups meet by two xor-shuffles, and the
+// epilogue finishes y = rstd (acc - mean s_n) + b'.  No statistics buffer, no extra pass over the rows: the 36 LayerNorm
+// launches of a streamed frame disappear.  The statistics are those of the bf16-rounded rows (what the products see).
+SF_DEVICE void sk_stats(const bf16x8_t& f, float& s1, float& s2) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  const v8bf h = __builtin_bit_cast(v8bf, f);
+  const v2bf one = {(__bf16)1.0f, (__bf16)1.0f};
+  // pairs taken with shufflevector: indexing a bit-cast u32x4 copy of the fragment (u[j]) made hipcc 7.2 feed dword 0 to
+  // all four dot products (seen in the ISA as four v_dot2c on the same VGPR)
+  const v2bf x0 = __builtin_shufflevector(h, h, 0, 1), x1 = __builtin_shufflevector(h, h, 2, 3);
+  const v2bf x2 = __builtin_shufflevector(h, h, 4, 5), x3 = __builtin_shufflevector(h, h, 6, 7);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x0, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x0, x0, s2, false);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x1, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x1, x1, s2, false);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x2, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x2, x2, s2, false);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x3, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x3, x3, s2, false);
+}
+SF_DEVICE void sk_ln_finish(float s1, float s2, int K, float eps, float& mean, float& rstd) {
+  const float inv_k = 1.0f / (float)K;
+  mean = s1 * inv_k;
+  rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * inv_k - mean * mean, 0.f) + eps);
+}
+
+template <bool SPLIT, int EPI, bool LNF = false>
 __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p) {
   constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);     // hi plane (+ lo plane)
   constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // 16-byte chunks per thread per plane = 2
@@ -77,6 +106,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   };
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float ln1 = 0.f, ln2 = 0.f;
   const int nkt = p.K / SK_BK;
   constexpr int PER = LOADS * (SPLIT ? 2 : 1);            // load instructions per stage per thread
   const int mt = wave & 1, nt = wave >> 1;                // this wave's 16x16 output tile
@@ -101,6 +131,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       const int kc = ks * 4 + g;
       const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
       const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
+      if (LNF) sk_stats(af, ln1, ln2);
       if (SPLIT) {
         const char* lo = img + SK_PLANE;
         const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
@@ -110,6 +141,10 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       }
       acc = sk_mfma(wf, af, acc);
     }
+  }
+  if (LNF) {       // the four k-groups of row l15 (all 64 lanes still active here)
+    ln1 += __shfl_xor(ln1, 16, 64); ln1 += __shfl_xor(ln1, 32, 64);
+    ln2 += __shfl_xor(ln2, 16, 64); ln2 += __shfl_xor(ln2, 32, 64);
   }
 
   // ---- epilogue: lane holds C[m = tile row l15][n = tile col 4g .. 4g+3] ----------------------------------
@@ -121,6 +156,11 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   {
     size_t orow = (size_t)m;
     if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+    if (LNF) {
+      float mean, rstd;
+      sk_ln_finish(ln1, ln2, p.K, p.ln_eps, mean, rstd);
+      acc = rstd * (acc - mean * *reinterpret_cast<const f32x4_t*>(p.ln_s + n));
+    }
     f32x4_t v = acc + bias;
     const size_t o = orow * (size_t)p.ldc + n;
     if (EPI == SF_EPI_F32) {
@@ -129,12 +169,16 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.resid + o);
       v = r + p.alpha * v;
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+      if (!SPLIT && p.out_hi)    // small-M LayerNorm fold producer: bf16 copy of the new residual rows
+        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     } else if (EPI == SF_EPI_EMBED_F32) {
       const int pn = m % p.Np, tt = (m / p.Np) % p.Tn;
       const f32x4_t pe = *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)pn * p.N + n);
       const f32x4_t te = *reinterpret_cast<const f32x4_t*>(p.time_rows + (size_t)tt * p.N + n);
       v = v + pe + te;
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+      if (!SPLIT && p.out_hi)      // small-M LayerNorm fold: bf16 copy of the embedded rows for layer 0's folded qkv
+        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     } else {
       if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
@@ -159,7 +203,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
 // ------------------------------------------------------------------------------------------------
 #define SKG_STAGES 4
 
-template <bool SPLIT, int EPI, int KG>
+template <bool SPLIT, int EPI, int KG, bool LNF = false>
 __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGemmArgs p) {
   constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);
   constexpr int RING = SKG_STAGES * STAGE;
@@ -206,6 +250,7 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   };
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float ln1 = 0.f, ln2 = 0.f;
   const int mt = w4 & 1, nt = w4 >> 1;
   for (int j = 0; j < SKG_STAGES - 1 && j < mine; ++j) issue(j);
   for (int j = 0; j < per_grp; ++j) {                    // every group runs per_grp steps: one barrier domain
@@ -220,6 +265,7 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
         const int kc = ks * 4 + g;
         const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
         const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
+        if (LNF) sk_stats(af, ln1, ln2);
         if (SPLIT) {
           const char* lo = img + SK_PLANE;
           const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
@@ -232,13 +278,30 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
     }
   }
   // ---- cross-group reduction through the (now idle) ring of group 0 ------------------------------------
+  if (LNF) {
+    ln1 += __shfl_xor(ln1, 16, 64); ln1 += __shfl_xor(ln1, 32, 64);
+    ln2 += __shfl_xor(ln2, 16, 64); ln2 += __shfl_xor(ln2, 32, 64);
+  }
   __builtin_amdgcn_s_barrier();
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
-  if (kgrp > 0) red[((kgrp - 1) * 4 + w4) * 64 + lane] = acc;
+  float* reds = reinterpret_cast<float*>(smem + (KG - 1) * 4 * 64 * 16);       // [KG-1][4 waves][2][16 rows]
+  if (kgrp > 0) {
+    red[((kgrp - 1) * 4 + w4) * 64 + lane] = acc;
+    if (LNF && g == 0) {
+      reds[(((kgrp - 1) * 4 + w4) * 2 + 0) * 16 + l15] = ln1;
+      reds[(((kgrp - 1) * 4 + w4) * 2 + 1) * 16 + l15] = ln2;
+    }
+  }
   __syncthreads();
   if (kgrp > 0) return;
 #pragma unroll
-  for (int k = 1; k < KG; ++k) acc += red[((k - 1) * 4 + w4) * 64 + lane];
+  for (int k = 1; k < KG; ++k) {
+    acc += red[((k - 1) * 4 + w4) * 64 + lane];
+    if (LNF) {
+      ln1 += reds[(((k - 1) * 4 + w4) * 2 + 0) * 16 + l15];
+      ln2 += reds[(((k - 1) * 4 + w4) * 2 + 1) * 16 + l15];
+    }
+  }
 
   const int n = n0 + nt * 16 + g * 4;
   const int m = m0 + mt * 16 + l15;
@@ -247,6 +310,11 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   if (p.bias) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
   size_t orow = (size_t)m;
   if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+  if (LNF) {
+    float mean, rstd;
+    sk_ln_finish(ln1, ln2, p.K, p.ln_eps, mean, rstd);
+    acc = rstd * (acc - mean * *reinterpret_cast<const f32x4_t*>(p.ln_s + n));
+  }
   f32x4_t v = acc + bias;
   const size_t o = orow * (size_t)p.ldc + n;
   if (EPI == SF_EPI_F32) {
@@ -255,6 +323,8 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
     const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.resid + o);
     v = r + p.alpha * v;
     *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+    if (!SPLIT && p.out_hi)      // small-M LayerNorm fold producer: bf16 copy of the new residual rows
+      *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
   } else {
     if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
@@ -271,6 +341,18 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
 template <bool SPLIT, int KG>
 static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
   const size_t lds = (size_t)KG * SKG_STAGES * SK_PLANE * (SPLIT ? 2 : 1);
+  if (a.ln_inkernel) {       // LayerNorm-folded consumers (bf16 mode): qkv (BF16) and MLP-up (ACT_BF16) epilogues
+    if (SPLIT) return hipErrorInvalidValue;
+    static SfPerDeviceOnce attr_ln;
+    if (attr_ln.first()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<false, SF_EPI_BF16, KG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<false, SF_EPI_ACT_BF16, KG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (a.epi == SF_EPI_BF16) hipLaunchKernelGGL((sf_gemm_skinny_kg_kernel<false, SF_EPI_BF16, KG, true>), grid, dim3(SK_THREADS * KG), lds, s, a);
+    else if (a.epi == SF_EPI_ACT_BF16) hipLaunchKernelGGL((sf_gemm_skinny_kg_kernel<false, SF_EPI_ACT_BF16, KG, true>), grid, dim3(SK_THREADS * KG), lds, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   static SfPerDeviceOnce attr_set;
   if (attr_set.first()) {
 #define SKG_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<SPLIT, E, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -296,8 +378,8 @@ static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
   // few rows, or few output columns (the rank-32 LoRA projections of the training step: A streams once)
   if (a.M <= 0 || (a.M > 512 && a.N > 64) || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
-  if (a.ln_stats || a.ln_stats_out) return false;
-  if (a.epi == SF_EPI_RESID_F32 && a.out_hi) return false;         // LayerNorm-fold producer: panel kernel only
+  if (a.ln_stats || a.ln_stats_out) return false;                  // the statistics-buffer fold: panel / 256^2 kernels
+  if (a.ln_inkernel && (split || !a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
   if (split && (!a.a_lo || !a.w_lo)) return false;
   return true;
 }
@@ -328,6 +410,16 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s)
   if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !getenv("SF_SKINNY_NO_KG"))
     return split ? skg_launch<true, 2>(a, grid, s) : skg_launch<false, 4>(a, grid, s);
   const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
+  if (a.ln_inkernel) {
+    static SfPerDeviceOnce attr_ln;
+    if (attr_ln.first()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, SF_EPI_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
+    }
+    if (a.epi == SF_EPI_BF16) hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_BF16, true>), grid, dim3(SK_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true>), grid, dim3(SK_THREADS), lds, s, a);
+    return hipGetLastError();
+  }
   static SfPerDeviceOnce attr_set;
   if (attr_set.first()) {
 #define SK_ATTR(S, E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);

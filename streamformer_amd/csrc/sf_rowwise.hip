@@ -236,3 +236,18 @@ hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, fl
   hipLaunchKernelGGL(sf_pos_time_table_kernel, dim3(blocks), dim3(256), 0, s, pos, time_rows, out, T, N, D / 4);
   return hipGetLastError();
 }
+
+__global__ __launch_bounds__(256) void sf_copy2_kernel(const float* __restrict__ a_src, float* __restrict__ a_dst, size_t na4,
+                                                       const float* __restrict__ b_src, float* __restrict__ b_dst, size_t nb4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < na4) reinterpret_cast<f32x4_t*>(a_dst)[i] = reinterpret_cast<const f32x4_t*>(a_src)[i];
+  else if (i - na4 < nb4) reinterpret_cast<f32x4_t*>(b_dst)[i - na4] = reinterpret_cast<const f32x4_t*>(b_src)[i - na4];
+}
+hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s) {
+  if ((na % 4) || (nb % 4)) return hipErrorInvalidValue;
+  if (!b_src || !b_dst) nb = 0;
+  const size_t n4 = (na + nb) / 4;
+  if (!n4) return hipSuccess;
+  hipLaunchKernelGGL(sf_copy2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a_src, a_dst, na / 4, b_src, b_dst, nb / 4);
+  return hipGetLastError();
+}

@@ -237,7 +237,9 @@ def test_streaming_f4(sa, golden_dir, mode, tag, nf):
         got = torch.cat(outs, 1)
         assert maxabs(got, want) <= lt
         # streamed == full clip on the same device path, to fp32 re-ordering noise
-        assert maxabs(got, full) <= (1e-4 if mode == "fp32" else 2e-2)   # same kernels serve both at these sizes
+        # streamed vs full clip on the device: fp32 re-ordering noise; in bf16 mode the small-M calls fold the LayerNorms into
+        # the GEMMs (statistics of the bf16-rounded rows) while a 64-frame clip runs the separate LayerNorm: two bf16 roundings apart
+        assert maxabs(got, full) <= (1e-4 if mode == "fp32" else 4e-2)
     with pytest.raises(Exception):                        # past the time-embedding rows / cache capacity
         m(x[:, :1], use_cache=True, past_key_values=cache)
     cache.reset()
@@ -662,6 +664,37 @@ def test_streaming_is_bit_reproducible_at_base_size(mode):
     full = m(x)
     tol = 2e-4 if mode == "fp32" else BF16_LHS
     assert maxabs(runs[0][0], full.last_hidden_state) <= tol and maxabs(runs[0][1], full.pooler_output) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol_l,tol_p", [("fp32", ACC_TOL, ACC_TOL), ("bf16", BF16_LHS, BF16_POOL)])
+def test_streaming_config5_full_size_vs_oracle(mode, tol_l, tol_p):
+    """BASELINE configs[4] at full size: SigLIP-base with num_frames = 64, one 224^2 frame per call through the KV-cache,
+    64 calls — against the ORACLE's full-clip forward of the same 64 frames (causal temporal attention makes the two
+    identical in exact arithmetic; vqa_enc:491-560, 1316-1392).  The streamed path runs the small-M kernels (register-direct
+    GEMM with the LayerNorm fold, the cache-append epilogue, temporal attention over the growing cache) inside hipGraph
+    replays; a second pass over the same stream after cache.reset() must reproduce the first bit for bit."""
+    import streamformer_amd as sa
+    cfg = siglip_base(num_frames=64)
+    sd = make_state_dict(cfg, seed=0)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    x = frames(64, (1, 64, 3, 224, 224))
+    want = O.forward(sd, cfg, x)
+    xd = x.cuda()
+    cache = m.new_cache(1, 64)
+    passes = []
+    for rep in range(2):
+        cache.reset()
+        outs = [m(xd[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(64)]
+        passes.append((torch.cat([o.last_hidden_state for o in outs], 1), torch.cat([o.pooler_output for o in outs], 1)))
+    lhs, pool = passes[0]
+    per_frame = (lhs.cpu() - want["last_hidden_state"]).abs().amax(dim=(0, 2, 3))
+    assert float(per_frame.max()) <= tol_l, per_frame.tolist()
+    assert maxabs(pool, want["pooler_output"]) <= tol_p
+    assert cosine(lhs, want["last_hidden_state"]) >= (0.9995 if mode == "bf16" else 0.999999)
+    assert torch.equal(passes[0][0], passes[1][0]) and torch.equal(passes[0][1], passes[1][1])
 
 
 @pytest.mark.gpu

@@ -1,0 +1,30 @@
+"""Per-frame timeline from a rocprofv3 rocpd database of tools/stream_trace.py: kernels sorted by start time, frames split
+at the patchify kernel; reports per kernel-name mean duration, mean gap BEFORE it, and the busy / idle split of a frame."""
+import sqlite3, sys, collections
+db = sqlite3.connect(sys.argv[1])
+rows = list(db.execute("select name, start, end from kernels order by start"))
+frames, cur = [], []
+for name, s, e in rows:
+    if "sf_gather_rows" in name and cur:
+        frames.append(cur); cur = []
+    cur.append((name, s, e))
+frames.append(cur)
+frames = [f for f in frames if len(f) > 50][64:]          # skip the first (untimed) repeat
+agg = collections.OrderedDict()
+busy = idle = span = 0.0
+for f in frames:
+    prev_end = None
+    for name, s, e in f:
+        short = name.split("(")[0].replace("void ", "")[:60]
+        d = agg.setdefault(short, [0, 0.0, 0.0])
+        d[0] += 1; d[1] += (e - s)
+        if prev_end is not None:
+            d[2] += max(0, s - prev_end); idle += max(0, s - prev_end)
+        busy += e - s
+        prev_end = e
+    span += f[-1][2] - f[0][1]
+n = len(frames)
+print(f"{n} frames; per frame: kernels {sum(len(f) for f in frames)/n:.1f}, busy {busy/n/1e3:.1f} us, idle between kernels {idle/n/1e3:.1f} us, span {span/n/1e3:.1f} us")
+print(f"{'per_frame':>9} {'dur_us':>8} {'gap_before_us':>13} {'total_us/frame':>14}  kernel")
+for k, (c, d, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{c/n:9.1f} {d/c/1e3:8.2f} {g/c/1e3:13.2f} {(d+g)/n/1e3:14.1f}  {k}")
