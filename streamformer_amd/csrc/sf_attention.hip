@@ -14,6 +14,7 @@
 // ACC = the fp32-accurate mode: fp32 inputs are split into bf16 hi+lo and every product becomes
 // hi*hi + hi*lo + lo*hi (same three-term scheme as the GEMM).
 #include "sf_common.h"
+#include <cstdlib>
 
 #define HD 64  // head_dim supported by these kernels (SigLIP-base/large: 64)
 
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  // qsplit = 2 (few frames in flight, e.g. the per-frame streaming step): two workgroups per (frame, head), each
-  // stages K / V^T and takes one of the two query-tile rounds, so twice as many CUs share the work
+  // qsplit > 1 (few frames in flight, e.g. the per-frame streaming step: 12 (frame, head) problems on 256 CUs): qsplit
+  // workgroups per (frame, head); each stages K / V^T (all 8 waves) and then waves 0 .. tpw-1 take one query tile each of
+  // the workgroup's share, so qsplit times as many CUs work on the launch
   const int fhq = blockIdx.x / qsplit, qs = blockIdx.x % qsplit;
   const int frame = fhq / p.heads, h = fhq % p.heads;
   const int N = p.N;
@@ -164,13 +166,19 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
   char* o_st = v_lo + HD * vpitch + wave * (ACC ? 4096 : 2048);   // per-wave [16 rows][128 B] (hi [, lo])
   const size_t row0 = (size_t)frame * N;
   const int nqt = (N + 15) >> 4;
+  const int tpw = (nqt + qsplit - 1) / qsplit;         // query tiles per workgroup when split (<= SP_WAVES)
+  auto tile_of = [&](int u) -> int {                     // query tile of this wave in round u, or -1
+    if (qsplit == 1) return wave + u * SP_WAVES;
+    return (u == 0 && wave < tpw) ? qs * tpw + wave : -1;
+  };
 
   // ---- Q fragments of this wave's query tiles (in flight during the staging below) ----------------
   bf16x8_t qh[SP_QT][2], ql[SP_QT][2];
 #pragma unroll
   for (int u = 0; u < SP_QT; ++u) {
-    if (qsplit > 1 && u != qs) continue;
-    int qi = (wave + u * SP_WAVES) * 16 + l15;
+    const int qt_u = tile_of(u);
+    if (qt_u < 0) continue;
+    int qi = qt_u * 16 + l15;
     qi = qi < N ? qi : N - 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -217,9 +225,8 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
 
 #pragma unroll
   for (int u = 0; u < SP_QT; ++u) {
-    if (qsplit > 1 && u != qs) continue;
-    const int qt = wave + u * SP_WAVES;
-    if (qt >= nqt) break;
+    const int qt = tile_of(u);
+    if (qt < 0 || qt >= nqt) continue;
 
     // ---- S^T = K Q^T ---------------------------------------------------------------------------
     f32x4_t s[MAXNT2][2];
@@ -529,7 +536,17 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   }
   const int vp = (2 * nkp + 255) & ~255;          // V^T row pitch: whole groups of 16 chunks (vswz is 4-bit)
   const size_t lds = (size_t)(nkp * 128 + HD * vp + SP_WAVES * 2048) * (accurate ? 2 : 1);
-  const int qsplit = (a.frames * a.heads <= 128 && a.N > 128 && !a.probs) ? 2 : 1;
+  // few (frame, head) problems: split the query tiles of each over several workgroups (each re-stages K / V^T: 50 KB)
+  const int nqt = (a.N + 15) >> 4, fh = a.frames * a.heads;
+  int qsplit = 1;
+  if (!a.probs && a.N > 32) {
+    if (fh <= 32) qsplit = (nqt + 1) / 2;           // two query tiles per workgroup: 84 workgroups for one 196-patch frame
+    else if (fh <= 64) qsplit = (nqt + 3) / 4;
+    else if (fh <= 128) qsplit = (nqt + 7) / 8;
+    static const char* env = getenv("SF_SPATIAL_TPW");   // tuning: query tiles per workgroup
+    if (env && fh <= 128) qsplit = (nqt + atoi(env) - 1) / atoi(env);
+    if (qsplit < 1) qsplit = 1;
+  }
   const dim3 grid(a.frames * a.heads * qsplit), block(SP_WAVES * 64);
   static SfPerDeviceOnce attr;
   if (attr.first()) {
@@ -702,8 +719,150 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int
   }
 }
 
+// ================================================================================================
+// temporal attention of ONE new frame per stream (Tq = 1: the streaming step, vqa_enc:1316-1392 with a
+// single-frame call): a matrix-vector problem per (b, patch, head) — q (64) against Tk cached keys — so there
+// is nothing for the MFMA to do.  One wave per task, plain VALU:
+//   scores : lane = key (KP passes of 64 keys); the lane reads its key row (128 B bf16 / 256 B fp32) and dots it
+//            with q in fp32 (exact products of the stored operands; the fp32-accurate mode needs no bf16x3 here);
+//   softmax: two wave reductions (max, sum) on the DPP path;
+//   P V    : lane = (key mod 8, 8-wide d chunk): eight keys x 128 B per load instruction (whole lines), the lane's
+//            probability comes by ds_bpermute, partial rows meet by three xor-shuffles per value.
+// Every load of the task is issued before the first use (one memory latency per task), no LDS, no barrier.
+// The MFMA kernel above pays ~10-17 us per launch at one frame (V^T staging through LDS, 16-query tiles with one
+// live query); this one is bound by the cache read: Tk x 196 x 768 x 2 x 2 B.
+// ================================================================================================
+SF_DEVICE float wave_max_dpp(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <bool F32, int KP>
+__global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, int ntasks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= ntasks) return;
+  const int h = task % p.heads, bn = task / p.heads;
+  const int b = bn / p.N, n = bn % p.N;
+  const int Tk = p.Tk;
+  constexpr int ESZ = F32 ? 4 : 2;
+  constexpr int QL = F32 ? 16 : 8;                 // 16-byte loads per 64-dim row
+  const char* qb = reinterpret_cast<const char*>(p.q);
+  const char* kb = reinterpret_cast<const char*>(p.k);
+  const char* vb = reinterpret_cast<const char*>(p.v);
+  const size_t qoff = ((((size_t)b * p.Tq_cap + p.q_t0) * p.N + n) * p.row_pitch_q + h * HD) * ESZ;
+
+  // ---- issue: q (same 128 / 256 bytes for every lane), this lane's key rows, this lane's V chunks -------------------
+  u32x4_t qv[QL], kv[KP][QL], vv[KP][8][F32 ? 2 : 1];
+#pragma unroll
+  for (int c = 0; c < QL; ++c) qv[c] = *reinterpret_cast<const u32x4_t*>(qb + qoff + c * 16);
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) {
+    int key = kp * 64 + lane;
+    key = key < Tk ? key : Tk - 1;                 // clamped rows are masked below
+    const size_t off = ((((size_t)b * p.Tcap + key) * p.N + n) * p.row_pitch_kv + h * HD) * ESZ;
+#pragma unroll
+    for (int c = 0; c < QL; ++c) kv[kp][c] = *reinterpret_cast<const u32x4_t*>(kb + off + c * 16);
+  }
+  const int tsub = lane >> 3, ch = lane & 7;       // P V layout: key = 8 i + tsub, d = 8 ch .. 8 ch + 7
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int key = kp * 64 + i * 8 + tsub;
+      key = key < Tk ? key : Tk - 1;
+      const size_t off = ((((size_t)b * p.Tcap + key) * p.N + n) * p.row_pitch_kv + h * HD + ch * 8) * ESZ;
+      vv[kp][i][0] = *reinterpret_cast<const u32x4_t*>(vb + off);
+      if (F32) vv[kp][i][F32 ? 1 : 0] = *reinterpret_cast<const u32x4_t*>(vb + off + 16);
+    }
+  __builtin_amdgcn_sched_barrier(0);     // keep every load of the task ahead of the arithmetic (one latency per task)
+
+  // ---- scores -----------------------------------------------------------------------------------------------------
+  const int qpos = p.t_past;                       // absolute frame index of the one query
+  float sc[KP];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < QL; ++c) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (F32) {
+          a0 = fmaf(__uint_as_float(qv[c][j]), __uint_as_float(kv[kp][c][j]), a0);
+        } else {
+          a0 = fmaf(bf2f(qv[c][j] & 0xffffu), bf2f(kv[kp][c][j] & 0xffffu), a0);
+          a1 = fmaf(__uint_as_float(qv[c][j] & 0xffff0000u), __uint_as_float(kv[kp][c][j] & 0xffff0000u), a1);
+        }
+      }
+    }
+    const int key = kp * 64 + lane;
+    const bool ok = key < Tk && (!p.causal || key <= qpos);
+    sc[kp] = ok ? (a0 + a1) : -INFINITY;
+    mx = fmaxf(mx, sc[kp]);
+  }
+  mx = wave_max_dpp(mx);
+  const float c2 = p.scale * 1.44269504088896340736f;
+  float pr[KP], sum = 0.f;
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) {
+    const float a = (sc[kp] - mx) * c2;
+    pr[kp] = F32 ? exp2f(a) : __builtin_amdgcn_exp2f(a);       // masked: 2^-inf = 0
+    sum += pr[kp];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+
+  // ---- P V ----------------------------------------------------------------------------------------------------------
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float pt = __shfl(pr[kp], i * 8 + tsub, 64);          // probability of key kp*64 + 8 i + tsub
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (F32) {
+          o[j] = fmaf(pt, __uint_as_float(vv[kp][i][0][j]), o[j]);
+          o[4 + j] = fmaf(pt, __uint_as_float(vv[kp][i][F32 ? 1 : 0][j]), o[4 + j]);
+        } else {
+          o[2 * j] = fmaf(pt, bf2f(vv[kp][i][0][j] & 0xffffu), o[2 * j]);
+          o[2 * j + 1] = fmaf(pt, __uint_as_float(vv[kp][i][0][j] & 0xffff0000u), o[2 * j + 1]);
+        }
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    o[j] += __shfl_xor(o[j], 8, 64);
+    o[j] += __shfl_xor(o[j], 16, 64);
+    o[j] += __shfl_xor(o[j], 32, 64);
+  }
+  if (tsub == 0) {
+    const size_t o_off = (((size_t)b * p.Tq) * p.N + n) * p.D + h * HD + ch * 8;
+    unsigned int hb[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf(o[j] * inv, hb[j], lb[j]);
+    *reinterpret_cast<u32x4_t*>(p.ctx_hi + o_off) = (u32x4_t){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+    if (F32) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = (u32x4_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+  }
+}
+
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.Tq <= 0 || a.Tk <= 0 || a.B <= 0 || a.N <= 0) return hipErrorInvalidValue;
+  static const bool decode_off = getenv("SF_DISABLE_TEMPORAL_DECODE") != nullptr;
+  if (a.Tq == 1 && a.Tk <= 256 && !decode_off) {        // one new frame per stream: the matrix-vector kernel
+    const int ntasks = a.B * a.N * a.heads;
+    const dim3 grid((ntasks + 3) / 4), block(256);
+    const int kp = (a.Tk + 63) >> 6;
+#define SF_TD(F, KPV) hipLaunchKernelGGL((sf_temporal_decode_kernel<F, KPV>), grid, block, 0, s, a, ntasks)
+    if (accurate) { if (kp <= 1) SF_TD(true, 1); else if (kp <= 2) SF_TD(true, 2); else SF_TD(true, 4); }
+    else { if (kp <= 1) SF_TD(false, 1); else if (kp <= 2) SF_TD(false, 2); else SF_TD(false, 4); }
+#undef SF_TD
+    return hipGetLastError();
+  }
   const int tkp = (a.Tk + 31) & ~31;
   if (tkp > 32 * 8) return hipErrorInvalidValue;   // <= 256 cached frames per stream
   const int vp = vt_pitch(tkp);

@@ -84,6 +84,7 @@ struct sf_encoder {
   DevLN post_ln, head_ln;
   DevLinear head_kv, head_out, head_fc1, head_fc2;
   float* head_q = nullptr;    // [D] probe query, projected and scaled
+  bf16_t* head_q_bf = nullptr; // the same rounded to bf16 (storage type of the bf16-mode k / v it meets in the decode kernel)
   size_t weight_bytes = 0;
   uint64_t generation = 0;    // process-unique id of this handle's current weight packing (bumped by every finalize)
   SfPixelNorm pixel_norm = {{1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f}, {-1.f, -1.f, -1.f, -1.f}};
@@ -432,6 +433,9 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
       q[o] = (float)(acc * sc);
     }
     TRY(dev_upload<float>(e, q, &e->head_q));
+    std::vector<uint16_t> qb(D);
+    for (int o = 0; o < D; ++o) qb[o] = h_f2bf(q[o]);
+    TRY(dev_upload<uint16_t>(e, qb, &e->head_q_bf));
     std::vector<float> wkv(w.begin() + (size_t)D * D, w.end());
     std::vector<float> bkv(b.begin() + D, b.end());
     TRY(upload_linear(e, wkv, &bkv, 2 * D, D, &e->head_kv));
@@ -730,7 +734,21 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     HIP_TRY(sf_launch_split(ws.resid, ws.xn_hi, acc ? ws.xn_lo : nullptr, (size_t)M * D, s));
   if (pooler) {
     HIP_TRY(run_linear(e, e->head_kv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
-    HIP_TRY(sf_launch_pool_attention(e->head_q, ws.qkv, acc, 2 * D, ws.pc_hi, ws.pc_lo, F, N, heads, D, s));
+    static const bool pool_decode_off = getenv("SF_DISABLE_POOL_DECODE") != nullptr;
+    if (N <= 256 && !pool_decode_off) {
+      // one learned query against the N tokens of a frame = the single-query attention of the streaming step with
+      // (stream, patch) -> (frame, -) and the cache -> the frame's tokens: same matrix-vector kernel (sf_temporal_decode_kernel)
+      SfAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = acc ? (const void*)e->head_q : (const void*)e->head_q_bf;      // pre-projected, pre-scaled: scale = 1
+      a.k = ws.qkv; a.v = (char*)ws.qkv + (size_t)D * esz;
+      a.in_is_f32 = acc; a.row_pitch_q = 0; a.row_pitch_kv = 2 * D; a.heads = heads; a.scale = 1.0f;
+      a.N = 1; a.B = F; a.Tq = 1; a.Tk = N; a.Tcap = N; a.t_past = N; a.causal = 0; a.Tq_cap = 0; a.q_t0 = 0;
+      a.ctx_hi = ws.pc_hi; a.ctx_lo = ws.pc_lo; a.D = D;
+      HIP_TRY(sf_launch_temporal_attention(a, acc, s));
+    } else {
+      HIP_TRY(sf_launch_pool_attention(e->head_q, ws.qkv, acc, 2 * D, ws.pc_hi, ws.pc_lo, F, N, heads, D, s));
+    }
     HIP_TRY(run_linear(e, e->head_out, ws.pc_hi, ws.pc_lo, F, SF_EPI_F32, s, ws.attn_out, nullptr, nullptr));
     HIP_TRY(sf_launch_layernorm(ws.attn_out, e->head_ln.g, e->head_ln.b, nullptr, ws.hn_hi, ws.hn_lo, F, D, c.layer_norm_eps, s));
     HIP_TRY(run_linear(e, e->head_fc1, ws.hn_hi, ws.hn_lo, F, SF_EPI_ACT_BF16, s, nullptr, ws.hm_hi, ws.hm_lo));

@@ -67,7 +67,10 @@ SF_DEVICE void sk_ln_finish(float s1, float s2, int K, float eps, float& mean, f
   rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * inv_k - mean * mean, 0.f) + eps);
 }
 
-template <bool SPLIT, int EPI, bool LNF = false>
+// TPS = K-tiles consumed per barrier (1 or 2): the loop is a serial chain of wait -> barrier -> LDS reads -> MFMA, a few
+// hundred cycles per step with two MFMAs of work in it, so halving the step count (12 -> 6 at K = 768) is worth more than
+// the one stage of prefetch depth it costs (STAGES - TPS tiles in flight instead of STAGES - 1).
+template <bool SPLIT, int EPI, bool LNF = false, int TPS = 1>
 __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p) {
   constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);     // hi plane (+ lo plane)
   constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // 16-byte chunks per thread per plane = 2
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   constexpr int PER = LOADS * (SPLIT ? 2 : 1);            // load instructions per stage per thread
   const int mt = wave & 1, nt = wave >> 1;                // this wave's 16x16 output tile
 
-  for (int s = 0; s < SK_STAGES - 1 && s < nkt; ++s) issue(s);
-  for (int kt = 0; kt < nkt; ++kt) {
-    // stage kt complete: at most the later in-flight stages may remain outstanding
-    switch (min(nkt - 1 - kt, SK_STAGES - 2)) {
+  for (int s = 0; s < SK_STAGES - TPS && s < nkt; ++s) issue(s);
+  for (int kt = 0; kt < nkt; kt += TPS) {
+    // tiles kt .. kt+TPS-1 complete: at most the later in-flight tiles may remain outstanding
+    switch (min(nkt - TPS - kt, SK_STAGES - 2 * TPS)) {
       case 6: sk_wait<6 * PER>(); break;
       case 5: sk_wait<5 * PER>(); break;
       case 4: sk_wait<4 * PER>(); break;
@@ -124,22 +127,27 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       default: sk_wait<0>(); break;
     }
     __builtin_amdgcn_s_barrier();
-    if (kt + SK_STAGES - 1 < nkt) issue(kt + SK_STAGES - 1);     // overwrites the stage read in iteration kt-1
-    const char* img = smem + (kt % SK_STAGES) * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kc = ks * 4 + g;
-      const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
-      const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
-      if (LNF) sk_stats(af, ln1, ln2);
-      if (SPLIT) {
-        const char* lo = img + SK_PLANE;
-        const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
-        const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
-        acc = sk_mfma(wl, af, acc);
-        acc = sk_mfma(wf, al, acc);
+    for (int u = 0; u < TPS; ++u)                                  // overwrites the stages read in the previous step
+      if (kt + SK_STAGES - TPS + u < nkt) issue(kt + SK_STAGES - TPS + u);
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      const char* img = smem + ((kt + u) % SK_STAGES) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = ks * 4 + g;
+        const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
+        const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
+        if (LNF) sk_stats(af, ln1, ln2);
+        if (SPLIT) {
+          const char* lo = img + SK_PLANE;
+          const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
+          const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
+          acc = sk_mfma(wl, af, acc);
+          acc = sk_mfma(wf, al, acc);
+        }
+        acc = sk_mfma(wf, af, acc);
       }
-      acc = sk_mfma(wf, af, acc);
     }
   }
   if (LNF) {       // the four k-groups of row l15 (all 64 lanes still active here)
@@ -252,29 +260,40 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   float ln1 = 0.f, ln2 = 0.f;
   const int mt = w4 & 1, nt = w4 >> 1;
-  for (int j = 0; j < SKG_STAGES - 1 && j < mine; ++j) issue(j);
-  for (int j = 0; j < per_grp; ++j) {                    // every group runs per_grp steps: one barrier domain
-    const int later = min(mine - 1 - j, SKG_STAGES - 2);
-    if (later >= 2) sk_wait<2 * PER>(); else if (later == 1) sk_wait<PER>(); else sk_wait<0>();
-    __builtin_amdgcn_s_barrier();
-    if (j + SKG_STAGES - 1 < mine) issue(j + SKG_STAGES - 1);
-    if (j < mine) {
-      const char* img = ring + (j % SKG_STAGES) * STAGE;
+  auto compute = [&](int j) {
+    const char* img = ring + (j % SKG_STAGES) * STAGE;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int kc = ks * 4 + g;
-        const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
-        const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
-        if (LNF) sk_stats(af, ln1, ln2);
-        if (SPLIT) {
-          const char* lo = img + SK_PLANE;
-          const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
-          const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
-          acc = sk_mfma(wl, af, acc);
-          acc = sk_mfma(wf, al, acc);
-        }
-        acc = sk_mfma(wf, af, acc);
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 4 + g;
+      const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
+      const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
+      if (LNF) sk_stats(af, ln1, ln2);
+      if (SPLIT) {
+        const char* lo = img + SK_PLANE;
+        const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
+        const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
+        acc = sk_mfma(wl, af, acc);
+        acc = sk_mfma(wf, al, acc);
       }
+      acc = sk_mfma(wf, af, acc);
+    }
+  };
+  // every group runs the same number of steps (one barrier domain); a step is a serial wait -> barrier -> LDS read -> MFMA
+  // chain of a few hundred cycles.  (Two tiles per step on the 4-stage ring measured slower at K = 3072: it gives up the
+  // prefetch distance.)
+  if (per_grp <= SKG_STAGES) {                           // the whole slice fits the ring (K = 768: 3 tiles): ONE step
+    for (int j = 0; j < mine; ++j) issue(j);
+    sk_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < mine; ++j) compute(j);
+  } else {
+    for (int j = 0; j < SKG_STAGES - 1 && j < mine; ++j) issue(j);
+    for (int j = 0; j < per_grp; ++j) {
+      const int later = min(mine - 1 - j, SKG_STAGES - 2);
+      if (later >= 2) sk_wait<2 * PER>(); else if (later == 1) sk_wait<PER>(); else sk_wait<0>();
+      __builtin_amdgcn_s_barrier();
+      if (j + SKG_STAGES - 1 < mine) issue(j + SKG_STAGES - 1);
+      if (j < mine) compute(j);
     }
   }
   // ---- cross-group reduction through the (now idle) ring of group 0 ------------------------------------
@@ -416,8 +435,26 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, SF_EPI_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
     }
-    if (a.epi == SF_EPI_BF16) hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_BF16, true>), grid, dim3(SK_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true>), grid, dim3(SK_THREADS), lds, s, a);
+    static const int tps_env = getenv("SF_SKINNY_TPS") ? atoi(getenv("SF_SKINNY_TPS")) : 0;
+    const int nkt = a.K / SK_BK;
+    int tps = tps_env ? tps_env : 4;
+    while (tps > 1 && (nkt % tps)) --tps;
+    static SfPerDeviceOnce attr_ln2;
+    if (attr_ln2.first()) {
+#define SK_LNATTR(E, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, E, true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
+      SK_LNATTR(SF_EPI_BF16, 2) SK_LNATTR(SF_EPI_BF16, 3) SK_LNATTR(SF_EPI_BF16, 4)
+      SK_LNATTR(SF_EPI_ACT_BF16, 2) SK_LNATTR(SF_EPI_ACT_BF16, 3) SK_LNATTR(SF_EPI_ACT_BF16, 4)
+#undef SK_LNATTR
+    }
+#define SK_LNGO(E)                                                                                                               \
+    switch (tps) {                                                                                                               \
+      case 4: hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, E, true, 4>), grid, dim3(SK_THREADS), lds, s, a); break;          \
+      case 3: hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, E, true, 3>), grid, dim3(SK_THREADS), lds, s, a); break;          \
+      case 2: hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, E, true, 2>), grid, dim3(SK_THREADS), lds, s, a); break;          \
+      default: hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, E, true>), grid, dim3(SK_THREADS), lds, s, a); break;            \
+    }
+    if (a.epi == SF_EPI_BF16) { SK_LNGO(SF_EPI_BF16) } else { SK_LNGO(SF_EPI_ACT_BF16) }
+#undef SK_LNGO
     return hipGetLastError();
   }
   static SfPerDeviceOnce attr_set;
