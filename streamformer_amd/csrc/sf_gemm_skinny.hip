@@ -403,11 +403,17 @@ bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
   return true;
 }
 
-template <bool SPLIT>
+template <bool SPLIT, int TPS>
 static hipError_t sk_launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-#define SK_CASE(E)                                                                               \
-  case E:                                                                                        \
-    hipLaunchKernelGGL((sf_gemm_skinny_kernel<SPLIT, E>), grid, dim3(SK_THREADS), lds, s, a);    \
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
+#define SK_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<SPLIT, E, false, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
+    SK_ATTR(SF_EPI_F32) SK_ATTR(SF_EPI_BF16) SK_ATTR(SF_EPI_ACT_BF16) SK_ATTR(SF_EPI_RESID_F32) SK_ATTR(SF_EPI_EMBED_F32)
+#undef SK_ATTR
+  }
+#define SK_CASE(E)                                                                                           \
+  case E:                                                                                                    \
+    hipLaunchKernelGGL((sf_gemm_skinny_kernel<SPLIT, E, false, TPS>), grid, dim3(SK_THREADS), lds, s, a);    \
     break;
   switch (a.epi) {
     SK_CASE(SF_EPI_F32)
@@ -457,14 +463,7 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s)
 #undef SK_LNGO
     return hipGetLastError();
   }
-  static SfPerDeviceOnce attr_set;
-  if (attr_set.first()) {
-#define SK_ATTR(S, E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
-    SK_ATTR(false, SF_EPI_F32) SK_ATTR(false, SF_EPI_BF16) SK_ATTR(false, SF_EPI_ACT_BF16)
-    SK_ATTR(false, SF_EPI_RESID_F32) SK_ATTR(false, SF_EPI_EMBED_F32)
-    SK_ATTR(true, SF_EPI_F32) SK_ATTR(true, SF_EPI_BF16) SK_ATTR(true, SF_EPI_ACT_BF16)
-    SK_ATTR(true, SF_EPI_RESID_F32) SK_ATTR(true, SF_EPI_EMBED_F32)
-#undef SK_ATTR
-  }
-  return split ? sk_launch_epi<true>(a, grid, lds, s) : sk_launch_epi<false>(a, grid, lds, s);
+  const bool four = ((a.K / SK_BK) % 4) == 0;         // four K-tiles per barrier when the tile count allows
+  if (split) return four ? sk_launch_epi<true, 4>(a, grid, lds, s) : sk_launch_epi<true, 1>(a, grid, lds, s);
+  return four ? sk_launch_epi<false, 4>(a, grid, lds, s) : sk_launch_epi<false, 1>(a, grid, lds, s);
 }
