@@ -10,8 +10,9 @@ collective ("scaling": "weak"); the only collectives here are the start/stop bar
 max-over-ranks reduction of the elapsed time.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel (MLP up-projection GEMM, MFMA-bound): algorithmic FLOPs / launch
-                over its mean launch time measured with HIP events on the launch stream
+  roofline      the dominant kernel of the forward (sf_gemm_panel_kernel, the N = 768 residual projections: ~38 % of kernel
+                time, MFMA-bound at K = 3072, HBM-bound at K = 768): algorithmic FLOPs of its three launches per layer over
+                their launch times measured with HIP events on the launch stream; the 256^2 kernel's shapes under other_gemms
   attention     the two attention kernels against the HBM roofline ("fraction of the attention roofline")
   accuracy      max-abs deviation of last_hidden_state / pooler_output vs the CPU oracle, both modes
   accurate_mode frames/s of the fp32-accurate (bf16x3) mode on the same workload
@@ -308,20 +309,40 @@ def main():
             nat.check(nat.lib.sf_bench_gemm(model._handle, M, which, 20, ws.data_ptr(), ws.numel(), stream,
                                             nat.C.byref(ms), nat.C.byref(fl)))
             gemms[name] = {"ms": round(ms.value, 4), "tflops": round(fl.value / ms.value / 1e9, 1)}
-        up = gemms["mlp_up"]
-        traffic = None
+        # The kernel with the largest share of the forward (in-forward rocprof profile, profiles/r02_forward_kernel_stats.txt)
+        # is sf_gemm_panel_kernel: per layer two K = 768 launches (temporal / spatial attention output projection) and one
+        # K = 3072 launch (MLP down-projection), each with the fp32 residual read-modify-write, the bf16 copy and the
+        # LayerNorm statistics of the next GEMM in its epilogue.  Its launches are MFMA-work-weighted here exactly as the
+        # forward runs them: achieved = algorithmic FLOPs of (2 x out_proj + 1 x mlp_down) / their summed launch times.
+        L = cfg.num_hidden_layers
+        panel_flop = (2 * 2.0 * M * 768 * 768 + 2.0 * M * 768 * 3072)               # per layer
+        panel_ms = 2 * gemms["out_proj"]["ms"] + gemms["mlp_down"]["ms"]
+        panel_tflops = panel_flop / panel_ms / 1e9
+        traffic, traffic_note = None, "no PMC file"
         try:   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)["kernels"]
-            traffic = next(v["traffic_bytes_corrected"] for k, v in pmc.items() if k.startswith("void sf_gemm256_kernel<2, true"))
-        except Exception:
-            pass
-        out["roofline"] = {"kernel": "sf_gemm256_kernel<SF_EPI_ACT_BF16, LN-folded> (LayerNorm + MLP up-projection + erf-GELU, M=%d N=3072 K=768)" % M,
-                           "bound": "mfma", "achieved": up["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(up["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                           "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (profiles/r01_pmc_traffic.json, separate --pmc passes; "
-                                           "FETCH includes Infinity-Cache hits); algorithmic bytes/launch = 197e6 (A 38.5 + W 4.7 + C 154 MB)",
-                           "avg_launch_ms": up["ms"], "other_gemms": gemms}
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            tr = next(v["traffic_bytes_corrected"] for k, v in pmc["kernels"].items() if k.startswith("void sf_gemm_panel_kernel<13>"))
+            import hashlib
+            hsrc = hashlib.sha256(open(os.path.join(ROOT, "streamformer_amd", "csrc", "sf_gemm_panel.hip"), "rb").read()).hexdigest()[:16]
+            if pmc.get("panel_source_sha16") == hsrc:
+                traffic = tr
+                traffic_note = ("bytes/launch, mean over the panel launches of a forward = 2*FETCH_SIZE + WRITE_SIZE (profiles/r02_pmc_traffic.json, "
+                                "separate --pmc passes; FETCH includes Infinity-Cache hits); algorithmic bytes/launch: 231e6 at K = 768 "
+                                "(A 38.5 + W 1.2 + fp32 residual in/out 154 + bf16 copy 38.5 MB), 346e6 at K = 3072")
+            else:
+                traffic_note = "profiles/r02_pmc_traffic.json was taken on an older sf_gemm_panel.hip: traffic withheld until the PMC passes are re-run"
+        except Exception as e:
+            traffic_note = f"PMC file unreadable: {e!r}"
+        out["roofline"] = {"kernel": "sf_gemm_panel_kernel<13> (N = 768 residual projections: 2 x attention out-proj K=768 + MLP down-proj K=3072 per layer, "
+                                     "epilogue = fp32 residual RMW + bf16 copy + LayerNorm row sums; M=%d)" % M,
+                           "bound": "mfma", "achieved": round(panel_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(panel_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                           "avg_launch_ms": round(panel_ms / 3, 4), "share_of_forward_kernel_time": "~38 % (rocprof)",
+                           "launches": {"out_proj_K768": gemms["out_proj"], "mlp_down_K3072": gemms["mlp_down"]},
+                           "hbm_view_K768": {"algorithmic_GB": 0.2312, "GBps": round(0.2312 / gemms["out_proj"]["ms"] * 1e3, 1),
+                                             "frac_of_hbm_peak": round(0.2312 / gemms["out_proj"]["ms"] * 1e3 / PEAK_HBM_GBS, 4)},
+                           "other_gemms": {"mlp_up": gemms["mlp_up"], "qkv": gemms["qkv"]}}
         by = nat.C.c_double()
         att = {}
         for which, name in ((0, "spatial"), (1, "temporal")):

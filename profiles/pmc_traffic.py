@@ -37,7 +37,10 @@ def main(df, dw):
         wk = w[k][0] / max(w[k][1], 1)
         out[k[:110]] = {"FETCH_SIZE_KB_avg": round(fk, 1), "dispatches": f[k][1] or w[k][1], "WRITE_SIZE_KB_avg": round(wk, 1),
                         "traffic_bytes_corrected": int(2 * fk * 1024 + wk * 1024)}
-    print(json.dumps({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --profile --steps 2 "
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256(open(os.path.join(root, "streamformer_amd", "csrc", "sf_gemm_panel.hip"), "rb").read()).hexdigest()[:16]
+    print(json.dumps({"panel_source_sha16": sha, "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --profile --steps 2 "
                               "--warmup 1, B=8 bf16 mode. Units: KB per dispatch (mean). Correction per MI355X_MICROARCH.md HBM "
                               "section: read_bytes = 2 * FETCH_SIZE * 1024 on gfx950; WRITE_SIZE as is. FETCH counts L2 misses at "
                               "the fabric, Infinity-Cache hits included.", "kernels": out}, indent=1))

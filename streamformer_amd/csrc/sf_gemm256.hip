@@ -357,6 +357,7 @@ static int g256_grid() {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (const char* e = getenv("SF_ASSUME_CUS")) cus = atoi(e);      // experiment: kernels sized for a CU-masked stream
     if (cus < 8) cus = 256;
     cus &= ~7;      // the XCD-aware walk wants a multiple of 8
   }

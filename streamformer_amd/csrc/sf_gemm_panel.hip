@@ -218,6 +218,7 @@ static int panel_cus() {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (const char* e = getenv("SF_ASSUME_CUS")) cus = atoi(e);      // experiment: kernels sized for a CU-masked stream
     if (cus < 16) cus = 256;
     cus &= ~15;
   }
