@@ -3,8 +3,10 @@ outputs.  Tolerances (max-abs), stated once:
 
   * fp32-accurate mode (bf16x3 products): last_hidden_state <= 1e-3 (north_star bound), pooler <= 1e-3;
     measured values are ~1e-4 and the tests also assert a 5e-4 ceiling so regressions show early.
-  * bf16 throughput mode: last_hidden_state <= 6e-2, pooler <= 3e-2 — the error floor of bf16 operands
-    the reference itself shows in pure bf16 (0.08-0.11 / 0.012); cosine >= 0.9995.
+  * bf16 throughput mode: last_hidden_state <= 5e-2 (SURVEY §7's suggestion; measured 2.8-3.4e-2), pooler <= 3e-2 —
+    SURVEY suggested 2e-2 for the pooler, but the measured value at SigLIP-base is 2.1-2.6e-2: the pooled vector sums
+    196 value rows whose bf16 rounding errors add (the reference itself shows 0.08-0.11 / 0.012 in pure bf16,
+    BASELINE.md §2, with weights whose scale differs from the seeded ones here); cosine >= 0.9995.
 """
 import os
 
@@ -21,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 ACC_TOL = 1e-3
 ACC_CEIL = 5e-4
-BF16_LHS, BF16_POOL = 6e-2, 3e-2
+BF16_LHS, BF16_POOL = 5e-2, 3e-2
 
 
 @pytest.fixture(scope="module")
@@ -610,7 +612,7 @@ def test_output_attentions(golden_dir, mode, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 5e-2)])
 def test_submodule_calls_compose_to_the_forward(mode, tol):
     """embeddings -> encoder.layer[i] one by one -> post_layernorm -> head, with the reference's patch-major
     (B, N*T, D) tensors between the calls (adapter / classifier usage), equals model.forward and the oracle."""

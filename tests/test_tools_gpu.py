@@ -68,7 +68,7 @@ def test_feature_dump_cli_two_shards(tmp_path):
         assert maxabs(torch.from_numpy(got), want) <= 1e-3, name
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 5e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 5e-4), ("bf16", 5e-2)])
 def test_siglip_surgery_on_the_hip_path(golden_dir, mode, tol):
     """f-4 on the GPU: the converted encoder (gate 0 => per-frame SigLIP) against fixture F11 = HF SiglipVisionModel's
     outputs; tanh-GELU (hidden_act code 1) through the GEMM epilogues."""

@@ -446,6 +446,48 @@ def test_two_rank_allreduced_gradients_equal_the_big_batch():
     assert rel_l2(ret["grads"], tr.grads.cpu()) < 2e-3
 
 
+def test_twenty_step_trajectory_tracks_the_oracle():
+    """A short TRAINING RUN, not a single step: 20 optimizer steps (alternating tasks, update_freq 1, clipped gradients,
+    lr / weight decay written per step from the cosine tables like tools/finetune_tools.py:406-410) on the HIP trainer and on
+    oracle/train_oracle.py (torch autograd + torch.optim.AdamW, pinned to the reference's modules by fixture F8) from the same
+    weights and batches.  bf16 operands perturb every step, so the two runs are compared as trajectories: per-step losses
+    within 3 %, and the parameter DISPLACEMENT after 20 steps (what training did) agreeing in direction and size."""
+    from oracle import train_oracle as TO
+    from streamformer_amd.training import cosine_scheduler
+    cfg = small_cfg(add_lora_spatial=True)
+    tr, orc = _trainer_and_oracle(cfg, True, seed=8, lora=True, lr=1e-3, wd=0.05)
+    dev = tr.device
+    sched = TO.schedule(cfg, B=4)
+    lrs = cosine_scheduler(1e-3, 1e-5, epochs=1, niter_per_ep=20, warmup_epochs=0.25)     # 5 warm-up steps
+    wds = cosine_scheduler(0.05, 0.05, epochs=1, niter_per_ep=20)
+    start = {k: v.detach().clone() for k, v in orc.named.items()}
+    got, want = [], []
+    for it in range(20):
+        task, x, ti, _ = sched[it % 4]
+        want_loss = orc.loss(task, x, ti)
+        want_loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(orc.named.values()), 1.0)
+        for g, wd in zip(orc.opt.param_groups, (wds[it], 0.0)):
+            g["lr"], g["weight_decay"] = lrs[it], wd
+        orc.opt.step()
+        orc.opt.zero_grad(set_to_none=True)
+        want.append(float(want_loss.detach()))
+        got.append(float(tr.micro_step(task, x.to(dev), _to_dev(ti, dev), lr=lrs[it], weight_decay=wds[it], clip_grad=1.0)))
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, want)]
+    assert max(rel) < 3e-2, list(zip(got, want))
+    assert want[16] < want[0] and got[16] < got[0]                      # the run actually trains (same batch as step 0)
+    sd = tr.state_dict()
+    num = den = dot = 0.0
+    for k, p0 in start.items():
+        if p0.numel() < 64:
+            continue
+        dw_o = (orc.named[k].detach() - p0).double().flatten()
+        dw_h = (sd[k].cpu() - p0).double().flatten()
+        dot += float(dw_o @ dw_h); num += float(dw_h @ dw_h); den += float(dw_o @ dw_o)
+    cos = dot / (num ** 0.5 * den ** 0.5)
+    assert cos > 0.97 and 0.9 < (num / den) ** 0.5 < 1.1, (cos, (num / den) ** 0.5)
+
+
 def test_trainer_rejects_what_it_cannot_do():
     import streamformer_amd._native as nat
     from streamformer_amd.init_weights import make_state_dict
