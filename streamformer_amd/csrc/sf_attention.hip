@@ -331,6 +331,181 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_kernel(SfAttnAr
 }
 
 // ================================================================================================
+// spatial attention, bf16 throughput mode, round 2: the same (frame, head) problem with NO register staging.
+//   * K and V go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, whole 128-byte rows) as plain row-major
+//     [key][64] images, 16-byte chunks XOR-swizzled on the SOURCE side (a DMA writes lane-linearly); no VALU, no
+//     VGPRs, and the loads of the next workgroup on the CU overlap the arithmetic of this one;
+//   * V is never transposed in memory: the A operand of O^T = V^T P^T (lane = head-dim column, k = 8 keys) comes
+//     from the row-major image by ds_read_b64_tr_b16 (a 16-lane group reads a [4 x 16] block and receives it transposed);
+//     its k order — keys {4g..4g+3} of one 16-key tile and {4g..4g+3} of the next — is exactly how the S^T = K Q^T
+//     result tiles sit in the lane (4 consecutive keys per 16-key tile), so K rows are read in NATURAL order and P never
+//     touches LDS.  (Round 1 transposed V on its way into LDS with 8 dword writes per item and permuted the K rows:
+//     19 of the kernel's 57 us at B = 8 were staging.)
+// Used unless the probabilities (output_attentions) or the fp32-accurate mode are requested.
+// ================================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef const __attribute__((address_space(1))) void* sp_gptr_t;
+typedef __attribute__((address_space(3))) void* sp_lptr_t;
+
+// chunk swizzle of the row-major images (same as sf_attention_bwd.hip): bijective in row bits 1..3 (row fragments of 16
+// rows conflict-free), upper two bits bijective in row bits 1..2 (the 8 rows of a half-wave transposed read)
+SF_DEVICE int sp_bswz(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
+SF_DEVICE int sp_img_off(int row, int chunk) { return row * 128 + ((chunk ^ sp_bswz(row)) << 4); }
+SF_DEVICE bf16x8_t sp_row_frag(const char* img, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8_t*>(img + sp_img_off(row, chunk));
+}
+// token-major fragment: lane (l15 = column e of head-dim tile et, g) gets rows {r0+4g..+3} and {r0+16+4g..+3}
+SF_DEVICE bf16x8_t sp_tr_frag(const char* img, int r0, int et, int lane) {
+  const int t16 = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * g + (t16 >> 2);
+  const int off = sp_img_off(row, 2 * et + ((t16 & 3) >> 1)) + ((t16 & 1) << 3);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + off));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + off + 16 * 128));
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+template <int MAXNT>       // 16-key tiles held in registers: 14 -> N <= 224
+__global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAttnArgs p, int qsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int fhq = blockIdx.x / qsplit, qs = blockIdx.x % qsplit;
+  const int frame = fhq / p.heads, h = fhq % p.heads;
+  const int N = p.N;
+  const int nkp = (N + 31) & ~31;                        // keys padded to whole 32-key pairs of tiles
+  const int nt = nkp >> 4;
+  char* k_img = smem;
+  char* v_img = k_img + nkp * 128;
+  char* o_st = v_img + nkp * 128 + wave * 2048;          // per-wave [16 rows][128 B]
+  const size_t row0 = (size_t)frame * N;
+  const int nqt = (N + 15) >> 4;
+  const int tpw = (nqt + qsplit - 1) / qsplit;
+  auto tile_of = [&](int u) -> int {
+    if (qsplit == 1) return wave + u * SP_WAVES;
+    return (u == 0 && wave < tpw) ? qs * tpw + wave : -1;
+  };
+
+  // ---- K / V images by LDS-DMA: instruction j covers rows 8j .. 8j+7 (lane -> row 8j + lane/8, slot lane%8) -------------
+  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(p.k) + h * HD;
+  const bf16_t* vbase = reinterpret_cast<const bf16_t*>(p.v) + h * HD;
+  for (int j = wave; j < (nkp >> 3); j += SP_WAVES) {
+    const int row = j * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ sp_bswz(row);         // the slot this lane fills holds logical chunk `chunk`
+    const int key = row < N ? row : N - 1;               // padding rows repeat the last key (masked in the softmax, P = 0 for V)
+    const size_t src = (row0 + key) * (size_t)p.row_pitch_kv + chunk * 8;
+    __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + src), (sp_lptr_t)(k_img + j * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + src), (sp_lptr_t)(v_img + j * 1024), 16, 0, 0);
+  }
+  // ---- Q fragments of this wave's query tiles (register loads, in flight with the DMA) -------------------------------
+  bf16x8_t qh[SP_QT][2];
+#pragma unroll
+  for (int u = 0; u < SP_QT; ++u) {
+    const int qt_u = tile_of(u);
+    if (qt_u < 0) continue;
+    int qi = qt_u * 16 + l15;
+    qi = qi < N ? qi : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qh[u][ks] = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16_t*>(p.q) + (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c2 = p.scale * 1.44269504088896340736f;
+#pragma unroll
+  for (int u = 0; u < SP_QT; ++u) {
+    const int qt = tile_of(u);
+    if (qt < 0 || qt >= nqt) continue;
+    // ---- S^T = K Q^T, natural key order: lane (query l15, g) holds keys 16 jt + 4 g + r ---------------------------------
+    f32x4_t s[MAXNT];
+#pragma unroll
+    for (int jt = 0; jt < MAXNT; ++jt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      if (jt < nt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = mfma16(sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g), qh[u][ks], acc);
+      }
+      s[jt] = acc;
+    }
+    // mask + row maximum in a SECOND pass over the finished tiles.  Taking the maximum of a tile right behind its MFMA
+    // (v_max on the accumulator VGPRs two instructions after v_mfma_f32_16x16x32_bf16) gave run-to-run different maxima on
+    // gfx950 / hipcc 7.2 — the VALU read of a still-in-flight MFMA result; results stayed within tolerance (softmax is
+    // shift-invariant) but were not bit-reproducible.  Here every tile is read long after its last MFMA issued.
+    __builtin_amdgcn_sched_barrier(0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < MAXNT; ++jt) {
+      if (jt < nt) {
+        if (jt * 16 + 16 > N) {                           // tiles that can hold padding keys
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (jt * 16 + 4 * g + r >= N) s[jt][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, fmaxf(fmaxf(s[jt][0], s[jt][1]), fmaxf(s[jt][2], s[jt][3])));
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c2;
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MAXNT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = 0.f;
+        if (jt < nt) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
+        s[jt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (p.lse2_out && g == 0) {        // training forward: base-2 log-sum-exp of the scaled scores, kept for the backward kernel
+      const int qi = qt * 16 + l15;
+      if (qi < N) p.lse2_out[((size_t)frame * p.heads + h) * N + qi] = mc + __log2f(sum);
+    }
+
+    // ---- O^T = V^T P^T: 32 keys per step, V^T fragments by transposed reads of the row-major image ------------------------
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j2 = 0; j2 < MAXNT / 2; ++j2) {
+      if (2 * j2 < nt) {
+        const u32x4_t pu = {pack_bf2(s[2 * j2][0], s[2 * j2][1]), pack_bf2(s[2 * j2][2], s[2 * j2][3]),
+                            pack_bf2(s[2 * j2 + 1][0], s[2 * j2 + 1][1]), pack_bf2(s[2 * j2 + 1][2], s[2 * j2 + 1][3])};
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(sp_tr_frag(v_img, j2 * 32, dt, lane), pf, o[dt]);
+      }
+    }
+    // ---- context rows: lane holds d = dt*16 + g*4 .. +4 of query l15 -> per-wave LDS patch -> whole 128-byte rows ---------
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
+      *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = it * 64 + lane;
+      const int r = idx >> 3, c = idx & 7;
+      const int qi = qt * 16 + r;
+      if (qi < N)
+        *reinterpret_cast<u32x4_t*>(p.ctx_hi + (row0 + qi) * p.D + h * HD + c * 8) = *reinterpret_cast<const u32x4_t*>(o_st + r * 128 + ((c ^ (r & 7)) << 4));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ================================================================================================
 // spatial attention for N > 224 tokens per frame (higher-resolution inputs, modeling:380-411 resizes
 // the position table): block = (frame, head, block of 128 queries), 8 waves = one 16-query tile each;
 // keys stream through LDS in chunks of 128 (K rows + V^T, same images and swizzles as above) with the
@@ -552,6 +727,15 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  static const bool dma_off = getenv("SF_DISABLE_SPATIAL_DMA") != nullptr;
+  if (!accurate && !a.probs && !dma_off && (a.row_pitch_kv % 8) == 0) {
+    const size_t lds2 = (size_t)nkp * 256 + SP_WAVES * 2048;
+    static SfPerDeviceOnce attr2;
+    if (attr2.first())
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14>), grid, block, lds2, s, a, qsplit);
+    return hipGetLastError();
   }
   if (accurate) hipLaunchKernelGGL((sf_spatial_attn_kernel<true, 7>), grid, block, lds, s, a, vp, qsplit);
   else hipLaunchKernelGGL((sf_spatial_attn_kernel<false, 7>), grid, block, lds, s, a, vp, qsplit);
