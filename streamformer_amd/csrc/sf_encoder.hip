@@ -610,7 +610,10 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
                        float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
                        const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
                        hipStream_t s, float* attentions = nullptr, int stages = 7, int la = 0, int lb = -1,
-                       bool patches_ready = false) {
+                       int ready = 0) {
+  // ready: 1 = the patch matrix is already in the workspace (the streaming entry extracts it outside its graph),
+  //        2 = ws.res_bf already holds bf16(residual) (a later layer range of the same call)
+  const bool patches_ready = (ready & 1) != 0;
   // stages: 1 = embeddings -> ws.resid, 2 = layers [la, lb) on ws.resid, 4 = post-LayerNorm + pooling head,
   // 8 = pooling head alone on already-normalised tokens in ws.resid
   // (the sub-module entry points run them one at a time on a caller-owned residual stream)
@@ -674,7 +677,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const bf16_t* ln_in = sfold ? ws.res_bf : ws.xn_hi;       // A operand of the three LayerNorm'd Linears
   const bool anyfold = fold || sfold;
   if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
-  if (sfold && (stages & 2) && !(stages & 1)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
+  if (sfold && (stages & 2) && !(stages & 1) && !(ready & 2)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
   for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];
     if (hidden_states)
@@ -959,7 +962,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
       // first call of this cache: run eagerly once so that every lazy per-kernel set-up (hipFuncSetAttribute, device
       // queries) has happened before a capture is opened
       rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws, c->qkv.data(),
-                       c->cap, c->len, true, s, nullptr, 7, 0, -1, true);
+                       c->cap, c->len, true, s, nullptr, 7, 0, -1, 1);
       if (rc == SF_OK) { c->len += T_new; c->warmed = true; }
       c->graphs.erase(key);
       return rc;
@@ -968,7 +971,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     if (!c->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
     rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
-                     ws, c->qkv.data(), c->cap, c->len, true, c->cap_stream, nullptr, 7, 0, -1, true);
+                     ws, c->qkv.data(), c->cap, c->len, true, c->cap_stream, nullptr, 7, 0, -1, 1);
     hipError_t ce = hipStreamEndCapture(c->cap_stream, &graph);
     if (rc != SF_OK || ce != hipSuccess || !graph) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -984,6 +987,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     }
     g.ws = workspace; g.pos = pos_dev; g.pooler = pooler != nullptr;
   }
+  // (Launching the embedding + first layers eagerly to cover the replay's host-side submit time measured no gain: 0.78 vs 0.77 ms.)
   HIP_TRY(hipGraphLaunch(g.exec, s));
   HIP_TRY(sf_launch_copy2(ws.lhs_stage, last_hidden, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, pooler, (size_t)F * e->D, s));
   c->len += T_new;
