@@ -719,7 +719,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
     else if (fh <= 64) qsplit = (nqt + 3) / 4;
     else if (fh <= 128) qsplit = (nqt + 7) / 8;
     static const char* env = getenv("SF_SPATIAL_TPW");   // tuning: query tiles per workgroup
-    if (env && fh <= 128) qsplit = (nqt + atoi(env) - 1) / atoi(env);
+    if (env) qsplit = (nqt + atoi(env) - 1) / atoi(env);
     if (qsplit < 1) qsplit = 1;
   }
   const dim3 grid(a.frames * a.heads * qsplit), block(SP_WAVES * 64);
