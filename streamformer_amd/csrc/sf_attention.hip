@@ -904,6 +904,110 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int
 }
 
 // ================================================================================================
+// temporal attention, bf16 mode, short sequences (Tq <= 16 queries against Tk <= 32 cached frames: every full 16-frame
+// clip): the round-2 staging of the spatial kernel applied to the per-(patch, head) problem.  One wave per task; K and
+// V rows (one 128-byte line per frame) go global -> LDS by LDS-DMA as row-major images, K fragments are plain row reads,
+// V^T fragments transposed reads (ds_read_b64_tr_b16), natural key order, P stays in registers.  The MFMA kernel above
+// keeps the long caches, the accurate mode and T_new > 16.
+// ================================================================================================
+__global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p, int ntasks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= ntasks) return;
+  const int h = task % p.heads, bn = task / p.heads;
+  const int b = bn / p.N, n = bn % p.N;
+  const int Tk = p.Tk, Tq = p.Tq;
+  char* k_img = smem + wave * 10240;          // [32 rows][128 B]
+  char* v_img = k_img + 4096;                 // [32 rows][128 B]
+  char* o_st = v_img + 4096;                  // [16 rows][128 B]
+  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(p.k) + h * HD;
+  const bf16_t* vbase = reinterpret_cast<const bf16_t*>(p.v) + h * HD;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {               // instruction j covers frames 8j .. 8j+7
+    const int row = j * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ sp_bswz(row);
+    const int key = row < Tk ? row : Tk - 1;  // padding rows repeat the last frame (masked below)
+    const size_t src = (((size_t)b * p.Tcap + key) * p.N + n) * (size_t)p.row_pitch_kv + chunk * 8;
+    __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + src), (sp_lptr_t)(k_img + j * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + src), (sp_lptr_t)(v_img + j * 1024), 16, 0, 0);
+  }
+  bf16x8_t qf[2];
+  {
+    const int t = l15 < Tq ? l15 : Tq - 1;
+    const size_t qrow = ((size_t)b * p.Tq_cap + p.q_t0 + t) * p.N + n;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16_t*>(p.q) + qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();            // the images are wave-private: no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // S^T = K Q^T: lane (query l15, g) holds keys 16 jt + 4 g + r
+  f32x4_t s[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) acc = mfma16(sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g), qf[ks], acc);
+    s[jt] = acc;
+  }
+  __builtin_amdgcn_sched_barrier(0);          // mask / maximum only after both tiles' MFMAs (see the spatial kernel)
+  const int qpos = p.t_past + l15;            // absolute frame of this lane's query
+  const int causal = p.causal;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = jt * 16 + 4 * g + r;
+      const bool ok = key < Tk && (!causal || key <= qpos);
+      s[jt][r] = ok ? s[jt][r] : -INFINITY;
+      mx = fmaxf(mx, s[jt][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float c2 = p.scale * 1.44269504088896340736f;
+  const float mc = mx * c2;
+  float sum = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
+      s[jt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const u32x4_t pu = {pack_bf2(s[0][0], s[0][1]), pack_bf2(s[0][2], s[0][3]), pack_bf2(s[1][0], s[1][1]), pack_bf2(s[1][2], s[1][3])};
+  const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(sp_tr_frag(v_img, 0, dt, lane), pf, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
+    *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = it * 64 + lane;
+    const int r = idx >> 3, c = idx & 7;
+    if (r < Tq)
+      *reinterpret_cast<u32x4_t*>(p.ctx_hi + (((size_t)b * Tq + r) * p.N + n) * p.D + h * HD + c * 8) =
+          *reinterpret_cast<const u32x4_t*>(o_st + r * 128 + ((c ^ (r & 7)) << 4));
+  }
+}
+
+// ================================================================================================
 // temporal attention of ONE new frame per stream (Tq = 1: the streaming step, vqa_enc:1316-1392 with a
 // single-frame call): a matrix-vector problem per (b, patch, head) — q (64) against Tk cached keys — so there
 // is nothing for the MFMA to do.  One wave per task, plain VALU:
@@ -1045,6 +1149,12 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
     if (accurate) { if (kp <= 1) SF_TD(true, 1); else if (kp <= 2) SF_TD(true, 2); else SF_TD(true, 4); }
     else { if (kp <= 1) SF_TD(false, 1); else if (kp <= 2) SF_TD(false, 2); else SF_TD(false, 4); }
 #undef SF_TD
+    return hipGetLastError();
+  }
+  static const bool tdma_off = getenv("SF_DISABLE_TEMPORAL_DMA") != nullptr;
+  if (!accurate && !tdma_off && a.Tq <= 16 && a.Tk <= 32 && (a.row_pitch_kv % 8) == 0) {     // every full 16-frame clip
+    const int ntasks = a.B * a.N * a.heads;
+    hipLaunchKernelGGL(sf_temporal_attn_dma_kernel, dim3((ntasks + 3) / 4), dim3(256), 4 * 10240, s, a, ntasks);
     return hipGetLastError();
   }
   const int tkp = (a.Tk + 31) & ~31;
