@@ -425,7 +425,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 #pragma unroll
     for (int jt = 0; jt < MAXNT; ++jt) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      if (jt < nt) {
+      if (jt * 16 < N) {                                   // tiles made of padding keys only are never computed
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) acc = mfma16(sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g), qh[u][ks], acc);
       }
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < MAXNT; ++jt) {
-      if (jt < nt) {
-        if (jt * 16 + 16 > N) {                           // tiles that can hold padding keys
+      if (jt * 16 < N) {
+        if (jt * 16 + 16 > N) {                           // the tile that holds the first padding keys
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (jt * 16 + 4 * g + r >= N) s[jt][r] = -INFINITY;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = 0.f;
-        if (jt < nt) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
+        if (jt * 16 < N) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
         s[jt][r] = e;
         sum += e;
       }

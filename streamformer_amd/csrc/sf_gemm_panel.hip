@@ -37,7 +37,7 @@ SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
 }
 
 template <int P_MT>
-__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks) {
+__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks, int dma_in_read) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,6 +119,21 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
   if (half == 1) __builtin_amdgcn_s_barrier();
 
   int t = 0;
+  if (dma_in_read) {
+    // The refill of K-tile t+3 is issued in the wave's READ segment (while the other wave of its SIMD is in its MFMA
+    // segment), not in front of its own MFMAs: five LDS-DMA instructions cost 300-500 issue cycles per phase that the
+    // matrix pipe of the SIMD otherwise sits out.  The slot (that of K-tile t-1) was last read one segment earlier by the
+    // other half; those ds_reads were issued before the barrier this wave has just passed and retire within tens of
+    // cycles, the DMA data arrives after a global-memory latency.
+    for (; t + 3 < nkt; ++t) {
+      reads(t);
+      issue(t + 3);
+      wait_vmp<10>();                   // K-tile t+1 landed (K-tiles t+2, t+3 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      mma();
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
   for (; t + 3 < nkt; ++t) {
     reads(t);
     wait_vmp<5>();                      // K-tile t+1 landed (only K-tile t+2 may be in flight)
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     issue(t + 3);                       // into the slot read in phase t-1
     mma();
     __builtin_amdgcn_s_barrier();
+  }
   }
   // tail: phases nkt-3, nkt-2, nkt-1 (nothing left to issue)
   reads(t); wait_vmp<5>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
@@ -272,11 +288,12 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = sf_wall_clock_ticks(atoi(e));
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
+  static const int dir = getenv("SF_PANEL_DMA_IN_READ") ? atoi(getenv("SF_PANEL_DMA_IN_READ")) : 1;
   switch (pl.mt) {
-    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
-    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
-    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
-    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
+    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
+    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
+    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
   }
   return hipGetLastError();
 }
