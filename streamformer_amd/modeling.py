@@ -207,6 +207,11 @@ class _Node(nn.Module):
     def _bind(self, root: "TimesformerMultiTaskingModelSigLIP") -> None:
         object.__setattr__(self, "_root_ref", weakref.ref(root))      # not a registered sub-module: no cycle
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_root_ref", None)              # weak references do not pickle; the root re-binds its tree in __setstate__
+        return d
+
     @property
     def _root(self) -> "TimesformerMultiTaskingModelSigLIP":
         r = getattr(self, "_root_ref", None)
@@ -471,7 +476,8 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         if assign:
             self._refresh_plist()
         self._force_repack = True
-        return missing, unexpected
+        from torch.nn.modules.module import _IncompatibleKeys      # what nn.Module.load_state_dict returns (also unpacks as a pair)
+        return _IncompatibleKeys(missing, unexpected)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args, config: Optional[StreamformerConfig] = None,
@@ -596,6 +602,28 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         """Force a re-pack of the library's operands on the next forward (needed only after writes the version counters
         cannot see, e.g. through ``param.data``)."""
         self._force_repack = True
+
+    # -------------------------------------------------------------------- copy / pickle (torch.save(model), copy.deepcopy)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_handle"] = None                   # native state is rebuilt from the parameters on first use
+        d["_handle_device"] = None
+        d["_packed_token"] = None
+        d["_force_repack"] = True
+        d["_ws"] = {}
+        d["_pos_cache"] = {}
+        d["_caches"] = None
+        d.pop("_named", None)
+        d.pop("_plist", None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._caches = weakref.WeakSet()
+        for m in self.modules():
+            if isinstance(m, _Node):
+                m._bind(self)
+        self._refresh_plist()
 
     def _release_native(self) -> None:
         for c in list(self._caches):

@@ -122,6 +122,18 @@ def test_module_protocol_without_a_gpu():
     assert tower.device.type == "cpu" and tower.dtype == torch.bfloat16 and tower.is_loaded
     with pytest.raises(OSError, match="no hub access"):
         sa.TimesformerVisionTower("Go2Heart/StreamFormer-timesformer-siglip")
+    # the module copies and pickles like any nn.Module (native state is rebuilt from the parameters on first use)
+    import copy, io
+    m2 = copy.deepcopy(m)
+    assert m2 is not m and m2.encoder.layer[0]._root is m2 and m2.head._root is m2
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3.encoder.layer[1]._root is m3 and set(m3.state_dict()) == set(m.state_dict())
+    res = m3.load_state_dict(m.state_dict())
+    assert res.missing_keys == [] and res.unexpected_keys == [] and tuple(res) == ([], [])
 
 
 def test_model_output_protocol():
