@@ -102,3 +102,20 @@ def test_train_bench_two_ranks_dry_run():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2" and out["allreduce_buckets"] >= 2
     assert all(np.isfinite(v) for v in out["losses_first_last"])
+
+
+def test_forward_bench_two_ranks_dry_run():
+    """bench.py (the headline forward mode) as the driver launches it at N = 2, both ranks on cuda:0 over gloo: clips sharded with
+    no data-path collective, start / stop barriers, max-over-ranks time, whole-job frames/s on the one JSON line."""
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch_clips"] == 16
+    assert out["value"] > 0 and abs(out["value"] - 2 * 8 * 16 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 0.02 * out["value"]
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] <= 1 and "cpu_baseline" not in out   # N = 1 only
