@@ -9,11 +9,11 @@
 // gfx950 structure: 8 waves = 1(M) x 8(N); a wave owns all 13 m-tiles x 3 n-tiles (208 x 48) = 39
 // MFMA 16x16x32 per 32-deep K-tile.  A K-tile is one A piece (256 rows x 64 B, rows past the tile are
 // clamped re-reads) + one W piece (384 x 64 B) = 40 KB, in a 4-slot LDS ring (160 KB: the whole CU).
-// One phase per K-tile: ds_reads -> vmcnt(5) -> barrier -> issue the K-tile three ahead -> 39 MFMA
-// -> barrier, with the two halves of the workgroup staggered by one barrier (one half in its MFMA
-// segment while the other reads).  Hazards by count: a slot is re-staged in the MFMA segment of the
-// phase after its last read (>= the retiring lgkmcnt + one barrier for both halves), and read one
-// phase after the vmcnt that retires it.
+// One phase per K-tile: [refill issue -> ds_reads -> counted vmcnt] -> barrier -> 39 MFMA -> barrier, with the two
+// halves of the workgroup staggered by one barrier (one half in its MFMA segment while the other refills and reads).
+// Hazards by count and distance, see the main loop: a slot is refilled only when every read of it has been consumed by
+// an MFMA segment that has since completed, and read one phase after the vmcnt that retires it.  (Round 1 issued the
+// refill in front of the wave's own MFMAs: 144-146 us per K = 3072 launch against 138-140 us now, same box.)
 #include "sf_common.h"
 #include <cstdlib>
 
@@ -37,7 +37,7 @@ SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
 }
 
 template <int P_MT>
-__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks, int dma_in_read) {
+__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -110,44 +110,51 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: K-tiles 0,1,2 in flight, K-tile 0 landed -----------------------------------------
-  issue(0);
-  issue(1);
-  issue(2);
-  wait_vmp<10>();
-  __builtin_amdgcn_s_barrier();
-  if (half == 1) __builtin_amdgcn_s_barrier();
-
+  // ---- main loop ---------------------------------------------------------------------------------------------------
+  // Two barriers per K-tile; the halves of the workgroup run one barrier apart (half 1 takes an extra barrier first), so
+  // that on every SIMD one wave is in its MFMA segment (39 MFMAs, s_setprio 1) while the other is in its READ segment:
+  // LDS-DMA refill + fragment reads + vmcnt wait.  Round 2: the refill is issued in the read segment, not in front of the
+  // wave's own MFMAs (five DMA instructions cost 300-500 issue cycles that the SIMD's matrix pipe sat out: -4 % per launch;
+  // without the s_setprio the loop is 15 % slower).  A slot may only be refilled once NO ds_read of it can be outstanding
+  // anywhere in the workgroup; with the refill inside a read segment that is guaranteed by the distance, per half:
+  //   half 1 (runs one segment late) refills K-tile t+3 = the slot of K-tile t-1: half 0 read it three segments earlier, half 1
+  //          itself two segments earlier and has since gone through the MFMA segment that consumed those reads;
+  //   half 0 refills K-tile t+2 = the slot of K-tile t-2, read by both halves at least three segments earlier.
+  // (Half 0 refilling K-tile t+3 here could overtake half 1's reads of K-tile t-1 issued just before the barrier: the
+  // timing margin is hundreds of cycles, but it is a margin, not an order.)
   int t = 0;
-  if (dma_in_read) {
-    // The refill of K-tile t+3 is issued in the wave's READ segment (while the other wave of its SIMD is in its MFMA
-    // segment), not in front of its own MFMAs: five LDS-DMA instructions cost 300-500 issue cycles per phase that the
-    // matrix pipe of the SIMD otherwise sits out.  The slot (that of K-tile t-1) was last read one segment earlier by the
-    // other half; those ds_reads were issued before the barrier this wave has just passed and retire within tens of
-    // cycles, the DMA data arrives after a global-memory latency.
+  if (half == 1) {
+    issue(0); issue(1); issue(2);
+    wait_vmp<10>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     for (; t + 3 < nkt; ++t) {
-      reads(t);
       issue(t + 3);
-      wait_vmp<10>();                   // K-tile t+1 landed (K-tiles t+2, t+3 may be in flight)
+      reads(t);
+      wait_vmp<10>();                   // own pieces of K-tile t+1 landed (t+2, t+3 may be in flight)
       __builtin_amdgcn_s_barrier();
       mma();
       __builtin_amdgcn_s_barrier();
     }
+    reads(t); wait_vmp<5>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
+    reads(t); wait_vmp<0>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
+    reads(t); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier();
   } else {
-  for (; t + 3 < nkt; ++t) {
-    reads(t);
-    wait_vmp<5>();                      // K-tile t+1 landed (only K-tile t+2 may be in flight)
+    issue(0); issue(1);
+    wait_vmp<5>();
     __builtin_amdgcn_s_barrier();
-    issue(t + 3);                       // into the slot read in phase t-1
-    mma();
+    for (; t + 2 < nkt; ++t) {
+      issue(t + 2);
+      reads(t);
+      wait_vmp<5>();                    // own pieces of K-tile t+1 landed (t+2 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      mma();
+      __builtin_amdgcn_s_barrier();
+    }
+    reads(t); wait_vmp<0>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
+    reads(t); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
   }
-  }
-  // tail: phases nkt-3, nkt-2, nkt-1 (nothing left to issue)
-  reads(t); wait_vmp<5>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
-  reads(t); wait_vmp<0>(); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier(); ++t;
-  reads(t); __builtin_amdgcn_s_barrier(); mma(); __builtin_amdgcn_s_barrier();
-  if (half == 0) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: stage 64-row groups in LDS as fp32 rows of 384, then whole-row 16-byte I/O --------
   int tid_e = threadIdx.x;
@@ -288,12 +295,11 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = sf_wall_clock_ticks(atoi(e));
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
-  static const int dir = getenv("SF_PANEL_DMA_IN_READ") ? atoi(getenv("SF_PANEL_DMA_IN_READ")) : 1;
   switch (pl.mt) {
-    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
-    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
-    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
-    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger, dir); break;
+    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
   }
   return hipGetLastError();
 }
