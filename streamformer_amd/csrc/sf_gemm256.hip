@@ -35,6 +35,10 @@ SF_DEVICE f32x4_t mfma16b(bf16x8_t a, bf16x8_t b, f32x4_t c) {
 SF_DEVICE bf16x8_t rd_frag(const char* piece, int row, int kc) {
   return *reinterpret_cast<const bf16x8_t*>(piece + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 }
+// bf16x3 (SPLIT) piece: [hi plane | lo plane], each [128 rows][32 k] = 64-byte rows, 16-byte slot XOR (row>>2)&3
+SF_DEVICE bf16x8_t rd_frag_s(const char* piece, int plane, int row, int g) {
+  return *reinterpret_cast<const bf16x8_t*>(piece + plane * 8192 + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+}
 
 template <int N>
 SF_DEVICE void wait_vm() {
@@ -46,7 +50,12 @@ SF_DEVICE void wait_vm() {
 // owns 112 rows: quadrant mq = 0 has 4 m-tiles, mq = 1 has 3 (its A piece is padded with clamped rows).
 #define G256_EPI_BF16_AUX 5     // kernel-internal: SF_EPI_BF16 with the training-step aux epilogue compiled in
 
-template <int EPI, bool LNF, int BM>
+//
+// SPLIT = the fp32-accurate mode (SF_COMPUTE_BF16X3): both operands arrive as hi + lo bf16 planes.  A K-tile is 32
+// wide and a 16 KB piece holds the hi plane and the lo plane of the same [128 rows][32 k] block (one DMA instruction
+// each), so ring, piece order, phase schedule and fragment registers are those of the bf16 kernel with "k-step" read as
+// "plane"; a phase is 24 MFMAs (hi*hi + hi*lo + lo*hi per fragment pair) over the same 12 ds_read_b128 + 2 DMA.
+template <int EPI, bool LNF, int BM, bool SPLIT = false>
 __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles, int stagger_ticks, int stagger_groups) {
   constexpr int HR = BM / 2;                 // rows per wave row
   constexpr int MT1 = (BM == 256) ? 4 : 3;   // m-tiles of the second row quadrant
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
   const int l15 = lane & 15, g = lane >> 4;
   const int tiles_n = p.N >> 8;
   const int K = p.K;
-  const int nkt = K >> 6;   // even, >= 2 (checked by the launcher)
+  const int nkt = SPLIT ? (K >> 5) : (K >> 6);   // even, >= 2 (checked by the launcher)
   const int dma_lds = wave * 1024;   // wave-uniform part of the DMA destination inside a piece
   // persistent, XCD-aware walk: in round r the 32 workgroups of XCD x take 32 consecutive tiles
   // (consecutive tiles share the A row panel, so it is fetched into that XCD's L2 once)
@@ -66,6 +75,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
   // loop carries no 64-bit address arithmetic (each operand is < 4 GiB: checked by the launcher)
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_hi, 0, (unsigned)p.M * (unsigned)K * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, (unsigned)p.N * (unsigned)K * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_al = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? p.a_lo : p.a_hi), 0, (unsigned)p.M * (unsigned)K * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_wl = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? p.w_lo : p.w_hi), 0, (unsigned)p.N * (unsigned)K * 2u, 0x00020000);
   const int cpx = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
 
@@ -93,10 +104,11 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
     int tid_p = threadIdx.x;
     asm volatile("" : "+v"(tid_p));     // recompute per tile instead of carrying (and spilling) invariants
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < (SPLIT ? 1 : 2); ++i) {
       const int c = i * G_THREADS + tid_p;
-      const int prow = c >> 3, slot = c & 7;
-      const int kc = slot ^ ((prow >> 1) & 7);
+      // SPLIT: one 16-byte chunk per lane and plane, the same offset in the hi and the lo array
+      const int prow = SPLIT ? (c >> 2) : (c >> 3), slot = SPLIT ? (c & 3) : (c & 7);
+      const int kc = SPLIT ? (slot ^ ((prow >> 2) & 3)) : (slot ^ ((prow >> 1) & 7));
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         int rr = prow & 63;
@@ -112,9 +124,17 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
     auto issue = [&](int t, int j) {
       char* dst = smem + ((t & 1) * 4 + j) * PIECE_BYTES + dma_lds;
       const unsigned o0 = (j & 1) ? offA[j >> 1][0] : offB[j >> 1][0];
-      const unsigned o1 = (j & 1) ? offA[j >> 1][1] : offB[j >> 1][1];
-      const int kof = t * 128;     // bytes along K: the scalar offset of the buffer load
-      if (j & 1) {
+      const unsigned o1 = (j & 1) ? offA[j >> 1][SPLIT ? 0 : 1] : offB[j >> 1][SPLIT ? 0 : 1];
+      const int kof = SPLIT ? t * 64 : t * 128;     // bytes along K: the scalar offset of the buffer load
+      if (SPLIT) {
+        if (j & 1) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)dst, 16, o0, kof, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_al, (lptr_t)(dst + 8192), 16, o1, kof, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, o0, kof, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_wl, (lptr_t)(dst + 8192), 16, o1, kof, 0, 0);
+        }
+      } else if (j & 1) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)dst, 16, o0, kof, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(dst + 8192), 16, o1, kof, 0, 0);
       } else {
@@ -139,7 +159,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) b[nt][ks] = rd_frag(pc, wn * 32 + nt * 16 + l15, ks * 4 + g);
+        for (int ks = 0; ks < 2; ++ks)
+          b[nt][ks] = SPLIT ? rd_frag_s(pc, ks, wn * 32 + nt * 16 + l15, g) : rd_frag(pc, wn * 32 + nt * 16 + l15, ks * 4 + g);
     };
     auto read_a = [&](int par, int mq) {
       const char* pc = smem + (par * 4 + mq * 2 + 1) * PIECE_BYTES;
@@ -147,17 +168,29 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-          if (mt < (mq ? MT1 : 4)) af[mt][ks] = rd_frag(pc, wm * 64 + mt * 16 + l15, ks * 4 + g);
+          if (mt < (mq ? MT1 : 4))
+            af[mt][ks] = SPLIT ? rd_frag_s(pc, ks, wm * 64 + mt * 16 + l15, g) : rd_frag(pc, wm * 64 + mt * 16 + l15, ks * 4 + g);
     };
     auto mma = [&](int mq, int nq, bf16x8_t (&b)[2][2]) {
       __builtin_amdgcn_s_setprio(1);
+      if (SPLIT) {      // [..][0] = hi plane, [..][1] = lo plane; the two small products first
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+          for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            if (mt < (mq ? MT1 : 4)) acc[mq][nq][mt][nt] = mfma16b(b[nt][ks], af[mt][ks], acc[mq][nq][mt][nt]);
+            for (int nt = 0; nt < 2; ++nt)
+              if (mt < (mq ? MT1 : 4))
+                acc[mq][nq][mt][nt] = mfma16b(b[nt][pr == 0 ? 1 : 0], af[mt][pr == 1 ? 1 : 0], acc[mq][nq][mt][nt]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              if (mt < (mq ? MT1 : 4)) acc[mq][nq][mt][nt] = mfma16b(b[nt][ks], af[mt][ks], acc[mq][nq][mt][nt]);
+      }
       __builtin_amdgcn_s_setprio(0);
     };
 
@@ -241,7 +274,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) lns4[nq][nt] = *reinterpret_cast<const f32x4_t*>(p.ln_s + n0 + wn * 64 + nq * 32 + nt * 16 + g * 4);
     }
-    if (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16 || EPI == G256_EPI_BF16_AUX) {
+    if (!SPLIT && (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16 || EPI == G256_EPI_BF16_AUX)) {
       // [256 rows][32 chunks of 16 B], chunk index XOR (row & 31)
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq)
@@ -300,7 +333,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
       }
       __syncthreads();   // staging reads retired before the next tile's DMA lands in the ring
     } else {
-      // fp32 outputs: two passes of [128 rows][64 chunks of 16 B], chunk index XOR (row & 63)
+      // fp32 outputs (and the hi + lo bf16 planes of the accurate mode, split from the staged fp32 values on the way
+      // out): two passes of [128 rows][64 chunks of 16 B], chunk index XOR (row & 63)
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq) {
 #pragma unroll
@@ -311,23 +345,52 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               const int nl = wn * 64 + nq * 32 + nt * 16 + g * 4;
-              const f32x4_t v = acc[mq][nq][mt][nt] + bias4[nq][nt];
+              f32x4_t v = acc[mq][nq][mt][nt] + bias4[nq][nt];
+              if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = p.act == 0 ? apply_act_fast(v[j], 0) : apply_act(v[j], p.act);   // erf to 1.5e-7 abs (ocml erff costs ~100 us per launch here)
+              }
               *reinterpret_cast<f32x4_t*>(smem + r * 1024 + (((nl >> 2) ^ (r & 63)) << 4)) = v;
             }
         }
         __syncthreads();
+        if (EPI == SF_EPI_BF16 || EPI == SF_EPI_ACT_BF16) {
+          // hi + lo planes: a lane takes 8 columns (two staged chunks) and writes 16 bytes to each plane
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-          const int idx = it * G_THREADS + tid;
-          const int r = idx >> 6, c = idx & 63;
-          f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + ((c ^ (r & 63)) << 4));
-          const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
-          if (m < p.M && (r & 63) < (mq ? MT1 : 4) * 16) {
-            size_t orow = (size_t)m;
-            if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
-            const size_t o = orow * (size_t)p.ldc + n0 + c * 4;
-            if (EPI == SF_EPI_RESID_F32) v = *reinterpret_cast<const f32x4_t*>(p.resid + o) + p.alpha * v;
-            *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+          for (int it = 0; it < 8; ++it) {
+            const int idx = it * G_THREADS + tid;
+            const int r = idx >> 5, c2 = idx & 31;
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + (((2 * c2) ^ (r & 63)) << 4));
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + (((2 * c2 + 1) ^ (r & 63)) << 4));
+            const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
+            if (m < p.M && (r & 63) < (mq ? MT1 : 4) * 16) {
+              size_t orow = (size_t)m;
+              if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+              const size_t o = orow * (size_t)p.ldc + n0 + c2 * 8;
+              u32x4_t h, l;
+              h[0] = pack_bf2(v0[0], v0[1]); h[1] = pack_bf2(v0[2], v0[3]); h[2] = pack_bf2(v1[0], v1[1]); h[3] = pack_bf2(v1[2], v1[3]);
+              l[0] = pack_bf2(v0[0] - bf2f(h[0] & 0xffffu), v0[1] - bf2f(h[0] >> 16));
+              l[1] = pack_bf2(v0[2] - bf2f(h[1] & 0xffffu), v0[3] - bf2f(h[1] >> 16));
+              l[2] = pack_bf2(v1[0] - bf2f(h[2] & 0xffffu), v1[1] - bf2f(h[2] >> 16));
+              l[3] = pack_bf2(v1[2] - bf2f(h[3] & 0xffffu), v1[3] - bf2f(h[3] >> 16));
+              *reinterpret_cast<u32x4_t*>(p.out_hi + o) = h;
+              if (p.out_lo) *reinterpret_cast<u32x4_t*>(p.out_lo + o) = l;
+            }
+          }
+        } else {
+#pragma unroll 4
+          for (int it = 0; it < 16; ++it) {
+            const int idx = it * G_THREADS + tid;
+            const int r = idx >> 6, c = idx & 63;
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + ((c ^ (r & 63)) << 4));
+            const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
+            if (m < p.M && (r & 63) < (mq ? MT1 : 4) * 16) {
+              size_t orow = (size_t)m;
+              if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+              const size_t o = orow * (size_t)p.ldc + n0 + c * 4;
+              if (EPI == SF_EPI_RESID_F32) v = *reinterpret_cast<const f32x4_t*>(p.resid + o) + p.alpha * v;
+              *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+            }
           }
         }
         __syncthreads();
@@ -337,13 +400,16 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 }
 
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
-  if (split) return false;
+  if (split && (!a.a_lo || !a.w_lo || a.ln_stats || a.aux_mode || getenv("SF_DISABLE_G256_SPLIT"))) return false;
   if (a.epi == SF_EPI_EMBED_F32) return false;
-  if (a.epi == SF_EPI_ACT_BF16 && a.act != 0 && a.act != 99) return false;   // other activations: 128^2 kernel
+  if (a.epi == SF_EPI_RESID_F32 && a.out_hi) return false;     // no bf16 copy of the new residual here (panel kernel)
+  if (!split && a.epi == SF_EPI_ACT_BF16 && a.act != 0 && a.act != 99) return false;   // other activations: 128^2 kernel
   if (a.K % 128 || a.K < 128) return false;
-  if (a.N % 256 || a.N < 1024) return false;    // N = 768: 294 tiles on 256 CUs -> the 128^2 kernel wins
+  int min_n = 1024;                             // N = 768: 294 tiles on 256 CUs -> the panel / 128^2 kernels win
+  if (split) { min_n = 768; if (const char* e = getenv("SF_G256_SPLIT_MIN_N")) min_n = atoi(e); }    // bf16x3: 392 / 120 us against 415 / 127 on the 128^2 kernel
+  if (a.N % 256 || a.N < min_n) return false;
   if (a.M < 2048 || (size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return false;                 // small problems: the 128x128 kernel fills the chip better
-  if (a.out_lo) return false;
+  if (a.out_lo && !split) return false;
   return true;
 }
 
@@ -365,7 +431,9 @@ static int g256_grid() {
 }
 
 template <int BM>
-static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
+static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
+  SfGemmArgs a = a_in;
+  if (getenv("SF_G256_LAB_NOSTORE")) a.act = 99;      // lab: main loops only (results are discarded)
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / 256);
   const size_t lds = 8 * PIECE_BYTES;
   static SfPerDeviceOnce attr_set;
@@ -373,6 +441,9 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
 #define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
     SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true) SF_ATTR(G256_EPI_BF16_AUX, false)
+#undef SF_ATTR
+#define SF_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, false, BM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SF_ATTR(SF_EPI_F32) SF_ATTR(SF_EPI_BF16) SF_ATTR(SF_EPI_ACT_BF16) SF_ATTR(SF_EPI_RESID_F32)
 #undef SF_ATTR
   }
   const dim3 grid(g256_grid()), block(G_THREADS);
@@ -391,12 +462,23 @@ static hipError_t launch_bm(const SfGemmArgs& a, hipStream_t s) {
     const char* env = getenv("SF_G256_STAGGER_NS");
     if (env) stagger = sf_wall_clock_ticks(atoi(env));
     else if (rounds >= 3) {
-      const double tile_ns = 2.0 * BM * 256.0 * a.K / 3.9e3 + 6500.0;     // flops / (3.9 TF per CU) + store burst
+      const double mfma_x = (a.a_lo && a.w_lo) ? 3.0 : 1.0;
+      const double tile_ns = mfma_x * 2.0 * BM * 256.0 * a.K / 3.9e3 + 6500.0;     // flops / (3.9 TF per CU) + store burst
       stagger = sf_wall_clock_ticks((int)(tile_ns * pct / 100.0));
     }
   }
   if (const char* only = getenv("SF_G256_STAGGER_ONLY")) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs
     if (a.epi != atoi(only)) stagger = 0;
+  }
+  if (a.a_lo && a.w_lo) {      // fp32-accurate mode: hi + lo planes of both operands, three products per fragment pair
+    if (a.ln_stats || a.aux_mode) return hipErrorInvalidValue;
+    switch (a.epi) {
+#define SF_CASE(E) case E: hipLaunchKernelGGL((sf_gemm256_kernel<E, false, BM, true>), grid, block, lds, s, a, tiles, stagger, sgroups); break;
+      SF_CASE(SF_EPI_F32) SF_CASE(SF_EPI_BF16) SF_CASE(SF_EPI_ACT_BF16) SF_CASE(SF_EPI_RESID_F32)
+#undef SF_CASE
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
   }
   const bool lnf = a.ln_stats != nullptr;
   if (lnf && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return hipErrorInvalidValue;

@@ -99,6 +99,29 @@ def test_op_linear(sa, M, N, K, mode):
     assert maxabs(got, want) <= (tol + (1e-5 if mode else 2e-2))   # bf16 output rounding in mode 0
 
 
+@pytest.mark.parametrize("M,N,K,bm256", [(2300, 1024, 256, False), (2100, 1280, 128, True)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_op_linear_large_tiles(sa, M, N, K, bm256, mode, monkeypatch):
+    """The 256x256 (and 224x256) persistent MFMA kernel incl. its bf16x3 variant (hi + lo planes, three products):
+    ragged M, every epilogue the encoder uses on it."""
+    if bm256:
+        monkeypatch.setenv("SF_G256_NO_BM224", "1")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    if mode == 0:
+        ref = x.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+        tol = 1e-4
+    else:
+        ref = x.double() @ w.double().t() + b.double()
+        tol = 2e-5 * K ** 0.5
+    assert maxabs(_linear(sa, x, w, b, None, 1.0, False, mode), ref) <= tol
+    assert maxabs(_linear(sa, x, w, b, r, 0.37, False, mode), r.double() + 0.37 * ref) <= tol
+    assert maxabs(_linear(sa, x, w, b, None, 1.0, True, mode), torch.nn.functional.gelu(ref)) <= (tol + (1e-5 if mode else 2e-2))
+
+
 def _attention(sa, qkv, groups, L, heads, causal, temporal, ntok, mode):
     nat = sa._native
     D = heads * 64
