@@ -58,7 +58,7 @@ SF_DEVICE void wait_vm() {
 template <int EPI, bool LNF, int BM, bool SPLIT = false>
 __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles, int stagger_ticks, int stagger_groups) {
   constexpr int HR = BM / 2;                 // rows per wave row
-  constexpr int MT1 = (BM == 256) ? 4 : 3;   // m-tiles of the second row quadrant
+  constexpr int MT1 = (HR - 64) / 16;        // m-tiles of the second row quadrant (BM = 256: 4, 224: 3, 192: 2, 160: 1)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -430,7 +430,7 @@ static int g256_grid() {
   return cus;
 }
 
-template <int BM>
+template <int BM, bool SPLIT_ONLY = false>
 static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   SfGemmArgs a = a_in;
   if (getenv("SF_G256_LAB_NOSTORE")) a.act = 99;      // lab: main loops only (results are discarded)
@@ -438,10 +438,12 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   const size_t lds = 8 * PIECE_BYTES;
   static SfPerDeviceOnce attr_set;
   if (attr_set.first()) {
+    if constexpr (!SPLIT_ONLY) {
 #define SF_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, L, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
-    SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true) SF_ATTR(G256_EPI_BF16_AUX, false)
+      SF_ATTR(SF_EPI_F32, false) SF_ATTR(SF_EPI_BF16, false) SF_ATTR(SF_EPI_ACT_BF16, false) SF_ATTR(SF_EPI_RESID_F32, false)
+      SF_ATTR(SF_EPI_BF16, true) SF_ATTR(SF_EPI_ACT_BF16, true) SF_ATTR(G256_EPI_BF16_AUX, false)
 #undef SF_ATTR
+    }
 #define SF_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, false, BM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(SF_EPI_F32) SF_ATTR(SF_EPI_BF16) SF_ATTR(SF_EPI_ACT_BF16) SF_ATTR(SF_EPI_RESID_F32)
 #undef SF_ATTR
@@ -480,6 +482,8 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
     }
     return hipGetLastError();
   }
+  if constexpr (SPLIT_ONLY) return hipErrorInvalidValue;
+  else {
   const bool lnf = a.ln_stats != nullptr;
   if (lnf && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return hipErrorInvalidValue;
   switch (a.epi) {
@@ -499,12 +503,26 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+  }
 }
 
 hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
   // pick the row-tile height that wastes fewer tile slots of the persistent grid
   const int g = g256_grid(), nt = a.N / 256;
   auto cost = [&](int bm) { const int tiles = ((a.M + bm - 1) / bm) * nt; return (long)((tiles + g - 1) / g) * bm; };
+  if (a.a_lo && a.w_lo && !getenv("SF_G256_NO_SHORT_BM")) {
+    // bf16x3 runs N = 768 here too (3 column tiles): shorter row tiles fill the second round of the persistent grid.
+    // A K-tile of the short quadrant costs the read segment of the other wave row, not its own few MFMAs, hence the
+    // per-height time factors (cycles per K-tile: 4 x max(MFMA segment, read segment ~ 350)).
+    auto t = [&](int bm, double f) { return (double)cost(bm) / bm * f; };
+    const double t256 = t(256, 1632), t224 = t(224, 1472), t192 = t(192, 1370), t160 = t(160, 1268);
+    const double best = fmin(fmin(t256, t224), fmin(t192, t160));
+    if (const char* fe = getenv("SF_G256_FORCE_BM")) {
+      switch (atoi(fe)) { case 160: return launch_bm<160, true>(a, s); case 192: return launch_bm<192, true>(a, s); case 224: return launch_bm<224>(a, s); default: return launch_bm<256>(a, s); }
+    }
+    if (best == t160 && t160 < 0.97 * fmin(t224, t256)) return launch_bm<160, true>(a, s);
+    if (best == t192 && t192 < 0.97 * fmin(t224, t256)) return launch_bm<192, true>(a, s);
+  }
   if (cost(224) < cost(256) && !getenv("SF_G256_NO_BM224")) return launch_bm<224>(a, s);   // env: A/B switch
   return launch_bm<256>(a, s);
 }

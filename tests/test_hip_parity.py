@@ -99,13 +99,15 @@ def test_op_linear(sa, M, N, K, mode):
     assert maxabs(got, want) <= (tol + (1e-5 if mode else 2e-2))   # bf16 output rounding in mode 0
 
 
-@pytest.mark.parametrize("M,N,K,bm256", [(2300, 1024, 256, False), (2100, 1280, 128, True)])
+@pytest.mark.parametrize("M,N,K,bm256", [(2300, 1024, 256, False), (2100, 1280, 128, True), (2077, 768, 256, 160), (2500, 768, 128, 192)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_op_linear_large_tiles(sa, M, N, K, bm256, mode, monkeypatch):
     """The 256x256 (and 224x256) persistent MFMA kernel incl. its bf16x3 variant (hi + lo planes, three products):
     ragged M, every epilogue the encoder uses on it."""
-    if bm256:
+    if bm256 is True:
         monkeypatch.setenv("SF_G256_NO_BM224", "1")
+    elif bm256:
+        monkeypatch.setenv("SF_G256_FORCE_BM", str(bm256))        # the short row tiles of the bf16x3 variant
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) * K ** -0.5
