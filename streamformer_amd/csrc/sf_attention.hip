@@ -368,7 +368,10 @@ SF_DEVICE bf16x8_t sp_tr_frag(const char* img, int r0, int et, int lane) {
   return f;
 }
 
-template <int MAXNT>       // 16-key tiles held in registers: 14 -> N <= 224
+// ACC = the fp32-accurate mode on the same structure: q / k / v arrive as hi + lo bf16 planes (the qkv GEMM writes them
+// instead of fp32, same bytes), four images (K hi, V hi, K lo, V lo) land by DMA, every product is three MFMAs
+// (lo*hi + hi*lo + hi*hi) and the probabilities are split into hi + lo in registers.
+template <int MAXNT, bool ACC>       // 16-key tiles held in registers: 14 -> N <= 224
 __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAttnArgs p, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -380,7 +383,9 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
   const int nt = nkp >> 4;
   char* k_img = smem;
   char* v_img = k_img + nkp * 128;
-  char* o_st = v_img + nkp * 128 + wave * 2048;          // per-wave [16 rows][128 B]
+  char* kl_img = v_img + nkp * 128;                      // ACC only
+  char* vl_img = kl_img + nkp * 128;
+  char* o_st = v_img + nkp * 128 * (ACC ? 3 : 1) + wave * (ACC ? 4096 : 2048);          // per-wave [16 rows][128 B] (hi [, lo])
   const size_t row0 = (size_t)frame * N;
   const int nqt = (N + 15) >> 4;
   const int tpw = (nqt + qsplit - 1) / qsplit;
@@ -399,9 +404,13 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
     const size_t src = (row0 + key) * (size_t)p.row_pitch_kv + chunk * 8;
     __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + src), (sp_lptr_t)(k_img + j * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + src), (sp_lptr_t)(v_img + j * 1024), 16, 0, 0);
+    if (ACC) {
+      __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + p.lo_plane_off + src), (sp_lptr_t)(kl_img + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + p.lo_plane_off + src), (sp_lptr_t)(vl_img + j * 1024), 16, 0, 0);
+    }
   }
   // ---- Q fragments of this wave's query tiles (register loads, in flight with the DMA) -------------------------------
-  bf16x8_t qh[SP_QT][2];
+  bf16x8_t qh[SP_QT][2], ql[SP_QT][2];
 #pragma unroll
   for (int u = 0; u < SP_QT; ++u) {
     const int qt_u = tile_of(u);
@@ -409,8 +418,11 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
     int qi = qt_u * 16 + l15;
     qi = qi < N ? qi : N - 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      qh[u][ks] = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16_t*>(p.q) + (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8);
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8;
+      qh[u][ks] = *reinterpret_cast<const bf16x8_t*>(qp);
+      if (ACC) ql[u][ks] = *reinterpret_cast<const bf16x8_t*>(qp + p.lo_plane_off);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -427,7 +439,14 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
       if (jt * 16 < N) {                                   // tiles made of padding keys only are never computed
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = mfma16(sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g), qh[u][ks], acc);
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8_t kh = sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g);
+          if (ACC) {
+            acc = mfma16(sp_row_frag(kl_img, jt * 16 + l15, ks * 4 + g), qh[u][ks], acc);
+            acc = mfma16(kh, ql[u][ks], acc);
+          }
+          acc = mfma16(kh, qh[u][ks], acc);
+        }
       }
       s[jt] = acc;
     }
@@ -457,7 +476,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = 0.f;
-        if (jt * 16 < N) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
+        if (jt * 16 < N) e = ACC ? exp2f(fmaf(s[jt][r], c2, -mc)) : __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
         s[jt][r] = e;
         sum += e;
       }
@@ -479,15 +498,38 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
         const u32x4_t pu = {pack_bf2(s[2 * j2][0], s[2 * j2][1]), pack_bf2(s[2 * j2][2], s[2 * j2][3]),
                             pack_bf2(s[2 * j2 + 1][0], s[2 * j2 + 1][1]), pack_bf2(s[2 * j2 + 1][2], s[2 * j2 + 1][3])};
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+        bf16x8_t pl;
+        if (ACC) {
+          u32x4_t lu;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(sp_tr_frag(v_img, j2 * 32, dt, lane), pf, o[dt]);
+          for (int w = 0; w < 4; ++w) {
+            const f32x4_t& sv = s[2 * j2 + (w >> 1)];
+            const int r0 = (w & 1) * 2;
+            lu[w] = pack_bf2(sv[r0] - bf2f(pu[w] & 0xffffu), sv[r0 + 1] - bf2f(pu[w] >> 16));
+          }
+          pl = __builtin_bit_cast(bf16x8_t, lu);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8_t vh = sp_tr_frag(v_img, j2 * 32, dt, lane);
+          if (ACC) {
+            o[dt] = mfma16(sp_tr_frag(vl_img, j2 * 32, dt, lane), pf, o[dt]);
+            o[dt] = mfma16(vh, pl, o[dt]);
+          }
+          o[dt] = mfma16(vh, pf, o[dt]);
+        }
       }
     }
     // ---- context rows: lane holds d = dt*16 + g*4 .. +4 of query l15 -> per-wave LDS patch -> whole 128-byte rows ---------
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
-      *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+      const f32x4_t ov = o[dt] * inv;
+      const u32x2_t hv = {pack_bf2(ov[0], ov[1]), pack_bf2(ov[2], ov[3])};
+      *reinterpret_cast<u32x2_t*>(o_st + off) = hv;
+      if (ACC)
+        *reinterpret_cast<u32x2_t*>(o_st + 2048 + off) = (u32x2_t){pack_bf2(ov[0] - bf2f(hv[0] & 0xffffu), ov[1] - bf2f(hv[0] >> 16)),
+                                                                  pack_bf2(ov[2] - bf2f(hv[1] & 0xffffu), ov[3] - bf2f(hv[1] >> 16))};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -497,8 +539,11 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
       const int idx = it * 64 + lane;
       const int r = idx >> 3, c = idx & 7;
       const int qi = qt * 16 + r;
-      if (qi < N)
-        *reinterpret_cast<u32x4_t*>(p.ctx_hi + (row0 + qi) * p.D + h * HD + c * 8) = *reinterpret_cast<const u32x4_t*>(o_st + r * 128 + ((c ^ (r & 7)) << 4));
+      if (qi < N) {
+        const size_t oo = (row0 + qi) * p.D + h * HD + c * 8;
+        *reinterpret_cast<u32x4_t*>(p.ctx_hi + oo) = *reinterpret_cast<const u32x4_t*>(o_st + r * 128 + ((c ^ (r & 7)) << 4));
+        if (ACC) *reinterpret_cast<u32x4_t*>(p.ctx_lo + oo) = *reinterpret_cast<const u32x4_t*>(o_st + 2048 + r * 128 + ((c ^ (r & 7)) << 4));
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -693,6 +738,12 @@ static int vt_pitch(int nkp) {
   return 2 * nkp + 32;
 }
 
+// accurate mode: may the caller hand q / k / v as hi + lo bf16 planes (DMA kernel) instead of fp32?
+bool sf_spatial_planes_ok(int N, bool probs) {
+  const bool off = getenv("SF_DISABLE_SPATIAL_DMA_ACC") != nullptr;
+  return !off && !probs && N > 0 && ((N + 31) & ~31) <= 32 * 7;
+}
+
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
   const int nkp = (a.N + 31) & ~31;
@@ -729,12 +780,20 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   static const bool dma_off = getenv("SF_DISABLE_SPATIAL_DMA") != nullptr;
+  static SfPerDeviceOnce attr2;
+  if (attr2.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
   if (!accurate && !a.probs && !dma_off && (a.row_pitch_kv % 8) == 0) {
     const size_t lds2 = (size_t)nkp * 256 + SP_WAVES * 2048;
-    static SfPerDeviceOnce attr2;
-    if (attr2.first())
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14>), grid, block, lds2, s, a, qsplit);
+    hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false>), grid, block, lds2, s, a, qsplit);
+    return hipGetLastError();
+  }
+  if (accurate && !a.in_is_f32) {       // hi + lo bf16 planes (sf_spatial_planes_ok): the DMA kernel with three products
+    if (a.probs || a.lo_plane_off <= 0 || (a.row_pitch_kv % 8) || (a.lo_plane_off % 8)) return hipErrorInvalidValue;
+    const size_t lds2 = (size_t)nkp * 512 + SP_WAVES * 4096;
+    hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, true>), grid, block, lds2, s, a, qsplit);
     return hipGetLastError();
   }
   if (accurate) hipLaunchKernelGGL((sf_spatial_attn_kernel<true, 7>), grid, block, lds, s, a, vp, qsplit);

@@ -201,6 +201,7 @@ struct SfAttnArgs {
   // with col0 = 0 / D / 2D for q / k / v.  Either bf16 (fast) or fp32 (accurate) storage.
   const void* q; const void* k; const void* v;
   int in_is_f32;
+  long long lo_plane_off;             // accurate mode with bf16 storage: elements from a hi value to its lo value (spatial DMA kernel)
   int row_pitch_q, row_pitch_kv;     // elements per token row of the q / kv buffers
   int heads;
   float scale;
@@ -219,6 +220,7 @@ struct SfAttnArgs {
                                       // (output_attentions=True, modeling:703-716); N <= 224
 };
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
+bool sf_spatial_planes_ok(int N, bool probs);
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
 // pooling head: one query (probe, pre-projected & pre-scaled, fp32 [D]) vs N keys per frame
 hipError_t sf_launch_pool_attention(const float* q, const void* kv, int kv_is_f32, int row_pitch,

@@ -707,13 +707,18 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     }
     // ---- spatial attention (modeling:962-996) ------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, anyfold ? l.s_qkv_f : l.s_qkv, ln_in, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr,
-                       nullptr, 1.f, 0, 0, 0, 0, fold_st, nullptr, sfold));
+    // accurate mode: q / k / v leave the GEMM as hi + lo bf16 planes (the bytes of the fp32 tensor) when the DMA attention
+    // kernel can take them; fp32 otherwise (probabilities requested, more than 224 tokens per frame)
+    const bool planes = acc && sf_spatial_planes_ok(N, attentions != nullptr);
+    const size_t sesz = planes ? 2 : esz;
+    HIP_TRY(run_linear(e, anyfold ? l.s_qkv_f : l.s_qkv, ln_in, ws.xn_lo, M, planes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv,
+                       planes ? (bf16_t*)ws.qkv + (size_t)M * 3 * D : nullptr, nullptr, 1.f, 0, 0, 0, 0, fold_st, nullptr, sfold));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
-      a.q = ws.qkv; a.k = (char*)ws.qkv + (size_t)D * esz; a.v = (char*)ws.qkv + (size_t)2 * D * esz;
-      a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.q = ws.qkv; a.k = (char*)ws.qkv + (size_t)D * sesz; a.v = (char*)ws.qkv + (size_t)2 * D * sesz;
+      a.in_is_f32 = acc && !planes; a.lo_plane_off = planes ? (long long)M * 3 * D : 0;
+      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
       a.probs = attentions ? attentions + (size_t)(li - la) * F * heads * N * N : nullptr;
       HIP_TRY(sf_launch_spatial_attention(a, acc, s));
@@ -1042,7 +1047,7 @@ extern "C" int sf_op_linear(const float* x, const float* w, const float* b, cons
 
 extern "C" size_t sf_op_attention_workspace_bytes(int groups, int L, int heads, int head_dim) {
   const size_t rows = (size_t)groups * L, D = (size_t)heads * head_dim;
-  return rows * 3 * D * 2 + rows * D * 2 * 2 + 4096;
+  return rows * 3 * D * 2 * 2 + rows * D * 2 * 2 + 4096;     // qkv hi (+ lo) planes, ctx hi + lo
 }
 
 extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, int heads, int head_dim, int causal,
@@ -1055,20 +1060,24 @@ extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, 
   const int D = heads * head_dim;
   const size_t rows = (size_t)groups * L;
   Carver c(workspace);
-  bf16_t* qb = c.take<bf16_t>(rows * 3 * D);
   bf16_t* ch = c.take<bf16_t>(rows * D);
   bf16_t* cl = c.take<bf16_t>(rows * D);
+  bf16_t* qb = c.take<bf16_t>(rows * 3 * D);
   const void* base = qkv;
   size_t esz = 4;
-  if (!acc) {
-    HIP_TRY(sf_launch_split(qkv, qb, nullptr, rows * 3 * D, s));
+  const bool planes = acc && !temporal_layout && sf_spatial_planes_ok(L, false);
+  bf16_t* ql = nullptr;
+  if (!acc || planes) {
+    if (planes) ql = c.take<bf16_t>(rows * 3 * D);
+    HIP_TRY(sf_launch_split(qkv, qb, ql, rows * 3 * D, s));
     base = qb;
     esz = 2;
   }
   SfAttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = base; a.k = (const char*)base + (size_t)D * esz; a.v = (const char*)base + (size_t)2 * D * esz;
-  a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 1.0f / sqrtf((float)head_dim);
+  a.in_is_f32 = acc && !planes; a.lo_plane_off = planes ? (long long)(ql - qb) : 0;
+  a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 1.0f / sqrtf((float)head_dim);
   a.ctx_hi = ch; a.ctx_lo = cl; a.D = D;
   if (temporal_layout) {
     // rows are [B, L, N_tokens, 3D] with groups = B * N_tokens sequences of length L
@@ -1175,6 +1184,10 @@ extern "C" int sf_bench_attention(sf_encoder* e, int B, int T, int which, int it
   a.q = qkv; a.k = qkv + (size_t)D * esz; a.v = qkv + (size_t)2 * D * esz;
   a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 0.125f;
   a.ctx_hi = ch; a.ctx_lo = cl; a.D = D; a.N = N;
+  if (which == 0 && acc && sf_spatial_planes_ok(N, false)) {      // what the forward does: hi + lo planes in the fp32 tensor's bytes
+    a.k = qkv + (size_t)D * 2; a.v = qkv + (size_t)2 * D * 2;
+    a.in_is_f32 = 0; a.lo_plane_off = (long long)M * 3 * D;
+  }
   if (which == 0) {
     a.frames = B * T;
   } else {

@@ -146,7 +146,19 @@ def _attn_ref(qkv, heads, mask=None):
 @pytest.mark.parametrize("frames_,N,heads", [(3, 196, 12), (2, 9, 2), (1, 33, 1), (2, 224, 2), (4, 1, 2), (2, 16, 3),
                                               (2, 225, 2), (1, 576, 3), (1, 1024, 1), (2, 400, 2)])   # > 224: streaming-key kernel
 @pytest.mark.parametrize("mode", [0, 1])
-def test_op_spatial_attention(sa, frames_, N, heads, mode):
+def test_op_spatial_attention(sa, frames_, N, heads, mode, monkeypatch):
+    _spatial_attention_case(sa, frames_, N, heads, mode)
+
+
+@pytest.mark.parametrize("frames_,N,heads", [(2, 196, 2), (1, 37, 12), (3, 224, 1)])
+def test_op_spatial_attention_accurate_fp32_inputs(sa, frames_, N, heads, monkeypatch):
+    """The accurate mode's register-staged kernel (fp32 q / k / v: what streaming and output_attentions use) next to
+    the DMA kernel on hi + lo planes that the plain call above takes."""
+    monkeypatch.setenv("SF_DISABLE_SPATIAL_DMA_ACC", "1")
+    _spatial_attention_case(sa, frames_, N, heads, 1)
+
+
+def _spatial_attention_case(sa, frames_, N, heads, mode):
     g = torch.Generator().manual_seed(N * 13 + heads)
     qkv = torch.randn(frames_, N, 3 * heads * 64, generator=g) * 1.5
     qkv[..., 5] += 6.0                                   # a spiky column: exercises the max-subtraction
