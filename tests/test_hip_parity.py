@@ -124,6 +124,34 @@ def test_op_linear_large_tiles(sa, M, N, K, bm256, mode, monkeypatch):
     assert maxabs(_linear(sa, x, w, b, None, 1.0, True, mode), torch.nn.functional.gelu(ref)) <= (tol + (1e-5 if mode else 2e-2))
 
 
+def test_op_linear_shape_sweep(sa):
+    """Dispatch heuristics (skinny / panel / 128^2 / 256^2 with 160..256-row tiles, both modes) over ragged shapes:
+    every (M, N, K) must give the same numbers whichever kernel it lands on."""
+    rng = np.random.default_rng(7)
+    shapes = [(25088, 768, 768), (25088, 2304, 768), (6272, 768, 3072), (3136, 3072, 768)]
+    for _ in range(14):
+        shapes.append((int(rng.integers(513, 9000)), int(rng.choice([768, 1024, 1536, 2304, 3072])), int(rng.choice([128, 256, 384, 768, 1152]))))
+    for M, N, K in shapes:
+        g = torch.Generator().manual_seed(M * 7 + N + K)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * K ** -0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        xd, wd = x.cuda().double(), w.cuda().double()
+        for mode in (0, 1):
+            if mode == 0:
+                ref = (x.bfloat16().cuda().double() @ w.bfloat16().cuda().double().t() + b.cuda().double()).cpu()
+                tol = 1e-4
+            else:
+                ref = (xd @ wd.t() + b.cuda().double()).cpu()
+                tol = 2e-5 * K ** 0.5
+            err = maxabs(_linear(sa, x, w, b, r, 0.37, False, mode), r.double() + 0.37 * ref)
+            assert err <= tol, (M, N, K, mode, err)
+            if M <= 9000:
+                err = maxabs(_linear(sa, x, w, b, None, 1.0, True, mode), torch.nn.functional.gelu(ref))
+                assert err <= tol + (1e-5 if mode else 2e-2), (M, N, K, mode, err)
+
+
 def _attention(sa, qkv, groups, L, heads, causal, temporal, ntok, mode):
     nat = sa._native
     D = heads * 64
