@@ -40,6 +40,10 @@ SF_DEVICE bf16x8_t rd_frag_s(const char* piece, int plane, int row, int g) {
   return *reinterpret_cast<const bf16x8_t*>(piece + plane * 8192 + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
 }
 
+#ifdef SF_G256_TRACE
+__device__ unsigned long long g256_trace[16];
+#endif
+
 template <int N>
 SF_DEVICE void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -55,7 +59,11 @@ SF_DEVICE void wait_vm() {
 // wide and a 16 KB piece holds the hi plane and the lo plane of the same [128 rows][32 k] block (one DMA instruction
 // each), so ring, piece order, phase schedule and fragment registers are those of the bf16 kernel with "k-step" read as
 // "plane"; a phase is 24 MFMAs (hi*hi + hi*lo + lo*hi per fragment pair) over the same 12 ds_read_b128 + 2 DMA.
-template <int EPI, bool LNF, int BM, bool SPLIT = false>
+// WIDE (lab only, tools/g256_trace_lab.hip; not instantiated in the library): two quadrants per barrier interval (32 MFMAs,
+// 48 in SPLIT) instead of one -- four intervals per K-tile instead of eight, same pieces, ring and registers.  It saves
+// 11 % of the main loop's CYCLES (1162 against 2 x 651 per pair of quadrants) and nothing on the wall clock: the chip runs
+// these loops against its power budget (1.88 GHz effective on random data) and gives the cycles back as clock.
+template <int EPI, bool LNF, int BM, bool SPLIT = false, bool WIDE = false>
 __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int ntiles, int stagger_ticks, int stagger_groups) {
   constexpr int HR = BM / 2;                 // rows per wave row
   constexpr int MT1 = (HR - 64) / 16;        // m-tiles of the second row quadrant (BM = 256: 4, 224: 3, 192: 2, 160: 1)
@@ -94,7 +102,13 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
     }
   }
 
+#ifdef SF_G256_TRACE
+  unsigned tr_read = 0, tr_bar1 = 0, tr_mma = 0, tr_bar2 = 0;
+#endif
   for (int round = 0;; ++round) {
+#ifdef SF_G256_TRACE
+    tr_read = tr_bar1 = tr_mma = tr_bar2 = 0;
+#endif
     const int tile = (round * 8 + xcd) * cpx + slot_in_xcd;
     if (tile >= ntiles) break;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
@@ -199,21 +213,46 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
     //  correct because loads return in order among themselves -- a pending needed load implies all
     //  later loads pending, i.e. more than N outstanding)
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1);
-    wait_vm<8>();
+    if (WIDE) wait_vm<6>(); else wait_vm<8>();      // WIDE reads three pieces in its first interval
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
 
+#ifdef SF_G256_TRACE      // lab build (tools/g256_trace_lab.hip): where a barrier interval goes, summed per wave over the main loops
+#define SF_TS(ACC) do { const unsigned tn_ = (unsigned)__builtin_readcyclecounter(); ACC += tn_ - tprev_; tprev_ = tn_; } while (0)
+    unsigned tprev_ = (unsigned)__builtin_readcyclecounter();
+#else
+#define SF_TS(ACC) do { } while (0)
+#endif
 #define PHASE(READS, ISSUE_STMT, WAIT_STMT, MMA_STMT) \
   do {                                               \
     READS;                                           \
     ISSUE_STMT;                                      \
     WAIT_STMT;                                       \
+    SF_TS(tr_read);                                  \
     __builtin_amdgcn_s_barrier();                    \
+    SF_TS(tr_bar1);                                  \
     MMA_STMT;                                        \
+    SF_TS(tr_mma);                                   \
     __builtin_amdgcn_s_barrier();                    \
+    SF_TS(tr_bar2);                                  \
   } while (0)
 
     int t = 0;
+    if (WIDE) {
+      // interval A of K-tile t reads Bp0, Ap0, Bp1 and runs quadrants (0,0), (0,1); interval B reads Ap1 and runs (1,1), (1,0).
+      // In flight behind the wait: A keeps the four pieces of K-tile t+1 (the next read, Ap1 of t, has landed);
+      // B keeps (t+1,3), (t+2,0), (t+2,1) (the next reads, pieces 0..2 of t+1, have landed).
+      for (; t + 2 < nkt; t += 2) {
+        PHASE((read_b(b0, 0, 0), read_a(0, 0), read_b(b1, 0, 1)), (issue(t + 1, 2), issue(t + 1, 3)), wait_vm<8>(), (mma(0, 0, b0), mma(0, 1, b1)));
+        PHASE(read_a(0, 1), (issue(t + 2, 0), issue(t + 2, 1)), wait_vm<6>(), (mma(1, 1, b1), mma(1, 0, b0)));
+        PHASE((read_b(b0, 1, 0), read_a(1, 0), read_b(b1, 1, 1)), (issue(t + 2, 2), issue(t + 2, 3)), wait_vm<8>(), (mma(0, 0, b0), mma(0, 1, b1)));
+        PHASE(read_a(1, 1), (issue(t + 3, 0), issue(t + 3, 1)), wait_vm<6>(), (mma(1, 1, b1), mma(1, 0, b0)));
+      }
+      PHASE((read_b(b0, 0, 0), read_a(0, 0), read_b(b1, 0, 1)), (issue(t + 1, 2), issue(t + 1, 3)), wait_vm<8>(), (mma(0, 0, b0), mma(0, 1, b1)));
+      PHASE(read_a(0, 1), (void)0, wait_vm<2>(), (mma(1, 1, b1), mma(1, 0, b0)));
+      PHASE((read_b(b0, 1, 0), read_a(1, 0), read_b(b1, 1, 1)), (void)0, wait_vm<0>(), (mma(0, 0, b0), mma(0, 1, b1)));
+      PHASE(read_a(1, 1), (void)0, (void)0, (mma(1, 1, b1), mma(1, 0, b0)));
+    } else {
     for (; t + 2 < nkt; t += 2) {
       // K-tile t (parity 0): phases issue pieces (t+1,2), (t+1,3), (t+2,0), (t+2,1)
       PHASE((read_b(b0, 0, 0), read_a(0, 0)), issue(t + 1, 2), wait_vm<8>(), mma(0, 0, b0));
@@ -235,7 +274,15 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
     PHASE(read_b(b1, 1, 1), (void)0, wait_vm<0>(), mma(0, 1, b1));
     PHASE(read_a(1, 1), (void)0, (void)0, mma(1, 1, b1));
     PHASE((void)0, (void)0, (void)0, mma(1, 0, b0));
+    }
 #undef PHASE
+#undef SF_TS
+#ifdef SF_G256_TRACE
+    if (blockIdx.x == SF_G256_TRACE && lane == 0 && wn == 0) {
+      unsigned long long* tb = g256_trace + wm * 8;
+      tb[0] += tr_read; tb[1] += tr_bar1; tb[2] += tr_mma; tb[3] += tr_bar2; tb[4] += (unsigned long long)(nkt * 4 / (WIDE ? 2 : 1));
+    }
+#endif
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger: every ring read is retired
 
     // ---- epilogue: stage the C tile in LDS (the ring is idle), then whole-row 16-byte stores -------
@@ -472,10 +519,11 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   if (const char* only = getenv("SF_G256_STAGGER_ONLY")) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs
     if (a.epi != atoi(only)) stagger = 0;
   }
+#define SF_LAUNCH256(E, L, SP) hipLaunchKernelGGL((sf_gemm256_kernel<E, L, BM, SP>), grid, block, lds, s, a, tiles, stagger, sgroups)
   if (a.a_lo && a.w_lo) {      // fp32-accurate mode: hi + lo planes of both operands, three products per fragment pair
     if (a.ln_stats || a.aux_mode) return hipErrorInvalidValue;
     switch (a.epi) {
-#define SF_CASE(E) case E: hipLaunchKernelGGL((sf_gemm256_kernel<E, false, BM, true>), grid, block, lds, s, a, tiles, stagger, sgroups); break;
+#define SF_CASE(E) case E: SF_LAUNCH256(E, false, true); break;
       SF_CASE(SF_EPI_F32) SF_CASE(SF_EPI_BF16) SF_CASE(SF_EPI_ACT_BF16) SF_CASE(SF_EPI_RESID_F32)
 #undef SF_CASE
       default: return hipErrorInvalidValue;
@@ -487,19 +535,19 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   const bool lnf = a.ln_stats != nullptr;
   if (lnf && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return hipErrorInvalidValue;
   switch (a.epi) {
-    case SF_EPI_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_F32, false, BM>), grid, block, lds, s, a, tiles, stagger, sgroups); break;
+    case SF_EPI_F32: SF_LAUNCH256(SF_EPI_F32, false, false); break;
     case SF_EPI_BF16:
       if (a.aux_mode) {
         if (lnf || !a.aux) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((sf_gemm256_kernel<G256_EPI_BF16_AUX, false, BM>), grid, block, lds, s, a, tiles, stagger, sgroups);
-      } else if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, true, BM>), grid, block, lds, s, a, tiles, stagger, sgroups);
-      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_BF16, false, BM>), grid, block, lds, s, a, tiles, stagger, sgroups);
+        SF_LAUNCH256(G256_EPI_BF16_AUX, false, false);
+      } else if (lnf) SF_LAUNCH256(SF_EPI_BF16, true, false);
+      else SF_LAUNCH256(SF_EPI_BF16, false, false);
       break;
     case SF_EPI_ACT_BF16:
-      if (lnf) hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, true, BM>), grid, block, lds, s, a, tiles, stagger, sgroups);
-      else hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_ACT_BF16, false, BM>), grid, block, lds, s, a, tiles, stagger, sgroups);
+      if (lnf) SF_LAUNCH256(SF_EPI_ACT_BF16, true, false);
+      else SF_LAUNCH256(SF_EPI_ACT_BF16, false, false);
       break;
-    case SF_EPI_RESID_F32: hipLaunchKernelGGL((sf_gemm256_kernel<SF_EPI_RESID_F32, false, BM>), grid, block, lds, s, a, tiles, stagger, sgroups); break;
+    case SF_EPI_RESID_F32: SF_LAUNCH256(SF_EPI_RESID_F32, false, false); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
