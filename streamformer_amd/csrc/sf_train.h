@@ -77,6 +77,7 @@ hipError_t sf_launch_sum_rows(const float* in, float* out, int n_out, int n_a, l
 // per weight: w_eff = scale * (w + lora_b * lora_a) [N,K] -> w_bf [N,K] and wT_bf [K,N] (either may be null);
 // scale = tanh(*gate) when a gate is given; bias_out = scale * bias.  All weights of the model go in ONE
 // launch through a job table; offsets are floats from `base` (-1 = absent)
+#define SF_PREP_TILE 64      // weight-refresh tile edge (sf_prep_weights_batched_kernel)
 struct SfPrepJob {
   long w_off, la_off, lb_off, gate_off, bias_off;
   bf16_t* w_bf; bf16_t* wT_bf; float* bias_out;

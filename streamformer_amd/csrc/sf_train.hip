@@ -258,7 +258,7 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
       SfPrepJob j;
       j.w_off = w_off; j.la_off = la; j.lb_off = lb; j.gate_off = gate; j.bias_off = bias;
       j.w_bf = w_bf; j.wT_bf = wT_bf; j.bias_out = bias_out; j.N = N; j.K = K; j.rank = rank; j.tile0 = tiles;
-      tiles += ((N + 31) / 32) * ((K + 31) / 32);
+      tiles += ((N + SF_PREP_TILE - 1) / SF_PREP_TILE) * ((K + SF_PREP_TILE - 1) / SF_PREP_TILE);
       jobs.push_back(j);
     };
     auto off = [&](int idx, size_t extra = 0) -> long { return idx < 0 ? -1 : (long)(t->params[idx].off + extra); };
