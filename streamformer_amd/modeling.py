@@ -144,22 +144,27 @@ def expected_keys(cfg: StreamformerConfig, lora: Optional[bool] = None) -> "Orde
         k[p + ".weight"] = (D,)
         k[p + ".bias"] = (D,)
 
+    # order = the reference's named_parameters() (tests/golden/f12_param_order.json, pinned by oracle/make_golden_param_order.py):
+    # torch.optim state ids, DDP buckets and checkpoint-*.pth optimizer entries follow it
     for i in range(cfg.num_hidden_layers):
         p = f"encoder.layer.{i}."
         k[p + "temporal_attention_gating"] = ()
+        lin(p + "attention.attention.qkv", 3 * D, D, cfg.qkv_bias)
+        if lora:
+            k[p + "attention.attention.qkv_lora_a.weight"] = (LORA_RANK, D)
+            k[p + "attention.attention.qkv_lora_b.weight"] = (3 * D, LORA_RANK)
+        lin(p + "attention.output.dense", D, D)
+        if lora:
+            k[p + "attention.output.dense_lora_a.weight"] = (LORA_RANK, D)
+            k[p + "attention.output.dense_lora_b.weight"] = (D, LORA_RANK)
+        lin(p + "intermediate.dense", I, D)
+        lin(p + "output.dense", D, I)
+        ln(p + "layernorm_before")
+        ln(p + "layernorm_after")
         ln(p + "temporal_layernorm")
         lin(p + "temporal_attention.attention.qkv", 3 * D, D, cfg.qkv_bias)
         lin(p + "temporal_attention.output.dense", D, D)
         lin(p + "temporal_dense", D, D)
-        ln(p + "layernorm_before")
-        lin(p + "attention.attention.qkv", 3 * D, D, cfg.qkv_bias)
-        lin(p + "attention.output.dense", D, D)
-        if lora:
-            for n, shape in _lora_keys(cfg, i).items():
-                k[n] = shape
-        ln(p + "layernorm_after")
-        lin(p + "intermediate.dense", I, D)
-        lin(p + "output.dense", D, I)
     ln("post_layernorm")
     k["head.probe"] = (1, 1, D)
     k["head.attention.in_proj_weight"] = (3 * D, D)

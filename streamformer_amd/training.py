@@ -23,6 +23,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -195,6 +197,99 @@ class StreamformerTrainer:
         for k in self.extra_slot:
             out[k] = self._view(k).detach().clone()
         return out
+
+    # ---- checkpoint / resume (reference layout: utils.py:608-636) ---------------------------------------
+    def _optimizer_order(self) -> List[str]:
+        """Trainable parameter names in the order the reference model yields them from ``named_parameters()``
+        (encoder tree under ``timesformer.``, then the task heads): torch.optim numbers its state in that order,
+        group by group (optim_factory.py:59-104).  Pinned by tests/golden/f12_param_order.json."""
+        from .modeling import expected_keys
+        enc = [k for k in expected_keys(self.config) if self.layout[k]["trainable"]]
+        heads = [k for t in self.task_heads for k in (f"task_heads.{t}.logit_scale", f"task_heads.{t}.logit_bias")]
+        return enc + heads
+
+    @staticmethod
+    def _no_decay(name: str, shape) -> bool:
+        return len(shape) == 1 or name.endswith(".bias")           # optim_factory.py:72-77, skip_list = ()
+
+    def optimizer_state_dict(self) -> dict:
+        """``torch.optim.AdamW.state_dict()`` of the reference's optimizer over the same parameters: two groups in order
+        of first appearance ("decay" / "no_decay"), ids running through the groups, per-id ``step / exp_avg / exp_avg_sq``."""
+        names = self._optimizer_order()
+        groups: Dict[str, List[str]] = {}
+        for n in names:
+            groups.setdefault("no_decay" if self._no_decay(n, self._entry(n)["shape"]) else "decay", []).append(n)
+        state, param_groups, pid = {}, [], 0
+        for gname, members in groups.items():
+            ids = []
+            for n in members:
+                e = self._entry(n)
+                sl = slice(e["offset"], e["offset"] + e["numel"])
+                if self.step_count > 0:
+                    state[pid] = {"step": torch.tensor(float(self.step_count)),
+                                  "exp_avg": self.exp_avg[sl].view(e["shape"]).detach().cpu().clone(),
+                                  "exp_avg_sq": self.exp_avg_sq[sl].view(e["shape"]).detach().cpu().clone()}
+                ids.append(pid)
+                pid += 1
+            param_groups.append({"weight_decay": 0.0 if gname == "no_decay" else self.weight_decay, "lr_scale": 1.0, "lr": self.lr,
+                                 "betas": tuple(self.betas), "eps": self.eps, "amsgrad": False, "maximize": False, "foreach": None,
+                                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+                                 "params": ids})
+        return {"state": state, "param_groups": param_groups, "param_names": [n for g in groups.values() for n in g]}
+
+    def load_optimizer_state_dict(self, osd: dict) -> None:
+        """Inverse of :meth:`optimizer_state_dict`; also accepts the reference's own ``optimizer.state_dict()`` (same ids)."""
+        names = self.optimizer_state_dict()["param_names"]
+        n_ids = sum(len(g["params"]) for g in osd["param_groups"])
+        if n_ids != len(names):
+            raise ValueError(f"optimizer state covers {n_ids} parameters, this trainer has {len(names)} trainable ones")
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for pid, st in osd.get("state", {}).items():
+            n = names[int(pid)]
+            e = self._entry(n)
+            sl = slice(e["offset"], e["offset"] + e["numel"])
+            if tuple(st["exp_avg"].shape) != tuple(e["shape"]):
+                raise ValueError(f"optimizer state {pid} has shape {tuple(st['exp_avg'].shape)}, {n} is {tuple(e['shape'])}")
+            self.exp_avg[sl].copy_(st["exp_avg"].to(torch.float32).reshape(-1))
+            self.exp_avg_sq[sl].copy_(st["exp_avg_sq"].to(torch.float32).reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one")
+        self.step_count = steps.pop() if steps else 0
+        g0 = osd["param_groups"][0]
+        self.lr = float(g0.get("lr", self.lr))
+        decays = [float(g["weight_decay"]) for g in osd["param_groups"] if float(g.get("weight_decay", 0.0)) > 0]
+        if decays:
+            self.weight_decay = decays[0]
+
+    def checkpoint(self, epoch: int = 0, args=None) -> dict:
+        """The dict the reference's ``save_model`` writes on rank 0: wrapper-keyed weights (``timesformer.*``,
+        ``task_heads.*``), optimizer state, epoch.  ``scaler`` is empty: bf16 operands need no loss scaling."""
+        model = OrderedDict()
+        for k, v in self.state_dict().items():
+            model[k if k.startswith("task_heads.") else "timesformer." + k] = v.detach().cpu()
+        return {"model": model, "optimizer": self.optimizer_state_dict(), "epoch": int(epoch), "scaler": {}, "args": args}
+
+    def save_checkpoint(self, path: str, epoch: int = 0, args=None) -> None:
+        if self.rank == 0:
+            tmp = path + ".tmp"
+            torch.save(self.checkpoint(epoch, args), tmp)
+            os.replace(tmp, path)
+
+    def load_checkpoint(self, path_or_dict) -> int:
+        """Resume: weights, Adam moments, step count.  Returns the stored epoch.  (The reference's pre-training driver only
+        reloads weights, run_finetuning_multi_task.py:353-357; the optimizer entry is what its downstream ``auto_load_model``
+        restores, utils.py:670-877.)"""
+        ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+        self.load_state_dict(ck["model"])
+        if ck.get("optimizer"):
+            self.load_optimizer_state_dict(ck["optimizer"])
+        self.micro = 0
+        self.grads.zero_()
+        self.sync_weights()
+        return int(ck.get("epoch", 0))
 
     def grad(self, key: str) -> torch.Tensor:
         e = self._entry(key)

@@ -661,7 +661,10 @@ def test_output_attentions(golden_dir, mode, tol):
     got = torch.stack(list(out.attentions)).cpu()
     assert maxabs(got, f["attentions"]) <= tol
     assert float((got.sum(-1) - 1).abs().max()) < 1e-5
-    assert torch.equal(out.last_hidden_state, m(x).last_hidden_state)
+    # the accurate mode materialises probabilities with the fp32-input kernel and otherwise runs the DMA kernel on hi + lo
+    # planes: same numbers to rounding, not to the bit
+    plain = m(x).last_hidden_state
+    assert torch.equal(out.last_hidden_state, plain) if mode == "bf16" else maxabs(out.last_hidden_state, plain) <= 2e-5
     tup = m(x, output_attentions=True, output_hidden_states=True, return_dict=False)
     assert len(tup) == 3 and len(tup[2]) == cfg.num_hidden_layers
     with pytest.raises(NotImplementedError):

@@ -257,3 +257,15 @@ def test_trainer_refuses_to_run_without_a_gpu():
                              num_attention_heads=2, intermediate_size=256)
     with pytest.raises(RuntimeError, match="GPU"):
         StreamformerTrainer(cfg, {}, ["retrieval"])
+
+
+def test_parameter_and_state_dict_order_match_the_reference(golden_dir):
+    """F12: optimizer state ids, DDP buckets and checkpoint-*.pth optimizer entries follow named_parameters() order."""
+    import json
+    import streamformer_amd as sa
+    with open(os.path.join(golden_dir, "f12_param_order.json")) as f:
+        ref = json.load(f)
+    for key, lora in (("plain", False), ("lora", True)):
+        m = sa.TimesformerMultiTaskingModelSigLIP(small_cfg(add_lora_spatial=lora))
+        assert [(n, list(p.shape)) for n, p in m.named_parameters()] == [(r[0], r[1]) for r in ref[key]]
+        assert list(m.state_dict().keys()) == ref[key + "_state_dict_keys"]

@@ -488,6 +488,60 @@ def test_twenty_step_trajectory_tracks_the_oracle():
     assert cos > 0.97 and 0.9 < (num / den) ** 0.5 < 1.1, (cos, (num / den) ** 0.5)
 
 
+def test_checkpoint_resume_and_reference_optimizer_layout(golden_dir, tmp_path):
+    """checkpoint-*.pth in the reference's layout (utils.py:608-636): wrapper-keyed weights + torch.optim.AdamW state.
+    (1) the optimizer entry loads into a torch.optim.AdamW built the reference's way (optim_factory.py:59-104) over
+    parameters enumerated in the REFERENCE's named_parameters() order (fixture F12), and every moment lands on the right
+    tensor; (2) a fresh trainer resumed from the file continues bit-identically."""
+    import json
+    from oracle import train_oracle as TO
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    cfg = small_cfg(add_lora_spatial=True)
+    tr, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True)
+    dev = tr.device
+    sched = TO.schedule(cfg, B=4)
+    for it in range(3):
+        task, x, ti, _ = sched[it % 4]
+        tr.micro_step(task, x.to(dev), _to_dev(ti, dev))
+    path = str(tmp_path / "checkpoint-2.pth")
+    tr.save_checkpoint(path, epoch=2, args={"lr": 1e-3})
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and set(ck) >= {"model", "optimizer", "epoch", "scaler", "args"}
+    assert all(k.startswith(("timesformer.", "task_heads.")) for k in ck["model"])
+    # (1) reference-side optimizer over reference-ordered parameters
+    with open(os.path.join(golden_dir, "f12_param_order.json")) as f:
+        rows = json.load(f)["lora"]
+    names = ["timesformer." + r[0] for r in rows if r[2]]
+    names += [f"task_heads.{t}.{k}" for t in ("retrieval", "localization") for k in ("logit_scale", "logit_bias")]
+    params = {n: torch.nn.Parameter(ck["model"][n].clone()) for n in names}
+    groups = {}
+    for n, p in params.items():
+        g = "no_decay" if (p.dim() == 1 or n.endswith(".bias")) else "decay"
+        groups.setdefault(g, {"weight_decay": 0.05 if g == "decay" else 0.0, "params": []})["params"].append(p)
+    opt = torch.optim.AdamW(list(groups.values()), lr=1e-3)
+    opt.load_state_dict(ck["optimizer"])
+    assert [len(g["params"]) for g in opt.param_groups] == [len(g["params"]) for g in ck["optimizer"]["param_groups"]]
+    assert opt.param_groups[0]["weight_decay"] == 0.05 and opt.param_groups[1]["weight_decay"] == 0.0
+    for n, p in params.items():
+        key = n[len("timesformer."):] if n.startswith("timesformer.") else n
+        e = tr._entry(key)
+        sl = slice(e["offset"], e["offset"] + e["numel"])
+        st = opt.state[p]
+        assert float(st["step"]) == 3.0
+        assert torch.equal(st["exp_avg"].flatten(), tr.exp_avg[sl].cpu()), n
+        assert torch.equal(st["exp_avg_sq"].flatten(), tr.exp_avg_sq[sl].cpu()), n
+    # (2) exact resume
+    tr2 = StreamformerTrainer(cfg, make_state_dict(cfg, seed=99, lora=True), ["retrieval", "localization"], freeze_spatial=True,
+                              device=dev, lr=5e-4, weight_decay=0.01)
+    assert tr2.load_checkpoint(path) == 2 and tr2.step_count == 3 and tr2.lr == 1e-3 and tr2.weight_decay == 0.05
+    task, x, ti, _ = sched[3]
+    la = tr.micro_step(task, x.to(dev), _to_dev(ti, dev))
+    lb = tr2.micro_step(task, x.to(dev), _to_dev(ti, dev))
+    assert float(la) == float(lb)
+    assert torch.equal(tr.params, tr2.params) and torch.equal(tr.exp_avg, tr2.exp_avg) and torch.equal(tr.exp_avg_sq, tr2.exp_avg_sq)
+
+
 def test_trainer_rejects_what_it_cannot_do():
     import streamformer_amd._native as nat
     from streamformer_amd.init_weights import make_state_dict
