@@ -164,6 +164,7 @@ hipError_t sf_launch_gemm128(const SfGemmArgs& a, bool split, hipStream_t s);   
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split);                      // sf_gemm256.hip
 bool sf_gemm256_aux_supported(const SfGemmArgs& a);                              // aux_mode epilogues
 hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s);
+int sf_skinny_max_rows();                                                        // sf_gemm_skinny.hip: largest M the skinny kernels take (several streams per call)
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split);                  // sf_gemm_skinny.hip (M <= 512)
 hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s);
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip

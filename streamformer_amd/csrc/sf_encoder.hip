@@ -512,7 +512,7 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.hn_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
   w.hm_hi = c.take<bf16_t>(F * I);
   w.hm_lo = acc ? c.take<bf16_t>(F * I) : nullptr;
-  w.res_bf = (!acc && M <= 512) ? c.take<bf16_t>(M * D) : nullptr;
+  w.res_bf = (!acc && M <= (size_t)sf_skinny_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
   w.lhs_stage = !need_tqkv ? c.take<float>(M * D) : nullptr;       // streaming carve (the cache holds the temporal qkv)
   w.pool_stage = !need_tqkv ? c.take<float>(F * D) : nullptr;
   w.bytes = (c.off + 255) & ~(size_t)255;
@@ -567,7 +567,7 @@ static bool ln_fold_ok(const sf_encoder* e, int M) {
 // Small-M variant (the per-frame streaming step): the skinny GEMM derives the row statistics itself from the A fragments
 // it reads anyway, every residual producer only adds the bf16 copy of its output rows.
 static bool ln_fold_small_ok(const sf_encoder* e, int M) {
-  if (e->compute != SF_COMPUTE_BF16 || M > 512) return false;
+  if (e->compute != SF_COMPUTE_BF16 || M > sf_skinny_max_rows()) return false;
   static const bool off = getenv("SF_DISABLE_STREAM_FOLD") != nullptr;
   if (off) return false;
   SfGemmArgs g;

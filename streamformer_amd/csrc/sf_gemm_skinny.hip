@@ -1,4 +1,4 @@
-// "Skinny" MFMA GEMM for few token rows (M <= 512): the per-frame streaming step (M = 196 rows per
+// "Skinny" MFMA GEMM for few token rows (M <= 2048, sf_skinny_max_rows()): the per-frame streaming step (M = 196 rows per
 // call, vqa_enc:1316-1392), the pooling-head MLP (M = frames) and small test shapes.
 //   C[M,N] = A[M,K] * W[N,K]^T (+ the same fused epilogues as sf_gemm.hip)
 //
@@ -394,9 +394,20 @@ static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+int sf_skinny_max_rows() {
+  static int m = 0;
+  if (!m) {
+    m = 2048;      // several streams per call (M = 196 per stream): 4 streams 2.51 -> 1.58 ms, 8 streams 2.79 -> 2.43 ms per step against
+                   // the 128^2 kernel; from 16 streams (M = 3136) on the large-tile kernels win
+    if (const char* e = getenv("SF_SKINNY_MAX_M")) m = atoi(e) > 0 ? atoi(e) : 2048;
+  }
+  return m;
+}
+
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
   // few rows, or few output columns (the rank-32 LoRA projections of the training step: A streams once)
-  if (a.M <= 0 || (a.M > 512 && a.N > 64) || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
+  const int max_rows = split ? (sf_skinny_max_rows() < 1024 ? sf_skinny_max_rows() : 1024) : sf_skinny_max_rows();   // bf16x3: the 128^2 kernel wins from 8 streams on
+  if (a.M <= 0 || (a.M > max_rows && a.N > 64) || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
   if (a.ln_stats || a.ln_stats_out) return false;                  // the statistics-buffer fold: panel / 256^2 kernels
   if (a.ln_inkernel && (split || !a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
   if (split && (!a.a_lo || !a.w_lo)) return false;
