@@ -217,12 +217,31 @@ def streaming_bench(dev):
     lat.sort()
     mean = sum(lat) / len(lat)
     gb = (255.0 + 7.225 * (64 + 1) / 2 + 7.225 + 12.0) / 1e3          # mean algorithmic GB per frame over t = 0..63
-    del m, cache
+    del cache
+    # the serving shape of the vision tower (vqa_enc:1494-1500: one cache per stream): 8 streams advance one frame per call
+    S = 8
+    xs = x.expand(S, -1, -1, -1, -1).contiguous()
+    cache = m.new_cache(S, 64)
+    lat8 = []
+    for rep in range(2):
+        cache.reset()
+        for t in range(64):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m(xs[:, t:t + 1], use_cache=True, past_key_values=cache)
+            torch.cuda.synchronize()
+            if rep:
+                lat8.append(time.perf_counter() - t0)
+    lat8.sort()
+    del m, cache, xs
     torch.cuda.empty_cache()
     return {"p50_ms": round(1e3 * lat[len(lat) // 2], 3), "p99_ms": round(1e3 * lat[int(len(lat) * 0.99)], 3),
             "mean_ms": round(1e3 * mean, 3), "frames_per_s": round(1.0 / mean, 1), "algorithmic_GB_per_frame": round(gb, 3),
             "GBps": round(gb / mean, 1), "frac_of_hbm_peak": round(gb / mean / PEAK_HBM_GBS, 4),
-            "config": "SigLIP-base, num_frames=64, B=1, one 224^2 frame per call, bf16 mode, KV-cache of 64 frames"}
+            "config": "SigLIP-base, num_frames=64, B=1, one 224^2 frame per call, bf16 mode, KV-cache of 64 frames",
+            "eight_streams": {"p50_ms_per_call": round(1e3 * lat8[len(lat8) // 2], 3),
+                              "frames_per_s": round(S / (sum(lat8) / len(lat8)), 1),
+                              "config": "same model, 8 independent streams advance one frame per call (one cache, B = 8)"}}
 
 
 def main():
