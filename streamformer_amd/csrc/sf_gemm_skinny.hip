@@ -357,6 +357,152 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Mid-size variant (512 < M <= sf_skinny_max_rows(): several streams advancing one frame per call, bf16 mode).
+// At M = 1568 the [32 x 32] tiles above move 346 MB from L2 to LDS for the qkv projection (every workgroup streams
+// 2 x 32 x K operands for 32 x 32 outputs: 16 FLOP per byte) and the launch is bound by that traffic.  Here a workgroup
+// owns [64 x 64], a wave a [32 x 32] quarter as 2 x 2 MFMA tiles: half the L2 -> LDS bytes and half the ds_reads per MFMA;
+// 4-stage ring of 16 KB stages (two workgroups per CU), one barrier per K-tile, same fragment layout, same in-kernel
+// LayerNorm statistics and epilogues.
+// ------------------------------------------------------------------------------------------------
+#define MD_B 64
+#define MD_STAGES 4
+#define MD_STAGE (2 * MD_B * SK_BK * 2)       // 16 KB: 64 A rows then 64 W rows
+
+template <int EPI, bool LNF>
+__global__ __launch_bounds__(SK_THREADS) void sf_gemm_mid_kernel(SfGemmArgs p) {
+  constexpr int LOADS = 2 * MD_B * 8 / SK_THREADS;      // 4 chunks of 16 bytes per thread and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * MD_B, m0 = blockIdx.y * MD_B;
+  const bf16_t* src[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int c = i * SK_THREADS + tid;
+    const int row = c >> 3, slot = c & 7;
+    const int kc = slot ^ ((row >> 1) & 7);
+    if (row < MD_B) {
+      int gr = m0 + row;
+      gr = gr < p.M ? gr : p.M - 1;
+      src[i] = p.a_hi + (size_t)gr * p.K + kc * 8;
+    } else {
+      int gr = n0 + row - MD_B;
+      gr = gr < p.N ? gr : p.N - 1;
+      src[i] = p.w_hi + (size_t)gr * p.K + kc * 8;
+    }
+  }
+  auto issue = [&](int kt) {
+    char* dst = smem + (kt % MD_STAGES) * MD_STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
+  };
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float ln1[2] = {0.f, 0.f}, ln2[2] = {0.f, 0.f};
+  const int nkt = p.K / SK_BK;
+  const int wm = wave & 1, wn = wave >> 1;
+  for (int s = 0; s < MD_STAGES - 1 && s < nkt; ++s) issue(s);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int later = min(nkt - 1 - kt, MD_STAGES - 2);       // tiles that may stay in flight behind tile kt
+    if (later >= 2) sk_wait<2 * LOADS>(); else if (later == 1) sk_wait<LOADS>(); else sk_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + MD_STAGES - 1 < nkt) issue(kt + MD_STAGES - 1);   // into the stage every wave finished reading before this barrier
+    const char* img = smem + (kt % MD_STAGES) * MD_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 4 + g;
+      bf16x8_t af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = sk_frag(img, wm * 32 + i * 16 + l15, kc);
+        wf[i] = sk_frag(img, MD_B + wn * 32 + i * 16 + l15, kc);
+        if (LNF) sk_stats(af[i], ln1[i], ln2[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = sk_mfma(wf[j], af[i], acc[i][j]);
+    }
+  }
+  if (LNF) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ln1[i] += __shfl_xor(ln1[i], 16, 64); ln1[i] += __shfl_xor(ln1[i], 32, 64);
+      ln2[i] += __shfl_xor(ln2[i], 16, 64); ln2[i] += __shfl_xor(ln2[i], 32, 64);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 32 + i * 16 + l15;
+    if (m >= p.M) continue;
+    size_t orow = (size_t)m;
+    if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+    float mean = 0.f, rstd = 1.f;
+    if (LNF) sk_ln_finish(ln1[i], ln2[i], p.K, p.ln_eps, mean, rstd);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4_t v = acc[i][j];
+      if (LNF) v = rstd * (v - mean * *reinterpret_cast<const f32x4_t*>(p.ln_s + n));
+      if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+      const size_t o = orow * (size_t)p.ldc + n;
+      if (EPI == SF_EPI_F32) {
+        *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+      } else if (EPI == SF_EPI_RESID_F32) {
+        v = *reinterpret_cast<const f32x4_t*>(p.resid + o) + p.alpha * v;
+        *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+        if (p.out_hi) *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      } else {
+        if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = apply_act_fast(v[q], p.act);
+        }
+        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      }
+    }
+  }
+}
+
+static bool mid_ok(const SfGemmArgs& a, bool split) {
+  static const bool off = getenv("SF_DISABLE_GEMM_MID") != nullptr;
+  static const int min_m = getenv("SF_GEMM_MID_MIN_M") ? atoi(getenv("SF_GEMM_MID_MIN_M")) : 512;
+  return !off && !split && a.M > min_m && a.N >= 64 && a.epi != SF_EPI_EMBED_F32 && !a.out_lo;
+}
+static hipError_t mid_launch(const SfGemmArgs& a, hipStream_t s) {
+  const dim3 grid((a.N + MD_B - 1) / MD_B, (a.M + MD_B - 1) / MD_B);
+  const size_t lds = (size_t)MD_STAGES * MD_STAGE;
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first()) {
+#define MD_ATTR(E, L) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_mid_kernel<E, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MD_ATTR(SF_EPI_F32, false) MD_ATTR(SF_EPI_BF16, false) MD_ATTR(SF_EPI_ACT_BF16, false) MD_ATTR(SF_EPI_RESID_F32, false)
+    MD_ATTR(SF_EPI_BF16, true) MD_ATTR(SF_EPI_ACT_BF16, true)
+#undef MD_ATTR
+  }
+#define MD_GO(E, L) hipLaunchKernelGGL((sf_gemm_mid_kernel<E, L>), grid, dim3(SK_THREADS), lds, s, a)
+  if (a.ln_inkernel) {
+    if (a.epi == SF_EPI_BF16) MD_GO(SF_EPI_BF16, true);
+    else if (a.epi == SF_EPI_ACT_BF16) MD_GO(SF_EPI_ACT_BF16, true);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  switch (a.epi) {
+    case SF_EPI_F32: MD_GO(SF_EPI_F32, false); break;
+    case SF_EPI_BF16: MD_GO(SF_EPI_BF16, false); break;
+    case SF_EPI_ACT_BF16: MD_GO(SF_EPI_ACT_BF16, false); break;
+    case SF_EPI_RESID_F32: MD_GO(SF_EPI_RESID_F32, false); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef MD_GO
+  return hipGetLastError();
+}
+
 template <bool SPLIT, int KG>
 static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
   const size_t lds = (size_t)KG * SKG_STAGES * SK_PLANE * (SPLIT ? 2 : 1);
@@ -441,6 +587,7 @@ static hipError_t sk_launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipS
 
 hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s) {
   if (!sf_gemm_skinny_supported(a, split)) return hipErrorInvalidValue;
+  if (mid_ok(a, split)) return mid_launch(a, s);
   const dim3 grid((a.N + SK_BN - 1) / SK_BN, (a.M + SK_BM - 1) / SK_BM);
   // every workgroup gets its own CU and the K loop is long: the K-parallel variant
   if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !getenv("SF_SKINNY_NO_KG"))
