@@ -551,6 +551,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
 static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16) return false;
   if (getenv("SF_DISABLE_LN_FOLD")) return false;        // A/B switch for measurements
+  if (M <= sf_skinny_max_rows()) return false;           // the small-M fold (in-kernel statistics, skinny / 64 x 64 kernels) takes these
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = e->D; g.epi = SF_EPI_RESID_F32;
