@@ -1,4 +1,4 @@
-// "Skinny" MFMA GEMM for few token rows (M <= 2048, sf_skinny_max_rows()): the per-frame streaming step (M = 196 rows per
+// "Skinny" MFMA GEMM for few token rows (M <= 2560, sf_skinny_max_rows()): the per-frame streaming step (M = 196 rows per
 // call, vqa_enc:1316-1392), the pooling-head MLP (M = frames) and small test shapes.
 //   C[M,N] = A[M,K] * W[N,K]^T (+ the same fused epilogues as sf_gemm.hip)
 //
@@ -543,9 +543,9 @@ static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
 int sf_skinny_max_rows() {
   static int m = 0;
   if (!m) {
-    m = 2048;      // several streams per call (M = 196 per stream): 4 streams 2.51 -> 1.58 ms, 8 streams 2.79 -> 2.43 ms per step against
+    m = 2560;      // several streams per call (M = 196 per stream): 4 streams 2.51 -> 1.58 ms, 8 streams 2.79 -> 2.43 ms per step against
                    // the 128^2 kernel; from 16 streams (M = 3136) on the large-tile kernels win
-    if (const char* e = getenv("SF_SKINNY_MAX_M")) m = atoi(e) > 0 ? atoi(e) : 2048;
+    if (const char* e = getenv("SF_SKINNY_MAX_M")) m = atoi(e) > 0 ? atoi(e) : 2560;
   }
   return m;
 }
