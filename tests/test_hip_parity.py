@@ -769,6 +769,32 @@ def test_streaming_config5_full_size_vs_oracle(mode, tol_l, tol_p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol_l,tol_p", [("fp32", ACC_TOL, ACC_TOL), ("bf16", BF16_LHS, BF16_POOL)])
+@pytest.mark.parametrize("streams,nframes", [(4, 3), (9, 2)])
+def test_several_streams_per_call_vs_oracle(mode, tol_l, tol_p, streams, nframes):
+    """The vision tower's serving shape at SigLIP-base size: one cache, `streams` independent clips, one new frame of each
+    per call (M = 784 / 1764 rows: the 64 x 64 GEMM tiles with the in-kernel LayerNorm fold in bf16 mode, the large split
+    tiles in the accurate mode), against the oracle's full-clip forward of every stream; and the short-clip forward of the
+    same frames outside streaming (same kernels, no cache)."""
+    import streamformer_amd as sa
+    cfg = siglip_base(num_hidden_layers=3)
+    sd = make_state_dict(cfg, seed=4)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    x = frames(21, (streams, nframes, 3, 224, 224))
+    want = O.forward(sd, cfg, x)
+    xd = x.cuda()
+    cache = m.new_cache(streams, cfg.num_frames)
+    outs = [m(xd[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(nframes)]
+    lhs = torch.cat([o.last_hidden_state for o in outs], 1)
+    pool = torch.cat([o.pooler_output for o in outs], 1)
+    assert maxabs(lhs, want["last_hidden_state"]) <= tol_l and maxabs(pool, want["pooler_output"]) <= tol_p
+    full = m(xd)
+    assert maxabs(full.last_hidden_state, want["last_hidden_state"]) <= tol_l and maxabs(full.pooler_output, want["pooler_output"]) <= tol_p
+
+
+@pytest.mark.gpu
 def test_feature_extraction_harness():
     """features.py against the reference's extraction loops restated on the oracle: sliding 6-frame windows with the
     clamped tail (extract_oad_feature.py:34-35, 122-136), last-frame pooled feature per window; long-video per-frame
