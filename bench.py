@@ -361,7 +361,11 @@ def main():
                            "launches": {"out_proj_K768": gemms["out_proj"], "mlp_down_K3072": gemms["mlp_down"]},
                            "hbm_view_K768": {"algorithmic_GB": 0.2312, "GBps": round(0.2312 / gemms["out_proj"]["ms"] * 1e3, 1),
                                              "frac_of_hbm_peak": round(0.2312 / gemms["out_proj"]["ms"] * 1e3 / PEAK_HBM_GBS, 4)},
-                           "other_gemms": {"mlp_up": gemms["mlp_up"], "qkv": gemms["qkv"]}}
+                           "other_gemms": {"mlp_up": gemms["mlp_up"], "qkv": gemms["qkv"]},
+                           "clock_note": "peak is the nominal 2.4 GHz figure the contract asks for; in-kernel cycle stamps put the shader clock of "
+                                         "these MFMA loops at 1.88 GHz on random data (power budget; the same binary runs 12 % faster on all-zero "
+                                         "operands), i.e. 1024 SIMDs x 16384 FLOP / 17.6 cycles x 1.88 GHz = 1790 TFLOP/s issue-bound (DESIGN.md 4.1c)",
+                           "frac_of_issue_bound_at_measured_clock": round(panel_tflops / 1790.0, 4)}
         by = nat.C.c_double()
         att = {}
         for which, name in ((0, "spatial"), (1, "temporal")):
