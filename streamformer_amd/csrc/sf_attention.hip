@@ -117,7 +117,7 @@ SF_DEVICE float softmax_tiles(f32x4_t (&s)[MAXNT2][2], int nt2, int g, float sca
         float e = 0.f;
         if (kt2 < nt2) {
           const float a = fmaf(s[kt2][hh][r], c, -mc);
-          e = ACC ? exp2f(a) : __builtin_amdgcn_exp2f(a);
+          e = __builtin_amdgcn_exp2f(a);      // v_exp_f32 (1 ulp) in both modes: arguments are <= 0, results below 2^-126 may flush
         }
         s[kt2][hh][r] = e;
         sum += e;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = 0.f;
-        if (jt * 16 < N) e = ACC ? exp2f(fmaf(s[jt][r], c2, -mc)) : __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
+        if (jt * 16 < N) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
         s[jt][r] = e;
         sum += e;
       }
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_large_kernel(Sf
     cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
     cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
     const float mn = fmaxf(m, cm);                     // finite: every chunk holds at least one valid key
-    const float alpha = ACC ? exp2f((m - mn) * c) : __builtin_amdgcn_exp2f((m - mn) * c);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
     const float mc = mn * c;
     float add = 0.f;
 #pragma unroll
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_large_kernel(Sf
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a = fmaf(s[kt2][hh][r], c, -mc);
-          const float e = ACC ? exp2f(a) : __builtin_amdgcn_exp2f(a);
+          const float e = __builtin_amdgcn_exp2f(a);
           s[kt2][hh][r] = e;
           add += e;
         }
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
 #pragma unroll
   for (int kp = 0; kp < KP; ++kp) {
     const float a = (sc[kp] - mx) * c2;
-    pr[kp] = F32 ? exp2f(a) : __builtin_amdgcn_exp2f(a);       // masked: 2^-inf = 0
+    pr[kp] = __builtin_amdgcn_exp2f(a);       // masked: 2^-inf = 0
     sum += pr[kp];
   }
   sum = wave_sum(sum);
