@@ -969,6 +969,9 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_kernel(SfAttnArgs p, int
 // V^T fragments transposed reads (ds_read_b64_tr_b16), natural key order, P stays in registers.  The MFMA kernel above
 // keeps the long caches, the accurate mode and T_new > 16.
 // ================================================================================================
+// ACC: hi + lo bf16 planes of q / k / v (the accurate mode's full-clip forward writes them instead of fp32), four images per
+// wave, three MFMAs per product, probabilities and context split into hi + lo in registers.
+template <bool ACC>
 __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p, int ntasks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -978,9 +981,11 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p,
   const int h = task % p.heads, bn = task / p.heads;
   const int b = bn / p.N, n = bn % p.N;
   const int Tk = p.Tk, Tq = p.Tq;
-  char* k_img = smem + wave * 10240;          // [32 rows][128 B]
+  char* k_img = smem + wave * (ACC ? 20480 : 10240);          // [32 rows][128 B]
   char* v_img = k_img + 4096;                 // [32 rows][128 B]
-  char* o_st = v_img + 4096;                  // [16 rows][128 B]
+  char* o_st = v_img + 4096;                  // [16 rows][128 B] (hi; ACC: lo at + 2048 ... see below)
+  char* kl_img = o_st + (ACC ? 4096 : 2048);  // ACC only
+  char* vl_img = kl_img + 4096;
   const bf16_t* kbase = reinterpret_cast<const bf16_t*>(p.k) + h * HD;
   const bf16_t* vbase = reinterpret_cast<const bf16_t*>(p.v) + h * HD;
 #pragma unroll
@@ -991,14 +996,21 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p,
     const size_t src = (((size_t)b * p.Tcap + key) * p.N + n) * (size_t)p.row_pitch_kv + chunk * 8;
     __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + src), (sp_lptr_t)(k_img + j * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + src), (sp_lptr_t)(v_img + j * 1024), 16, 0, 0);
+    if (ACC) {
+      __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + p.lo_plane_off + src), (sp_lptr_t)(kl_img + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + p.lo_plane_off + src), (sp_lptr_t)(vl_img + j * 1024), 16, 0, 0);
+    }
   }
-  bf16x8_t qf[2];
+  bf16x8_t qf[2], ql[2];
   {
     const int t = l15 < Tq ? l15 : Tq - 1;
     const size_t qrow = ((size_t)b * p.Tq_cap + p.q_t0 + t) * p.N + n;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      qf[ks] = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const bf16_t*>(p.q) + qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8);
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + qrow * p.row_pitch_q + h * HD + ks * 32 + g * 8;
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp);
+      if (ACC) ql[ks] = *reinterpret_cast<const bf16x8_t*>(qp + p.lo_plane_off);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1011,7 +1023,14 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p,
   for (int jt = 0; jt < 2; ++jt) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) acc = mfma16(sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g), qf[ks], acc);
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t kh = sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g);
+      if (ACC) {
+        acc = mfma16(sp_row_frag(kl_img, jt * 16 + l15, ks * 4 + g), qf[ks], acc);
+        acc = mfma16(kh, ql[ks], acc);
+      }
+      acc = mfma16(kh, qf[ks], acc);
+    }
     s[jt] = acc;
   }
   __builtin_amdgcn_sched_barrier(0);          // mask / maximum only after both tiles' MFMAs (see the spatial kernel)
@@ -1045,13 +1064,37 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p,
   const float inv = 1.0f / sum;
   const u32x4_t pu = {pack_bf2(s[0][0], s[0][1]), pack_bf2(s[0][2], s[0][3]), pack_bf2(s[1][0], s[1][1]), pack_bf2(s[1][2], s[1][3])};
   const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
+  bf16x8_t pl;
+  if (ACC) {
+    u32x4_t lu;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const f32x4_t& sv = s[w >> 1];
+      const int r0 = (w & 1) * 2;
+      lu[w] = pack_bf2(sv[r0] - bf2f(pu[w] & 0xffffu), sv[r0 + 1] - bf2f(pu[w] >> 16));
+    }
+    pl = __builtin_bit_cast(bf16x8_t, lu);
+  }
   f32x4_t o[4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(sp_tr_frag(v_img, 0, dt, lane), pf, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+  for (int dt = 0; dt < 4; ++dt) {
+    const bf16x8_t vh = sp_tr_frag(v_img, 0, dt, lane);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (ACC) {
+      acc = mfma16(sp_tr_frag(vl_img, 0, dt, lane), pf, acc);
+      acc = mfma16(vh, pl, acc);
+    }
+    o[dt] = mfma16(vh, pf, acc);
+  }
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     const int off = l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
-    *reinterpret_cast<u32x2_t*>(o_st + off) = (u32x2_t){pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+    const f32x4_t ov = o[dt] * inv;
+    const u32x2_t hv = {pack_bf2(ov[0], ov[1]), pack_bf2(ov[2], ov[3])};
+    *reinterpret_cast<u32x2_t*>(o_st + off) = hv;
+    if (ACC)
+      *reinterpret_cast<u32x2_t*>(o_st + 2048 + off) = (u32x2_t){pack_bf2(ov[0] - bf2f(hv[0] & 0xffffu), ov[1] - bf2f(hv[0] >> 16)),
+                                                                pack_bf2(ov[2] - bf2f(hv[1] & 0xffffu), ov[3] - bf2f(hv[1] >> 16))};
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1060,9 +1103,11 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p,
   for (int it = 0; it < 2; ++it) {
     const int idx = it * 64 + lane;
     const int r = idx >> 3, c = idx & 7;
-    if (r < Tq)
-      *reinterpret_cast<u32x4_t*>(p.ctx_hi + (((size_t)b * Tq + r) * p.N + n) * p.D + h * HD + c * 8) =
-          *reinterpret_cast<const u32x4_t*>(o_st + r * 128 + ((c ^ (r & 7)) << 4));
+    if (r < Tq) {
+      const size_t oo = (((size_t)b * Tq + r) * p.N + n) * p.D + h * HD + c * 8;
+      *reinterpret_cast<u32x4_t*>(p.ctx_hi + oo) = *reinterpret_cast<const u32x4_t*>(o_st + r * 128 + ((c ^ (r & 7)) << 4));
+      if (ACC) *reinterpret_cast<u32x4_t*>(p.ctx_lo + oo) = *reinterpret_cast<const u32x4_t*>(o_st + 2048 + r * 128 + ((c ^ (r & 7)) << 4));
+    }
   }
 }
 
@@ -1197,6 +1242,12 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
   }
 }
 
+// accurate mode: may the caller hand q / k / v of the temporal attention as hi + lo bf16 planes (short clips, no cache)?
+bool sf_temporal_planes_ok(int Tq, int Tk) {
+  const bool off = getenv("SF_DISABLE_TEMPORAL_DMA_ACC") != nullptr || getenv("SF_DISABLE_TEMPORAL_DMA") != nullptr;
+  return !off && Tq > 1 && Tq <= 16 && Tk <= 32;
+}
+
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.Tq <= 0 || a.Tk <= 0 || a.B <= 0 || a.N <= 0) return hipErrorInvalidValue;
   static const bool decode_off = getenv("SF_DISABLE_TEMPORAL_DECODE") != nullptr;
@@ -1213,7 +1264,16 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
   static const bool tdma_off = getenv("SF_DISABLE_TEMPORAL_DMA") != nullptr;
   if (!accurate && !tdma_off && a.Tq <= 16 && a.Tk <= 32 && (a.row_pitch_kv % 8) == 0) {     // every full 16-frame clip
     const int ntasks = a.B * a.N * a.heads;
-    hipLaunchKernelGGL(sf_temporal_attn_dma_kernel, dim3((ntasks + 3) / 4), dim3(256), 4 * 10240, s, a, ntasks);
+    hipLaunchKernelGGL(sf_temporal_attn_dma_kernel<false>, dim3((ntasks + 3) / 4), dim3(256), 4 * 10240, s, a, ntasks);
+    return hipGetLastError();
+  }
+  if (accurate && !a.in_is_f32) {        // hi + lo planes (sf_temporal_planes_ok)
+    if (a.Tq > 16 || a.Tk > 32 || a.lo_plane_off <= 0 || (a.row_pitch_kv % 8) || (a.lo_plane_off % 8)) return hipErrorInvalidValue;
+    const int ntasks = a.B * a.N * a.heads;
+    static SfPerDeviceOnce attr_t;
+    if (attr_t.first())
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 20480);
+    hipLaunchKernelGGL(sf_temporal_attn_dma_kernel<true>, dim3((ntasks + 3) / 4), dim3(256), 4 * 20480, s, a, ntasks);
     return hipGetLastError();
   }
   const int tkp = (a.Tk + 31) & ~31;

@@ -686,13 +686,18 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     // ---- temporal attention (modeling:937-958) ---------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_t.g, l.ln_t.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
     void* tq = layer_tqkv ? layer_tqkv[li] : ws.tqkv;
-    HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, qkv_epi, s, (float*)tq, (bf16_t*)tq, nullptr, nullptr, 1.f,
+    // accurate mode, whole short clip (no cache): hi + lo bf16 planes for the DMA kernel, like the spatial attention below
+    const bool tplanes = acc && !layer_tqkv && cap == T && t_past == 0 && sf_temporal_planes_ok(T, T);
+    const size_t tsz = tplanes ? 2 : esz;
+    HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, tplanes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)tq, (bf16_t*)tq,
+                       tplanes ? (bf16_t*)tq + (size_t)M * 3 * D : nullptr, nullptr, 1.f,
                        3 * D, T * N, cap * N, t_past * N, fold_st, nullptr, sfold));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
-      a.q = tq; a.k = (char*)tq + (size_t)D * esz; a.v = (char*)tq + (size_t)2 * D * esz;
-      a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.q = tq; a.k = (char*)tq + (size_t)D * tsz; a.v = (char*)tq + (size_t)2 * D * tsz;
+      a.in_is_f32 = acc && !tplanes; a.lo_plane_off = tplanes ? (long long)M * 3 * D : 0;
+      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.B = B; a.Tq = T; a.Tk = t_past + T; a.Tcap = cap; a.t_past = t_past;
       a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = t_past;
       a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
@@ -1066,7 +1071,7 @@ extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, 
   bf16_t* qb = c.take<bf16_t>(rows * 3 * D);
   const void* base = qkv;
   size_t esz = 4;
-  const bool planes = acc && !temporal_layout && sf_spatial_planes_ok(L, false);
+  const bool planes = acc && (temporal_layout ? sf_temporal_planes_ok(L, L) : sf_spatial_planes_ok(L, false));
   bf16_t* ql = nullptr;
   if (!acc || planes) {
     if (planes) ql = c.take<bf16_t>(rows * 3 * D);
@@ -1186,6 +1191,10 @@ extern "C" int sf_bench_attention(sf_encoder* e, int B, int T, int which, int it
   a.in_is_f32 = acc; a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 0.125f;
   a.ctx_hi = ch; a.ctx_lo = cl; a.D = D; a.N = N;
   if (which == 0 && acc && sf_spatial_planes_ok(N, false)) {      // what the forward does: hi + lo planes in the fp32 tensor's bytes
+    a.k = qkv + (size_t)D * 2; a.v = qkv + (size_t)2 * D * 2;
+    a.in_is_f32 = 0; a.lo_plane_off = (long long)M * 3 * D;
+  }
+  if (which == 1 && acc && sf_temporal_planes_ok(T, T)) {
     a.k = qkv + (size_t)D * 2; a.v = qkv + (size_t)2 * D * 2;
     a.in_is_f32 = 0; a.lo_plane_off = (long long)M * 3 * D;
   }

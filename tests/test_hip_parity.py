@@ -201,6 +201,18 @@ def _spatial_attention_case(sa, frames_, N, heads, mode):
                                                   (2, 16, 5, 3, 0), (1, 33, 2, 1, 1), (1, 100, 1, 2, 1)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_op_temporal_attention(sa, B, L, Nt, heads, causal, mode):
+    _temporal_attention_case(sa, B, L, Nt, heads, causal, mode)
+
+
+@pytest.mark.parametrize("B,L,Nt,heads,causal", [(2, 16, 9, 2, 1), (1, 5, 4, 12, 1), (2, 16, 5, 3, 0)])
+def test_op_temporal_attention_accurate_fp32_inputs(sa, B, L, Nt, heads, causal, monkeypatch):
+    """Short sequences in the accurate mode on the register-staged kernel with fp32 q / k / v (what streaming keeps using);
+    the plain call above takes the DMA kernel on hi + lo planes for L <= 16."""
+    monkeypatch.setenv("SF_DISABLE_TEMPORAL_DMA_ACC", "1")
+    _temporal_attention_case(sa, B, L, Nt, heads, causal, 1)
+
+
+def _temporal_attention_case(sa, B, L, Nt, heads, causal, mode):
     g = torch.Generator().manual_seed(L * 17 + Nt)
     D = heads * 64
     qkv = torch.randn(B, L, Nt, 3 * D, generator=g) * 1.5          # the encoder's [B,T,N,3D] layout
