@@ -804,6 +804,11 @@ def test_several_streams_per_call_vs_oracle(mode, tol_l, tol_p, streams, nframes
     assert maxabs(lhs, want["last_hidden_state"]) <= tol_l and maxabs(pool, want["pooler_output"]) <= tol_p
     full = m(xd)
     assert maxabs(full.last_hidden_state, want["last_hidden_state"]) <= tol_l and maxabs(full.pooler_output, want["pooler_output"]) <= tol_p
+    again = m(xd)                                   # no atomics, fixed reduction orders: bit-reproducible
+    assert torch.equal(full.last_hidden_state, again.last_hidden_state) and torch.equal(full.pooler_output, again.pooler_output)
+    cache.reset()
+    outs2 = [m(xd[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(nframes)]
+    assert torch.equal(torch.cat([o.last_hidden_state for o in outs2], 1), lhs)
 
 
 @pytest.mark.gpu
