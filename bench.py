@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="batches in flight: consecutive steps alternate over this many HIP streams")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run of the N>1 path with every rank on cuda:0")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="N=1 only: create the process group anyway (world_size 1) and run every collective of the N>1 path "
+                         "through it — barriers, max-over-ranks, bucketed gradient all-reduce, caption all-gather; the way to "
+                         "execute the RCCL branches on a one-GPU box")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward = BASELINE configs[1] (the headline metric); train = configs[2]/[3]: one multitask "
                          "pre-training step (forward + loss + backward + gradient all-reduce + AdamW) per GPU batch")
@@ -104,22 +108,37 @@ def timed_steps(model, x, steps, warmup, dist, world, nstreams=1):
     for i in range(max(warmup, nstreams)):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    return max_over_ranks(dt, dist)
+
+
+def max_over_ranks(dt, dist):
+    """MAX all-reduce of the elapsed time (on the GPU for RCCL, on the host for gloo)."""
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def ranks_seen(dist, rank, dev):
+    """What every rank of the job says about itself, gathered on all ranks (one all_gather_object)."""
+    me = {"rank": rank, "device": int(dev.index or 0), "gpu": torch.cuda.get_device_name(dev), "pid": os.getpid()}
+    if dist is None:
+        return [me]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, me)
+    return got
 
 
 # forward + input-gradient + weight-gradient products, minus the weight-gradient GEMMs of the frozen spatial
@@ -136,7 +155,8 @@ def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
     sd = sa.make_state_dict(cfg, seed=0, lora=True)
     B, T, D = args.batch, cfg.num_frames, cfg.hidden_size
     tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device=dev,
-                             lr=scaled_lr(2e-5, B, 1, world), weight_decay=0.05)
+                             lr=scaled_lr(2e-5, B, 1, world), weight_decay=0.05,
+                             collectives_at_world_1=dist is not None and world == 1)
     g = torch.Generator().manual_seed(2000 + rank)
     x = torch.randn(B, T, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
     lab = torch.randn(20, D, generator=g)
@@ -144,34 +164,58 @@ def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
     tasks = [("retrieval", {"kind": "retrieval", "text": torch.randn(B, D, generator=g).to(dev)}),
              ("localization", {"kind": "localization", "label_emb": lab,
                                "labels": torch.randint(-1, 20, (B, T), generator=g).to(dev)})]
-    losses = []
-    for i in range(warmup):
-        tr.micro_step(*tasks[i % 2][:1], x, tasks[i % 2][1])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        losses.append(tr.micro_step(tasks[i % 2][0], x, tasks[i % 2][1]))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def run(n, w):
+        out = []
+        for i in range(w):
+            tr.micro_step(tasks[i % 2][0], x, tasks[i % 2][1])
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            out.append(tr.micro_step(tasks[i % 2][0], x, tasks[i % 2][1]))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return max_over_ranks(time.perf_counter() - t0, dist), out
+
+    dt, losses = run(steps, warmup)
     value = world * B * T * steps / dt
+    per_task = {}
+    for i, l in enumerate(losses):                 # the two tasks have different loss scales: report them apart
+        per_task.setdefault(tasks[i % 2][0], []).append(round(float(l), 4))
     res = {"value": round(value, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
-           "clips_per_gpu": B, "losses_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "clips_per_gpu": B,
+           "losses_per_task_first_last": {k: [v[0], v[-1]] for k, v in per_task.items()},
            "trainable_params": int(sum(e["numel"] for e in tr.layout.values() if e["trainable"])),
            "grad_allreduce_MB": round(tr.n_train * 4 / 1e6, 1), "allreduce_buckets": len(tr.buckets),
            "workspace_GiB": round(tr._ws.numel() / 2**30, 2),
            "e2e_mfma_frac": round(value / world * TRAIN_GFLOP_PER_FRAME / 1e3 / PEAK_BF16_TFLOPS, 4),
            "recipe": "SigLIP-base + LoRA r=32 on spatial attention, spatial base frozen, retrieval/localization alternating, "
                      "AdamW (fp32 master weights, bf16 MFMA operands), update_freq 1"}
+    if dist is not None:
+        # How much of the gradient all-reduce is exposed: the same K steps with the collectives switched off (every rank
+        # steps on its local gradients), and the bucket all-reduces alone on an idle GPU, HIP-event timed.
+        n2 = max(2, min(steps, 6))
+        tr.comm_enabled = False
+        dt_nc, _ = run(n2, 1)
+        tr.comm_enabled = True
+        iso = tr.time_bucket_allreduce(iters=3)
+        iso_ms = max_over_ranks(iso, dist)
+        step_ms, nocomm_ms = 1e3 * dt / steps, 1e3 * dt_nc / n2
+        exposed = max(0.0, step_ms - nocomm_ms)
+        nbytes = tr.n_train * (2 if tr.grad_reduce_dtype == "bf16" else 4)
+        res["allreduce_ms"] = {"isolated": round(iso_ms, 3), "exposed": round(exposed, 3),
+                               "overlapped": round(max(0.0, iso_ms - exposed), 3),
+                               "step_ms_without_collectives": round(nocomm_ms, 3),
+                               "wire_dtype": tr.grad_reduce_dtype,
+                               "busbw_GBps": round(2.0 * (world - 1) / max(world, 1) * nbytes / max(iso_ms, 1e-6) / 1e6, 1),
+                               "how": "isolated = HIP-event time of the bucket all-reduces on an idle GPU (max over ranks); exposed = "
+                                      "step time minus the same steps with the collectives switched off; overlapped = isolated - exposed"}
+        res["backend"] = dist.get_backend()
     if with_cpu and rank == 0:
         # CPU baseline of the same step: the oracle's autograd + torch.optim.AdamW on ONE clip (bounded sample)
         from oracle import train_oracle as TO
@@ -244,28 +288,56 @@ def streaming_bench(dev):
                               "config": "same model, 8 independent streams advance one frame per call (one cache, B = 8)"}}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) with the same command line; rank 0 of the children prints the one JSON line."""
+    import socket
+    import subprocess
+    if not args.same_device and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node "
+                         "(--same-device puts every rank on cuda:0 for a dry run)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's P2P buffers over xGMI need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    if not launched and args.gpus > 1:
+        self_launch(args)
+    args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.init_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if not launched:                    # --init-dist at N = 1 without a launcher: a private rendezvous
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            kw = dict(init_method=f"tcp://127.0.0.1:{s.getsockname()[1]}", rank=0, world_size=1)
+            s.close()
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, **kw)
+    seen = ranks_seen(dist, rank, dev)
 
     import streamformer_amd as sa
     from streamformer_amd import _native as nat
@@ -279,11 +351,14 @@ def main():
                    "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: multitask pre-training step, "
                                           f"{args.batch} clips x 16 x 224^2 per GPU, " + r["recipe"],
                               "global_batch_clips": args.batch * world, "parallelism": f"dp{world}",
-                              "collective": "RCCL all-reduce of the fp32 gradient buffer in buckets issued behind the staged backward"
-                                            if world > 1 else "none"}}
+                              "collective": (f"{'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of the fp32 gradient buffer in "
+                                             f"{r['allreduce_buckets']} buckets issued behind the staged backward + one all-gather of the "
+                                             "caption features per retrieval step") if dist is not None else "none"}}
             out.update({k: v for k, v in r.items() if k not in ("value", "unit", "ms_per_step", "steps", "recipe")})
+            if dist is not None:
+                out["ranks_seen"] = seen
             print(json.dumps(out), flush=True)
-        if world > 1 and dist.is_initialized():
+        if dist is not None and dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -309,14 +384,22 @@ def main():
         "config": {"workload": f"SigLIP-base StreamFormer encoder forward, {B} clips x 16 x 224^2 per GPU, "
                                "random-init de-trivialised weights, causal temporal attention",
                    "global_batch_clips": B * world, "frames_per_clip": T, "parallelism": f"dp{world}",
-                   "steps_in_flight": args.streams},
+                   "steps_in_flight": args.streams,
+                   "collective": "none on the data path (clips are independent); start/stop barriers and the max-over-ranks "
+                                 "reduction of the elapsed time only" + (f" [{args.backend}]" if dist is not None else "")},
         "e2e_mfma_frac": round(value / world * GFLOP_PER_FRAME / 1e3 / PEAK_BF16_TFLOPS, 4),
         "streams_in_flight": args.streams,
     }
+    if dist is not None:
+        out["ranks_seen"] = seen
     if args.streams > 1:
         dt1 = timed_steps(model, x, args.steps, 2, dist, world, 1)
         out["single_stream"] = {"value": round(frames / dt1, 1), "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
 
+    if args.profile and rank != 0:
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if rank == 0:
         # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ------
         M = B * T * cfg.num_patches
@@ -378,6 +461,9 @@ def main():
         del ws
         if args.profile:
             print(json.dumps(out), flush=True)
+            if dist is not None and dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
             return
 
         # ---- accuracy vs the CPU oracle + the fp32-accurate mode's throughput -------------------
@@ -481,7 +567,7 @@ def main():
             except Exception as e:      # never lose the headline line to the extra measurement
                 out["train_step"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1 and dist.is_initialized():
+    if dist is not None and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

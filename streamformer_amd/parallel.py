@@ -29,11 +29,12 @@ def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+def all_gather_rows(t: torch.Tensor, group=None, at_world_1: bool = False) -> torch.Tensor:
     """[B, D] per rank -> [world*B, D] in rank order (same B on every rank): one all-gather into a single output
-    tensor (48 KB at B = 8, D = 768) instead of the reference's ring of P2P exchanges (modeling:244-295)."""
+    tensor (48 KB at B = 8, D = 768) instead of the reference's ring of P2P exchanges (modeling:244-295).
+    ``at_world_1``: issue the collective even in a 1-rank group (identity; exercises the backend on one GPU)."""
     rank, ws = world(group)
-    if ws == 1:
+    if ws == 1 and not (at_world_1 and dist.is_available() and dist.is_initialized()):
         return t
     t = t.contiguous()
     if dist.get_backend(group) == "nccl":            # RCCL: gather straight into one output tensor
@@ -55,10 +56,10 @@ def max_over_ranks(seconds: float, device=None, group=None) -> float:
     return float(t.item())
 
 
-def all_reduce_mean_(buckets: List[torch.Tensor], group=None) -> None:
+def all_reduce_mean_(buckets: List[torch.Tensor], group=None, at_world_1: bool = False) -> None:
     """In-place mean all-reduce of a few large flat gradient buckets (one collective each)."""
     rank, ws = world(group)
-    if ws == 1:
+    if ws == 1 and not (at_world_1 and dist.is_available() and dist.is_initialized()):
         return
     for b in buckets:
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)

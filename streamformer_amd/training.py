@@ -83,7 +83,7 @@ class StreamformerTrainer:
     def __init__(self, config: StreamformerConfig, state_dict: Dict[str, torch.Tensor], task_heads: Sequence[str],
                  freeze_spatial: bool = True, device="cuda", lr: float = 1e-3, weight_decay: float = 0.05,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0,
-                 grad_reduce_dtype: str = "fp32"):
+                 grad_reduce_dtype: str = "fp32", collectives_at_world_1: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamformerTrainer needs an AMD GPU: the training step runs only on the HIP library")
         if config.hidden_act not in _ACT:
@@ -108,6 +108,10 @@ class StreamformerTrainer:
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size(process_group) if dist_on else 1
         self.rank = torch.distributed.get_rank(process_group) if dist_on else 0
+        # world_size 1 normally skips every collective; with this flag they are issued anyway (a 1-rank all-reduce /
+        # all-gather is the identity), which is how the RCCL branches get executed and tested on a one-GPU box
+        self._collectives = dist_on and (self.world > 1 or bool(collectives_at_world_1))
+        self.comm_enabled = True            # bench.py switches the gradient all-reduce off to measure its exposed time
         c = config
         sc = nat.SfConfig(c.image_size, c.patch_size, c.num_channels, c.num_frames, c.hidden_size, c.num_hidden_layers,
                           c.num_attention_heads, c.intermediate_size, _ACT[c.hidden_act], int(c.qkv_bias),
@@ -353,12 +357,13 @@ class StreamformerTrainer:
         nst = len(self.stage_ranges)
         with torch.cuda.device(self.device):
             first = 0
-            plan = self.buckets if (reduce and self.world > 1) else [(nst - 1, 0, 0)]
+            reduce = reduce and self._collectives and self.comm_enabled
+            plan = self.buckets if reduce else [(nst - 1, 0, 0)]
             for last, off, n in plan:
                 nat.check(nat.lib.sf_trainer_backward(self._h, dp.data_ptr(), nat.ptr(dl), self.grads.data_ptr(), first, last,
                                                       ws.data_ptr(), ws.numel(), self._stream()))
                 first = last + 1
-                if reduce and self.world > 1:
+                if reduce:
                     sl = self.grads[off: off + n]
                     if self.grad_reduce_dtype == "bf16":
                         # half the bytes on the xGMI links (204 MB instead of 407 MB per step for SigLIP-base);
@@ -372,6 +377,27 @@ class StreamformerTrainer:
             if half is not None:
                 sl.copy_(half)
 
+    def time_bucket_allreduce(self, iters: int = 3) -> float:
+        """Milliseconds for ONE round of the bucket all-reduces of a step on an otherwise idle GPU (HIP events on the
+        current stream around `iters` rounds; a scratch buffer stands in for the gradients)."""
+        if not self._collectives:
+            return 0.0
+        wire = torch.bfloat16 if self.grad_reduce_dtype == "bf16" else torch.float32
+        buf = torch.zeros(self.n_train, dtype=wire, device=self.device)
+
+        def one_round():
+            for _, off, n in self.buckets:
+                torch.distributed.all_reduce(buf[off: off + n], group=self.group)
+        one_round()
+        torch.cuda.synchronize(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            one_round()
+        e1.record()
+        torch.cuda.synchronize(self.device)
+        return e0.elapsed_time(e1) / iters
+
     def loss_and_grad(self, task: str, pooler: torch.Tensor, task_input: dict):
         """Task-head loss (HIP kernels of heads.py) -> (loss [1], d loss/d pooler, d loss/d (scale, bias)).
 
@@ -384,9 +410,9 @@ class StreamformerTrainer:
         if task_input["kind"] == "retrieval":
             text = task_input["text"].to(self.device)
             rank = 0
-            if task_input.get("gather_negatives", True) and self.world > 1:
+            if task_input.get("gather_negatives", True) and self._collectives:
                 from .parallel import all_gather_rows
-                text = all_gather_rows(text.contiguous(), group=self.group)
+                text = all_gather_rows(text.contiguous(), group=self.group, at_world_1=True)
                 rank = self.rank
             return RetrievalHead(ls, lb).loss(pooler, text, rank=rank)
         return LocalizationHead(task_input["label_emb"], ls, lb).loss(pooler, task_input["labels"])

@@ -29,14 +29,19 @@ def load_npz(path):
     return {k: z[k] for k in z.files}
 
 
-def _rank_entry(fn, rank, world, port, args, q):
+def _rank_entry(fn, rank, world, port, args, q, backend="gloo"):
     """Child process of run_ranks: rendezvous on 127.0.0.1, run fn(rank, world, *args), report result or traceback."""
     import os
     import traceback
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     try:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":               # RCCL: one rank per device; bind the communicator to the device up front
+            import torch
+            torch.cuda.set_device(rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         q.put((rank, "ok", fn(rank, world, *args)))
     except BaseException:
         q.put((rank, "error", traceback.format_exc()))
@@ -46,8 +51,8 @@ def _rank_entry(fn, rank, world, port, args, q):
         os._exit(0)          # no destroy_process_group: a peer that died must not leave this rank waiting in a collective
 
 
-def run_ranks(fn, world, args=(), timeout=240):
-    """Run fn(rank, world, *args) in `world` spawned processes over gloo; returns [result of rank 0, 1, ...].
+def run_ranks(fn, world, args=(), timeout=240, backend="gloo"):
+    """Run fn(rank, world, *args) in `world` spawned processes over `backend` (gloo; "nccl" = RCCL, one rank per GPU); returns [result of rank 0, 1, ...].
     Never hangs: results are awaited with a deadline and every child is killed afterwards; a rank's exception is
     re-raised here with its traceback."""
     import socket
@@ -58,7 +63,7 @@ def run_ranks(fn, world, args=(), timeout=240):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_entry, args=(fn, r, world, port, args, q), daemon=True) for r in range(world)]
+    procs = [ctx.Process(target=_rank_entry, args=(fn, r, world, port, args, q, backend), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     out, err = {}, None
