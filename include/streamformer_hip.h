@@ -247,6 +247,13 @@ int sf_trainer_adamw_step(sf_trainer* tr, float* params_dev, float* grads_dev, f
                           float* exp_avg_sq_dev, int step, float lr, float beta1, float beta2, float eps,
                           float weight_decay, float grad_scale, const float* grad_sumsq_dev, float clip_norm,
                           int zero_grads, sf_stream stream);
+/* Per-slot step counts of the `n_extra` scalar slots ("extra.<i>": the task heads' logit_scale / logit_bias) for
+ * the adamw steps that follow: steps_host[i] > 0 = update slot i with bias corrections of that step count,
+ * 0 = leave slot i untouched (its gradient is still cleared).  torch.optim.AdamW skips parameters whose .grad is
+ * None and counts `step` per parameter: a head whose task was not scheduled in an accumulation window gets
+ * neither weight decay nor moment decay (tools/finetune_tools.py:560-570 + zero_grad(set_to_none)).  n = 0
+ * (or steps_host NULL) restores the default: every slot follows the step passed to sf_trainer_adamw_step.     */
+int sf_trainer_set_extra_steps(sf_trainer* tr, const int32_t* steps_host, int n);
 /* out_dev[0] = sum of squares of the trainable gradient prefix (for clip_grad_norm_)             */
 int sf_trainer_grad_sumsq(sf_trainer* tr, const float* grads_dev, float* out_dev, sf_stream stream);
 

@@ -17,6 +17,11 @@ from .modeling import (  # noqa: F401
     TimesformerVisionTower,
 )
 from . import heads  # noqa: F401
+from .multitask import (  # noqa: F401
+    StreamformerForMultiTaskingSigLIP,
+    TimesformerUniversalLocalizationHead,
+    TimesformerVideoRetrievalHead,
+)
 from .processing import TimesformerImageProcessor  # noqa: F401
 
 __version__ = "0.1.0"

@@ -115,6 +115,10 @@ struct SfAdamWArgs {
   // gradient from device memory, total_norm = sqrt(sum) * grad_scale, and multiplies g by min(1, clip_norm / (total_norm + 1e-6))
   const float* clip_sumsq; float clip_norm;
   int zero_grads;                              // 1: g is cleared by the same pass (optimizer.zero_grad fused)
+  // the last n_extra trainable segments are scalar slots with their own step counts (0 = skipped this step):
+  // torch.optim.AdamW keeps `step` per parameter and skips parameters without a gradient
+  int extra_seg0, n_extra;                     // n_extra = 0: no per-slot handling
+  int extra_steps[64];
 };
 hipError_t sf_launch_adamw(const SfAdamWArgs& a, hipStream_t s);
 // out[0] = sum g^2 (deterministic two-stage); partial >= 1024 floats

@@ -67,6 +67,9 @@ struct sf_trainer {
   int n_prep_jobs = 0, prep_tiles = 0;
   const float* params_dev = nullptr;
   int fB = 0, fT = 0;               // geometry of the last forward (0 = none)
+  int n_extra = 0, extra_seg0 = 0;  // the scalar slots are the last n_extra trainable segments
+  bool extra_steps_set = false;
+  int extra_steps[64] = {};
 };
 
 static int add_param(sf_trainer* t, const std::string& name, std::initializer_list<int64_t> shape, bool trainable) {
@@ -211,6 +214,10 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
       dec[i] = p->decay; tr[i] = p->trainable;
     }
     t->nseg = (int)idx.size();
+    int ntr = 0;
+    for (const TParam& p : t->params) ntr += p.trainable ? 1 : 0;
+    t->n_extra = n_extra;
+    t->extra_seg0 = ntr - n_extra;   // trainable segments come first in offset order, the extras last among them
     if (hipMalloc(&t->seg_end, ends.size() * sizeof(int)) != hipSuccess || hipMalloc(&t->seg_decay, dec.size()) != hipSuccess ||
         hipMalloc(&t->seg_train, tr.size()) != hipSuccess) {
       free_trainer_device(t); delete t;
@@ -785,8 +792,23 @@ extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, float* grads,
   a.bias_correction2 = 1.0f - powf(beta2, (float)step);
   a.grad_scale = grad_scale;
   a.clip_sumsq = grad_sumsq_dev; a.clip_norm = clip_norm; a.zero_grads = zero_grads;
+  a.extra_seg0 = t->extra_seg0;
+  a.n_extra = t->extra_steps_set ? t->n_extra : 0;
+  for (int i = 0; i < 64; ++i) a.extra_steps[i] = t->extra_steps[i];
   if (grad_sumsq_dev && !(clip_norm > 0.f)) return sf_set_err(SF_ERR_INVALID, "clip_norm must be positive");
   HIP_TRY(sf_launch_adamw(a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_set_extra_steps(sf_trainer* t, const int32_t* steps, int n) {
+  if (!t) return sf_set_err(SF_ERR_INVALID, "null argument");
+  if (!steps || n == 0) { t->extra_steps_set = false; return SF_OK; }
+  if (n != t->n_extra) return sf_set_err(SF_ERR_INVALID, "sf_trainer_set_extra_steps: %d entries for %d slots", n, t->n_extra);
+  for (int i = 0; i < n; ++i) {
+    if (steps[i] < 0) return sf_set_err(SF_ERR_INVALID, "negative step count");
+    t->extra_steps[i] = steps[i];
+  }
+  t->extra_steps_set = true;
   return SF_OK;
 }
 

@@ -552,6 +552,19 @@ __global__ __launch_bounds__(256) void sf_adamw_kernel(SfAdamWArgs a) {
     }
     if (!a.seg_train[lo]) continue;
     const float wd = a.seg_decay[lo] ? a.weight_decay : 0.f;
+    float bc1 = a.bias_correction1, bc2 = a.bias_correction2;
+    if (a.n_extra && lo >= a.extra_seg0) {       // a head scalar: its own step count, or skipped (16 threads per slot)
+      const int idx = lo - a.extra_seg0;
+      int st = 0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) st = (k == idx) ? a.extra_steps[k] : st;      // static kernarg offsets
+      if (st <= 0) {
+        if (a.zero_grads) reinterpret_cast<f32x4_t*>(a.g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
+      bc1 = 1.0f - powf(a.beta1, (float)st);
+      bc2 = 1.0f - powf(a.beta2, (float)st);
+    }
     f32x4_t p = reinterpret_cast<f32x4_t*>(a.p)[i];
     f32x4_t g = reinterpret_cast<const f32x4_t*>(a.g)[i];
     if (a.zero_grads) reinterpret_cast<f32x4_t*>(a.g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -563,8 +576,8 @@ __global__ __launch_bounds__(256) void sf_adamw_kernel(SfAdamWArgs a) {
       p[j] *= 1.0f - a.lr * wd;
       m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
       v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
-      const float denom = sqrtf(v[j]) / sqrtf(a.bias_correction2) + a.eps;
-      p[j] -= (a.lr / a.bias_correction1) * (m[j] / denom);
+      const float denom = sqrtf(v[j]) / sqrtf(bc2) + a.eps;
+      p[j] -= (a.lr / bc1) * (m[j] / denom);
     }
     reinterpret_cast<f32x4_t*>(a.p)[i] = p;
     reinterpret_cast<f32x4_t*>(a.m)[i] = m;

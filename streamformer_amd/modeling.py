@@ -395,6 +395,10 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         self.image_processor = TimesformerImageProcessor(size=(config.image_size, config.image_size),
                                                          crop_size={"height": config.image_size, "width": config.image_size})
         self._build_tree()
+        self._engine = None                 # autograd bridge state (autograd.TrainEngine), built on the first training forward
+        # Constructed in eval mode, like a from_pretrained() model: the autograd path (12 GB of saved activations per 8
+        # clips) is entered only after an explicit .train(), which every training loop issues (tools/finetune_tools.py:403).
+        self.eval()
         if device is not None:
             self.to(device)
 
@@ -588,9 +592,18 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
     def num_parameters(self) -> int:
         return sum(v.numel() for v in self._plist)
 
+    def _train_engine(self):
+        """The flat-buffer training state behind the autograd bridge; rebuilt when device / LoRA / freeze pattern change."""
+        from .autograd import TrainEngine
+        if self._engine is None or self._engine.signature != TrainEngine._signature(self):
+            self._engine = None
+            self._engine = TrainEngine(self)
+        return self._engine
+
     def _apply(self, fn, recurse: bool = True):
         out = super()._apply(fn, recurse)
         self._refresh_plist()            # .to() / .cuda() / .half(): new storage -> re-pack, drop device-bound scratch
+        self._engine = None
         self._ws.clear()
         self._pos_cache.clear()
         return out
@@ -618,6 +631,7 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         d["_ws"] = {}
         d["_pos_cache"] = {}
         d["_caches"] = None
+        d["_engine"] = None
         d.pop("_named", None)
         d.pop("_plist", None)
         return d
@@ -743,6 +757,20 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         B, T, C_, H, W = pixel_values.shape
         if C_ != c.num_channels:
             raise ValueError(f"expected {c.num_channels} channels, got {C_}")
+        streaming = bool(use_cache) or past_key_values is not None
+        if self.training and torch.is_grad_enabled() and not streaming and any(p.requires_grad for p in self._plist):
+            # the reference wrapper's training forward (modeling:1506-1511): outputs carry a grad_fn (autograd.py)
+            if output_attentions or output_hidden_states:
+                raise NotImplementedError("output_attentions / output_hidden_states are not available on the autograd path: "
+                                          "call under torch.no_grad() or in eval mode for them")
+            if self.device.type != "cuda":
+                raise RuntimeError("the StreamFormer HIP encoder runs on an AMD GPU only: call .to('cuda') first")
+            from .autograd import encoder_forward_with_grad
+            x = pixel_values.to(self.device)
+            lhs, pool = encoder_forward_with_grad(self, x)
+            if not return_dict:
+                return (lhs,)
+            return BaseModelOutputWithPooling(lhs, pool)
         self._sync(trust_versions=isinstance(past_key_values, StreamCache) and past_key_values.valid
                    and past_key_values.get_seq_length() > 0)
         dev = self.device
@@ -755,7 +783,6 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         N = (H // c.patch_size) * (W // c.patch_size)
         D, L = c.hidden_size, c.num_hidden_layers
         pos = self._pos_table(H, W)
-        streaming = bool(use_cache) or past_key_values is not None
         out_dtype = self.dtype if self.dtype in (torch.bfloat16, torch.float16) else None    # a half-precision module answers in kind
 
         def cast(t):

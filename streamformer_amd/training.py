@@ -83,7 +83,7 @@ class StreamformerTrainer:
     def __init__(self, config: StreamformerConfig, state_dict: Dict[str, torch.Tensor], task_heads: Sequence[str],
                  freeze_spatial: bool = True, device="cuda", lr: float = 1e-3, weight_decay: float = 0.05,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0,
-                 grad_reduce_dtype: str = "fp32", collectives_at_world_1: bool = False):
+                 grad_reduce_dtype: str = "fp32", collectives_at_world_1: bool = False, with_optimizer: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamformerTrainer needs an AMD GPU: the training step runs only on the HIP library")
         if config.hidden_act not in _ACT:
@@ -146,18 +146,23 @@ class StreamformerTrainer:
         dev = self.device
         self.params = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        # the autograd bridge (autograd.py) leaves the update to torch.optim: no moment buffers then
+        self.exp_avg = torch.zeros(self.n_train, dtype=torch.float32, device=dev) if with_optimizer else None
+        self.exp_avg_sq = torch.zeros(self.n_train, dtype=torch.float32, device=dev) if with_optimizer else None
         self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.micro = 0
+        # torch.optim.AdamW keeps `step` per parameter and skips parameters whose grad is None: a head whose task was not
+        # scheduled in an accumulation window is left alone (no decay, no moment decay) and keeps its own step count
+        self.head_steps = {t: 0 for t in self.task_heads}
+        self._touched = set()
         self._ws = None
         self._ws_key = None
         self._pooler = self._lhs = None
-        self.load_state_dict(state_dict)
-        for t in self.task_heads:           # modeling:1363-1364: each head deep-copies log(10) / -2
+        for t in self.task_heads:           # modeling:1363-1364: each head deep-copies log(10) / -2 ...
             self._view(f"task_heads.{t}.logit_scale").fill_(math.log(10.0))
             self._view(f"task_heads.{t}.logit_bias").fill_(-2.0)
+        self.load_state_dict(state_dict)    # ... unless the checkpoint carries trained values for this trainer's heads
         self.sync_weights()
 
     # ---- parameter access --------------------------------------------------------------------------------
@@ -204,33 +209,56 @@ class StreamformerTrainer:
 
     # ---- checkpoint / resume (reference layout: utils.py:608-636) ---------------------------------------
     def _optimizer_order(self) -> List[str]:
-        """Trainable parameter names in the order the reference model yields them from ``named_parameters()``
-        (encoder tree under ``timesformer.``, then the task heads): torch.optim numbers its state in that order,
-        group by group (optim_factory.py:59-104).  Pinned by tests/golden/f12_param_order.json."""
+        """Names in the order the reference WRAPPER yields trainable parameters from ``named_parameters()``: its own
+        ``logit_scale`` / ``logit_bias`` first (modeling:1363-1364 — trainable, never used by a head, so they never get a
+        gradient or optimizer state), then the encoder tree under ``timesformer.``, then the task heads' deep copies.
+        torch.optim numbers its state in that order, group by group (optim_factory.py:59-104).  Pinned by
+        tests/golden/f12_param_order.json (``wrapper_lora``: generated from the reference's wrapper class)."""
         from .modeling import expected_keys
-        enc = [k for k in expected_keys(self.config) if self.layout[k]["trainable"]]
+        enc = ["timesformer." + k for k in expected_keys(self.config) if self.layout[k]["trainable"]]
         heads = [k for t in self.task_heads for k in (f"task_heads.{t}.logit_scale", f"task_heads.{t}.logit_bias")]
-        return enc + heads
+        return ["logit_scale", "logit_bias"] + enc + heads
+
+    _WRAPPER_SCALARS = ("logit_scale", "logit_bias")
+
+    def _opt_entry(self, name: str) -> Optional[dict]:
+        if name in self._WRAPPER_SCALARS:
+            return None
+        return self._entry(name[len("timesformer."):] if name.startswith("timesformer.") else name)
+
+    def _opt_step_of(self, name: str) -> int:
+        if name.startswith("task_heads."):
+            return self.head_steps[name.split(".")[1]]
+        return self.step_count
 
     @staticmethod
     def _no_decay(name: str, shape) -> bool:
         return len(shape) == 1 or name.endswith(".bias")           # optim_factory.py:72-77, skip_list = ()
 
+    def _optimizer_groups(self) -> Dict[str, List[str]]:
+        """{"decay": [...], "no_decay": [...]} in order of first appearance, as get_parameter_groups fills them."""
+        groups: Dict[str, List[str]] = {}
+        for n in self._optimizer_order():
+            e = self._opt_entry(n)
+            shape = () if e is None else e["shape"]
+            groups.setdefault("no_decay" if self._no_decay(n, shape) else "decay", []).append(n)
+        return groups
+
     def optimizer_state_dict(self) -> dict:
         """``torch.optim.AdamW.state_dict()`` of the reference's optimizer over the same parameters: two groups in order
-        of first appearance ("decay" / "no_decay"), ids running through the groups, per-id ``step / exp_avg / exp_avg_sq``."""
-        names = self._optimizer_order()
-        groups: Dict[str, List[str]] = {}
-        for n in names:
-            groups.setdefault("no_decay" if self._no_decay(n, self._entry(n)["shape"]) else "decay", []).append(n)
+        of first appearance ("decay" / "no_decay"), ids running through the groups, per-id ``step / exp_avg / exp_avg_sq``.
+        Parameters that never received a gradient have no state entry, exactly as torch leaves them: the wrapper's
+        own scalars always, a head whose task has not run yet."""
+        groups = self._optimizer_groups()
         state, param_groups, pid = {}, [], 0
         for gname, members in groups.items():
             ids = []
             for n in members:
-                e = self._entry(n)
-                sl = slice(e["offset"], e["offset"] + e["numel"])
-                if self.step_count > 0:
-                    state[pid] = {"step": torch.tensor(float(self.step_count)),
+                e = self._opt_entry(n)
+                step = 0 if e is None else self._opt_step_of(n)
+                if step > 0:
+                    sl = slice(e["offset"], e["offset"] + e["numel"])
+                    state[pid] = {"step": torch.tensor(float(step)),
                                   "exp_avg": self.exp_avg[sl].view(e["shape"]).detach().cpu().clone(),
                                   "exp_avg_sq": self.exp_avg_sq[sl].view(e["shape"]).detach().cpu().clone()}
                 ids.append(pid)
@@ -242,26 +270,48 @@ class StreamformerTrainer:
         return {"state": state, "param_groups": param_groups, "param_names": [n for g in groups.values() for n in g]}
 
     def load_optimizer_state_dict(self, osd: dict) -> None:
-        """Inverse of :meth:`optimizer_state_dict`; also accepts the reference's own ``optimizer.state_dict()`` (same ids)."""
-        names = self.optimizer_state_dict()["param_names"]
+        """Inverse of :meth:`optimizer_state_dict`; also accepts the reference's own ``optimizer.state_dict()``: ids are
+        mapped by position in the reference's enumeration (the head names of a reference file — ``TaskRetrieval`` … — need
+        not match this trainer's), ids without state are skipped, the encoder's common step count becomes ``step_count``
+        and every head keeps its own.  Files written before round 3 (no ids for the wrapper's scalars) still load."""
+        names = [n for g in self._optimizer_groups().values() for n in g]
         n_ids = sum(len(g["params"]) for g in osd["param_groups"])
-        if n_ids != len(names):
-            raise ValueError(f"optimizer state covers {n_ids} parameters, this trainer has {len(names)} trainable ones")
+        if n_ids == len(names) - 2:                                 # round-2 layout of this trainer
+            names = [n for n in names if n not in self._WRAPPER_SCALARS]
+        elif n_ids != len(names):
+            raise ValueError(f"optimizer state covers {n_ids} parameters, this trainer's reference-side enumeration has {len(names)} "
+                             f"(2 wrapper scalars + {len(names) - 2} trainable)")
+        ids = [i for g in osd["param_groups"] for i in g["params"]]
+        by_id = dict(zip(ids, names))
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
-        steps = set()
+        enc_steps = set()
+        head_steps = {t: set() for t in self.task_heads}
         for pid, st in osd.get("state", {}).items():
-            n = names[int(pid)]
-            e = self._entry(n)
+            n = by_id[int(pid)]
+            e = self._opt_entry(n)
+            if e is None:
+                continue                                            # state on the wrapper's unused scalars: nothing to restore
             sl = slice(e["offset"], e["offset"] + e["numel"])
-            if tuple(st["exp_avg"].shape) != tuple(e["shape"]):
-                raise ValueError(f"optimizer state {pid} has shape {tuple(st['exp_avg'].shape)}, {n} is {tuple(e['shape'])}")
+            for key in ("exp_avg", "exp_avg_sq"):
+                if tuple(st[key].shape) != tuple(e["shape"]):
+                    raise ValueError(f"optimizer state {pid}: {key} has shape {tuple(st[key].shape)}, {n} is {tuple(e['shape'])}")
+                if not st[key].dtype.is_floating_point:
+                    raise ValueError(f"optimizer state {pid}: {key} has dtype {st[key].dtype}")
             self.exp_avg[sl].copy_(st["exp_avg"].to(torch.float32).reshape(-1))
             self.exp_avg_sq[sl].copy_(st["exp_avg_sq"].to(torch.float32).reshape(-1))
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one")
-        self.step_count = steps.pop() if steps else 0
+            step = int(float(st["step"]))
+            if n.startswith("task_heads."):
+                head_steps[n.split(".")[1]].add(step)
+            else:
+                enc_steps.add(step)
+        if len(enc_steps) > 1:
+            raise ValueError(f"encoder parameters carry different step counts ({sorted(enc_steps)}): the fused AdamW keeps one")
+        self.step_count = enc_steps.pop() if enc_steps else 0
+        for t, ss in head_steps.items():
+            if len(ss) > 1:
+                raise ValueError(f"logit_scale / logit_bias of head {t!r} carry different step counts {sorted(ss)}")
+            self.head_steps[t] = ss.pop() if ss else 0
         g0 = osd["param_groups"][0]
         self.lr = float(g0.get("lr", self.lr))
         decays = [float(g["weight_decay"]) for g in osd["param_groups"] if float(g.get("weight_decay", 0.0)) > 0]
@@ -272,6 +322,8 @@ class StreamformerTrainer:
         """The dict the reference's ``save_model`` writes on rank 0: wrapper-keyed weights (``timesformer.*``,
         ``task_heads.*``), optimizer state, epoch.  ``scaler`` is empty: bf16 operands need no loss scaling."""
         model = OrderedDict()
+        model["logit_scale"] = torch.tensor(math.log(10.0))        # the wrapper's own pair (modeling:1363-1364): never trained,
+        model["logit_bias"] = torch.tensor(-2.0)                   # kept so that the reference's load_state_dict finds its keys
         for k, v in self.state_dict().items():
             model[k if k.startswith("task_heads.") else "timesformer." + k] = v.detach().cpu()
         return {"model": model, "optimizer": self.optimizer_state_dict(), "epoch": int(epoch), "scaler": {}, "args": args}
@@ -427,6 +479,7 @@ class StreamformerTrainer:
         gs = gs * inv
         self.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
         self.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+        self._touched.add(task)
         self.micro += 1
         last = self.micro % update_freq == 0
         self.backward(gp * inv, reduce=last)
@@ -443,9 +496,22 @@ class StreamformerTrainer:
                        clip_grad: Optional[float] = None) -> None:
         """AdamW on the trainable prefix (gradient cleared by the same kernel), then refresh the bf16 working
         weights.  ``clip_grad``: torch.nn.utils.clip_grad_norm_ semantics, coefficient computed on the device."""
+        if self.exp_avg is None:
+            raise RuntimeError("this trainer was built without optimizer state (with_optimizer=False)")
         self.step_count += 1
         scale = 1.0 / self.world                                  # all-reduce summed; DDP averages
         sumsq = 0
+        if self.task_heads:
+            # heads that received a gradient since the last step (micro_step records them; a caller that adds head
+            # gradients by hand and never says which gets the plain behaviour: every head steps)
+            active = self._touched or set(self.task_heads)
+            steps = []
+            for t in self.task_heads:
+                if t in active:
+                    self.head_steps[t] += 1
+                steps += [self.head_steps[t] if t in active else 0] * 2
+            nat.check(nat.lib.sf_trainer_set_extra_steps(self._h, (C.c_int32 * len(steps))(*steps), len(steps)))
+            self._touched = set()
         with torch.cuda.device(self.device):
             if clip_grad is not None:
                 nat.check(nat.lib.sf_trainer_grad_sumsq(self._h, self.grads.data_ptr(), self._scratch.data_ptr(), self._stream()))
@@ -460,3 +526,4 @@ class StreamformerTrainer:
     def zero_grad(self) -> None:
         self.grads.zero_()
         self.micro = 0
+        self._touched = set()

@@ -101,7 +101,7 @@ def test_train_bench_two_ranks_dry_run():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2" and out["allreduce_buckets"] >= 2
-    assert all(np.isfinite(v) for v in out["losses_first_last"])
+    assert all(np.isfinite(v) for pair in out["losses_per_task_first_last"].values() for v in pair)
 
 
 def test_forward_bench_two_ranks_dry_run():

@@ -478,6 +478,14 @@ def _nccl_worker(rank, world, reduce_dtype):
         want = grads[1][1] if reduce_dtype == "fp32" else grads[1][1].to(torch.bfloat16).float()      # bf16 on the wire
         out[f"{task}_loss_equal"] = grads[0][0] == grads[1][0]
         out[f"{task}_grads_equal"] = bool(torch.equal(grads[0][1], want))
+        if not out[f"{task}_grads_equal"]:          # name the tensors that differ (shown in the assertion message)
+            bad = (grads[0][1] != want).nonzero().flatten()
+            where = {}
+            for i in bad[:2000].tolist():
+                for n, e in tr.layout.items():
+                    if e["trainable"] and e["offset"] <= i < e["offset"] + e["numel"]:
+                        where[n] = where.get(n, 0) + 1
+            out[f"{task}_mismatch"] = (int(bad.numel()), where, float((grads[0][1] - want).abs().max()))
         out[f"{task}_grad_absmax"] = float(want.abs().max())
         for t in (tr, ref):                          # the whole enqueue path: micro_step = the above + clipped AdamW
             t.zero_grad()
@@ -507,7 +515,7 @@ def test_rccl_world_size_1_step_equals_the_plain_step(reduce_dtype):
         if reduce_dtype == "fp32":
             assert r[f"{task}_params_maxdiff"] == 0.0, r
         else:
-            assert r[f"{task}_params_maxdiff"] < 1e-3, r          # one AdamW step of lr 1e-3 on bf16-rounded gradients
+            assert r[f"{task}_params_maxdiff"] < 2.5e-3, r        # <= two AdamW steps of lr 1e-3 on bf16-rounded gradients
     assert r["gather_identity"] and r["allreduce_identity"] and r["iso_ms"] > 0, r
 
 
@@ -573,13 +581,18 @@ def test_checkpoint_resume_and_reference_optimizer_layout(golden_dir, tmp_path):
     tr.save_checkpoint(path, epoch=2, args={"lr": 1e-3})
     ck = torch.load(path, map_location="cpu", weights_only=False)
     assert ck["epoch"] == 2 and set(ck) >= {"model", "optimizer", "epoch", "scaler", "args"}
-    assert all(k.startswith(("timesformer.", "task_heads.")) for k in ck["model"])
-    # (1) reference-side optimizer over reference-ordered parameters
+    assert all(k.startswith(("timesformer.", "task_heads.")) or k in ("logit_scale", "logit_bias") for k in ck["model"])
+    # (1) reference-side optimizer over the parameters of the reference WRAPPER in its named_parameters() order (F12
+    # "wrapper_lora": its own logit_scale / logit_bias first, then timesformer.*, then the heads' deep copies)
     with open(os.path.join(golden_dir, "f12_param_order.json")) as f:
-        rows = json.load(f)["lora"]
-    names = ["timesformer." + r[0] for r in rows if r[2]]
-    names += [f"task_heads.{t}.{k}" for t in ("retrieval", "localization") for k in ("logit_scale", "logit_bias")]
-    params = {n: torch.nn.Parameter(ck["model"][n].clone()) for n in names}
+        rows = [r for r in json.load(f)["wrapper_lora"] if r[2]]
+    ours = {"TaskRetrieval": "retrieval", "TaskLocalization": "localization"}
+
+    def our_name(n):
+        return ".".join(ours.get(part, part) for part in n.split("."))
+    params = {}
+    for n, shape, _ in rows:
+        params[n] = torch.nn.Parameter(ck["model"][our_name(n)].clone() if our_name(n) in ck["model"] else torch.zeros(shape))
     groups = {}
     for n, p in params.items():
         g = "no_decay" if (p.dim() == 1 or n.endswith(".bias")) else "decay"
@@ -588,18 +601,36 @@ def test_checkpoint_resume_and_reference_optimizer_layout(golden_dir, tmp_path):
     opt.load_state_dict(ck["optimizer"])
     assert [len(g["params"]) for g in opt.param_groups] == [len(g["params"]) for g in ck["optimizer"]["param_groups"]]
     assert opt.param_groups[0]["weight_decay"] == 0.05 and opt.param_groups[1]["weight_decay"] == 0.0
+    want_steps = {"retrieval": 1.0, "localization": 2.0}            # schedule: retrieval, localization, localization
     for n, p in params.items():
-        key = n[len("timesformer."):] if n.startswith("timesformer.") else n
+        if n in ("logit_scale", "logit_bias"):
+            assert p not in opt.state or not opt.state[p]           # the wrapper's unused scalars never get state
+            continue
+        key = our_name(n)
+        key = key[len("timesformer."):] if key.startswith("timesformer.") else key
         e = tr._entry(key)
         sl = slice(e["offset"], e["offset"] + e["numel"])
         st = opt.state[p]
-        assert float(st["step"]) == 3.0
+        assert float(st["step"]) == (want_steps[key.split(".")[1]] if key.startswith("task_heads.") else 3.0), n
         assert torch.equal(st["exp_avg"].flatten(), tr.exp_avg[sl].cpu()), n
         assert torch.equal(st["exp_avg_sq"].flatten(), tr.exp_avg_sq[sl].cpu()), n
+    # (1b) the other direction: a state dict written by that torch optimizer after one more step in which only the
+    # retrieval head and the encoder had gradients (torch skips grad-None parameters) loads into a trainer
+    for n, p in params.items():
+        if n.startswith("timesformer.") or "TaskRetrieval" in n:
+            p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    tr3 = StreamformerTrainer(cfg, make_state_dict(cfg, seed=8, lora=True), ["retrieval", "localization"], freeze_spatial=True, device=dev)
+    tr3.load_optimizer_state_dict(opt.state_dict())
+    assert tr3.step_count == 4 and tr3.head_steps == {"retrieval": 2, "localization": 2}
+    pq = params["timesformer.encoder.layer.1.intermediate.dense.weight"]
+    e = tr3._entry("encoder.layer.1.intermediate.dense.weight")
+    assert torch.equal(opt.state[pq]["exp_avg"].flatten(), tr3.exp_avg[e["offset"]: e["offset"] + e["numel"]].cpu())
     # (2) exact resume
     tr2 = StreamformerTrainer(cfg, make_state_dict(cfg, seed=99, lora=True), ["retrieval", "localization"], freeze_spatial=True,
                               device=dev, lr=5e-4, weight_decay=0.01)
     assert tr2.load_checkpoint(path) == 2 and tr2.step_count == 3 and tr2.lr == 1e-3 and tr2.weight_decay == 0.05
+    assert tr2.head_steps == tr.head_steps == {"retrieval": 1, "localization": 2}
     task, x, ti, _ = sched[3]
     la = tr.micro_step(task, x.to(dev), _to_dev(ti, dev))
     lb = tr2.micro_step(task, x.to(dev), _to_dev(ti, dev))
