@@ -167,6 +167,10 @@ hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s);
 int sf_skinny_max_rows();                                                        // sf_gemm_skinny.hip: largest M the skinny kernels take (several streams per call)
 bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split);                  // sf_gemm_skinny.hip (M <= 512)
 hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s);
+bool sf_gemm_tile_supported(const SfGemmArgs& a, bool split);                    // sf_gemm_tile.hip: one to a few clips (2560 < M <= sf_tile_max_rows())
+hipError_t sf_launch_gemm_tile(const SfGemmArgs& a, hipStream_t s);
+int sf_tile_max_rows();
+int sf_infold_max_rows();                                                        // largest M of the in-kernel-statistics LayerNorm fold (skinny + tile kernels)
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip
 hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 

@@ -512,7 +512,7 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.hn_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
   w.hm_hi = c.take<bf16_t>(F * I);
   w.hm_lo = acc ? c.take<bf16_t>(F * I) : nullptr;
-  w.res_bf = (!acc && M <= (size_t)sf_skinny_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
+  w.res_bf = (!acc && M <= (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
   w.lhs_stage = !need_tqkv ? c.take<float>(M * D) : nullptr;       // streaming carve (the cache holds the temporal qkv)
   w.pool_stage = !need_tqkv ? c.take<float>(F * D) : nullptr;
   w.bytes = (c.off + 255) & ~(size_t)255;
@@ -546,12 +546,14 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   return sf_launch_gemm(g, split, s);
 }
 
+static bool ln_fold_small_ok(const sf_encoder* e, int M);
+
 // LayerNorm folding needs the panel kernel as every residual producer (it emits the row statistics)
 // and the 256^2 kernel as every consumer (it applies them): true for the BASELINE shape.
 static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16) return false;
   if (getenv("SF_DISABLE_LN_FOLD")) return false;        // A/B switch for measurements
-  if (M <= sf_skinny_max_rows()) return false;           // the small-M fold (in-kernel statistics, skinny / 64 x 64 kernels) takes these
+  if (ln_fold_small_ok(e, M)) return false;              // the small-M fold (in-kernel statistics: skinny / 64 x 64 / tile kernels) takes these
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = e->D; g.epi = SF_EPI_RESID_F32;
@@ -568,20 +570,22 @@ static bool ln_fold_ok(const sf_encoder* e, int M) {
 // Small-M variant (the per-frame streaming step): the skinny GEMM derives the row statistics itself from the A fragments
 // it reads anyway, every residual producer only adds the bf16 copy of its output rows.
 static bool ln_fold_small_ok(const sf_encoder* e, int M) {
-  if (e->compute != SF_COMPUTE_BF16 || M > sf_skinny_max_rows()) return false;
+  if (e->compute != SF_COMPUTE_BF16 || M > sf_infold_max_rows()) return false;
   static const bool off = getenv("SF_DISABLE_STREAM_FOLD") != nullptr;
   if (off) return false;
+  auto takes = [](const SfGemmArgs& g) { return sf_gemm_skinny_supported(g, false) || sf_gemm_tile_supported(g, false); };
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.M = M; g.K = e->D; g.ldc = 3 * e->D; g.ln_inkernel = 1; g.ln_s = (const float*)1;
+  g.M = M; g.K = e->D; g.ldc = 3 * e->D; g.ln_inkernel = 1; g.ln_s = (const float*)1; g.out_hi = (bf16_t*)1;
   g.epi = SF_EPI_BF16; g.N = 3 * e->D;
-  if (!sf_gemm_skinny_supported(g, false)) return false;
+  if (!takes(g)) return false;
   g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.ldc = e->I;
-  if (!sf_gemm_skinny_supported(g, false)) return false;
+  if (!takes(g)) return false;
   g.ln_inkernel = 0; g.ln_s = nullptr; g.epi = SF_EPI_RESID_F32; g.N = e->D; g.ldc = e->D; g.out_hi = (bf16_t*)1;
-  if (!sf_gemm_skinny_supported(g, false)) return false;      // producers (they add the bf16 copy): K = D ...
+  g.out_f32 = (float*)1; g.resid = (const float*)1;
+  if (!takes(g)) return false;                                // producers (they add the bf16 copy): K = D ...
   g.K = e->I;
-  return sf_gemm_skinny_supported(g, false);                  // ... and K = I
+  return takes(g);                                            // ... and K = I
 }
 
 static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfRowIndex* idx) {

@@ -231,10 +231,19 @@ int sf_wall_clock_ticks(int ns) {
   return (int)((long long)ns * khz / 1000000);
 }
 
+int sf_infold_max_rows() {
+  const int a = sf_skinny_max_rows(), b = sf_tile_max_rows();
+  return a > b ? a : b;
+}
+
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
   if (a.aux_mode) return sf_gemm256_aux_supported(a) && !split ? sf_launch_gemm256(a, s) : hipErrorInvalidValue;
-  if (a.ln_inkernel) return sf_gemm_skinny_supported(a, split) ? sf_launch_gemm_skinny(a, split, s) : hipErrorInvalidValue;
+  if (a.ln_inkernel) {
+    if (sf_gemm_skinny_supported(a, split)) return sf_launch_gemm_skinny(a, split, s);
+    return sf_gemm_tile_supported(a, split) ? sf_launch_gemm_tile(a, s) : hipErrorInvalidValue;
+  }
   if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);
+  if (sf_gemm_tile_supported(a, split)) return sf_launch_gemm_tile(a, s);
   if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
   return sf_launch_gemm128(a, split, s);

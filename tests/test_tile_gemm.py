@@ -1,0 +1,59 @@
+"""The tile GEMM family of one to a few clips per call (sf_gemm_tile.hip; 2560 < M <= SF_TILE_MAX_M): every candidate tile
+shape forced in turn (lab switch SF_TILE_SHAPE, read once per process -> each case runs in its own interpreter) on ragged
+row counts, every epilogue sf_op_linear reaches (plain fp32, residual read-modify-write, erf-GELU bf16), and the whole
+SigLIP-base forward of ONE clip (README.md:55-71: LayerNorm-folded consumers, embedding epilogue, KV-cache row remap of the
+temporal qkv) against the reference's outputs (fixture F2)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PROBE = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["SF_ROOT"])
+import streamformer_amd as sa
+from tests.test_hip_parity import _linear
+from tests.helpers import load_npz, maxabs
+worst = 0.0
+for (M, N, K) in [(3136, 768, 768), (2999, 768, 3072), (4100, 2304, 768), (2600, 3072, 256), (3136, 1536, 768)]:
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g)
+    ref = x.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+    e1 = maxabs(_linear(sa, x, w, b, None, 1.0, False, 0), ref)
+    e2 = maxabs(_linear(sa, x, w, b, r, 0.37, False, 0), r.double() + 0.37 * ref)
+    e3 = maxabs(_linear(sa, x, w, b, None, 1.0, True, 0), torch.nn.functional.gelu(ref))
+    assert e1 <= 1e-4 and e2 <= 1e-4 and e3 <= 2e-2 + 1e-4, (M, N, K, e1, e2, e3)
+    worst = max(worst, e1, e2)
+f2 = load_npz(os.path.join(os.environ["SF_ROOT"], "tests", "golden", "f2_base.npz"))
+cfg = sa.siglip_base()
+sd = sa.make_state_dict(cfg, seed=0)
+if sa.state_dict_sha256(sd) == str(f2["sha256"]):
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16"); m.load_state_dict(sd); m.cuda().eval()
+    torch.manual_seed(0)
+    x = torch.randn(1, 16, 3, 224, 224)
+    out = m(x.cuda())
+    d = maxabs(out.pooler_output, f2["randn_pooler_output"])
+    a = m(x.cuda()).pooler_output
+    assert torch.equal(a, out.pooler_output)          # bit-reproducible
+    assert d <= 3e-2, d
+    print("F2 pooler max-abs", d)
+print("OK worst", worst)
+'''
+
+
+@pytest.mark.parametrize("shape", ["auto", "0", "1", "2", "3", "4", "5"])
+def test_tile_gemm_shapes(shape):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["SF_ROOT"] = ROOT
+    env["SF_TILE_MAX_M"] = "6272"
+    if shape != "auto":
+        env["SF_TILE_SHAPE"] = shape
+    r = subprocess.run([sys.executable, "-c", PROBE], env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0 and "OK worst" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
