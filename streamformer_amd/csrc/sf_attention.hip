@@ -1137,13 +1137,16 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
   if (task >= ntasks) return;
   const int h = task % p.heads, bn = task / p.heads;
   const int b = bn / p.N, n = bn % p.N;
-  const int Tk = p.Tk;
+  // the cache position by value, or (streamed frame replayed from the position-free graph) from device memory
+  const int t_past = p.t_past_dev ? *p.t_past_dev : p.t_past;
+  const int q_t0 = p.t_past_dev ? t_past : p.q_t0;
+  const int Tk = p.t_past_dev ? min(t_past + 1, KP * 64) : p.Tk;
   constexpr int ESZ = F32 ? 4 : 2;
   constexpr int QL = F32 ? 16 : 8;                 // 16-byte loads per 64-dim row
   const char* qb = reinterpret_cast<const char*>(p.q);
   const char* kb = reinterpret_cast<const char*>(p.k);
   const char* vb = reinterpret_cast<const char*>(p.v);
-  const size_t qoff = ((((size_t)b * p.Tq_cap + p.q_t0) * p.N + n) * p.row_pitch_q + h * HD) * ESZ;
+  const size_t qoff = ((((size_t)b * p.Tq_cap + q_t0) * p.N + n) * p.row_pitch_q + h * HD) * ESZ;
 
   // ---- issue: q (same 128 / 256 bytes for every lane), this lane's key rows, this lane's V chunks -------------------
   u32x4_t qv[QL], kv[KP][QL], vv[KP][8][F32 ? 2 : 1];
@@ -1171,7 +1174,7 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
   __builtin_amdgcn_sched_barrier(0);     // keep every load of the task ahead of the arithmetic (one latency per task)
 
   // ---- scores -----------------------------------------------------------------------------------------------------
-  const int qpos = p.t_past;                       // absolute frame index of the one query
+  const int qpos = t_past;                         // absolute frame index of the one query
   float sc[KP];
   float mx = -INFINITY;
 #pragma unroll

@@ -143,6 +143,10 @@ struct SfGemmArgs {
   int ldc;                                  // output row pitch in elements
   // output row remap (KV-cache appends): out_row = (m / grp_rows) * grp_stride + grp_off + m % grp_rows
   int grp_rows, grp_stride, grp_off;
+  // streaming: the cache position comes from DEVICE memory (one hipGraph serves every position):
+  //   grp_off += *grp_off_dev * grp_off_scale
+  const int* grp_off_dev; int grp_off_scale;
+  int w_nt;                                 // skinny kernels: non-temporal policy on the weight loads (lab switch SF_SKINNY_NT)
   // LayerNorm folded into the NEXT Linear (bf16 mode): a residual producer also emits bf16(x) in out_hi
   // and per-row partial sums {sum x, sum x^2} per 384-column half in ln_stats_out [M][4]; the consumer
   // (A = bf16(x), W' = W * gamma) finishes y = rstd * (acc - mean * ln_s[n]) + bias' in its epilogue.
@@ -157,6 +161,11 @@ struct SfGemmArgs {
   int aux_mode;
   bf16_t* aux;                              // [*, ldc], same row remap as the output
 };
+SF_DEVICE size_t sf_out_row(const SfGemmArgs& p, int m) {
+  if (p.grp_rows <= 0) return (size_t)m;
+  const int off = p.grp_off + (p.grp_off_dev ? *p.grp_off_dev * p.grp_off_scale : 0);
+  return (size_t)(m / p.grp_rows) * p.grp_stride + off + (m % p.grp_rows);
+}
 // nanoseconds -> ticks of wall_clock64() on the current device (s_memrealtime: 100 MHz on MI355X; queried once)
 int sf_wall_clock_ticks(int ns);
 hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s);      // dispatches skinny / panel / 256^2 / 128^2
@@ -183,19 +192,27 @@ hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* 
 // pixels [F,C,H,W] -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw).
 // pixel_kind 0 fp32, 1 bf16, 2 uint8 raw frames normalised on the fly: y = x * scale[c] + shift[c]
 struct SfPixelNorm { float scale[4]; float shift[4]; };
+// Per-call parameters of a streamed frame, in DEVICE memory (written by one tiny launch in front of the graph replay): the
+// caller's input / output tensors and the cache position.  Kernels of the captured sequence read them through this block, so
+// ONE graph serves every call (no per-position capture, no staging copy of the outputs).
+struct SfStreamParams { const void* pixels; float* lhs; float* pooler; int t_past; int pad; };
+hipError_t sf_launch_stream_params(SfStreamParams* dst, const SfStreamParams& v, hipStream_t s);
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
-                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr);
+                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr,
+                              const SfStreamParams* sp = nullptr);     // sp != nullptr: pixels = sp->pixels (device read)
 // fp32 [n] -> bf16 hi (+lo)
 hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
 // two fp32 copies in one launch (b may be null): the streaming path's hand-over of graph-owned outputs to the caller's tensors
-hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s);
+hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s,
+                           const SfStreamParams* sp = nullptr);        // sp != nullptr: a_dst = sp->lhs, b_dst = sp->pooler (device reads)
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
 hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s);
 // out[t*N + n, :] = pos[n, :] + time_rows[t, :]   (the additive table of the embeddings, modeling:413-457)
 hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, float* out, int T, int N, int D, hipStream_t s);
 // gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)
 struct SfRowIndex { int n; int idx[256]; };
-hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s);
+hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s,
+                                 const int* base_dev = nullptr);       // row = idx[t] + *base_dev
 
 // ------------------------------------------------------------------------------------------------
 // attention
@@ -217,6 +234,7 @@ struct SfAttnArgs {
   //   q rows ((b*Tq_cap + q_t0 + t)*N + n), t < Tq ; kv rows ((b*Tcap + t)*N + n), t < Tk ;
   //   query t sits at absolute frame t_past + t (causal: keys <= that); ctx rows ((b*Tq + t)*N + n)
   int B, Tq, Tk, Tcap, t_past, causal, Tq_cap, q_t0;
+  const int* t_past_dev;              // single-query decode kernel only: t_past = q_t0 = *t_past_dev, Tk = t_past + 1 (position-free graph)
   bf16_t* ctx_hi; bf16_t* ctx_lo;     // [rows, D] output (lo only in accurate mode)
   int D;
   float* lse2_out;                    // spatial only, optional: base-2 log-sum-exp of the scaled scores per query,

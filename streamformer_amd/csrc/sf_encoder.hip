@@ -104,10 +104,12 @@ struct sf_cache {
     void* ws = nullptr;
     const float* pos = nullptr;
     bool pooler = false;
+    int pixel_kind = 0;
   };
   std::map<uint32_t, GraphEntry> graphs;
   hipStream_t cap_stream = nullptr;   // captures are recorded on a private stream (the caller's may be the null stream, which
                                       // cannot capture) and replayed on the caller's
+  SfStreamParams* dparams = nullptr;  // device block {pixels, outputs, position} of the single-frame graph (one graph for all positions)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -526,7 +528,8 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
                              int M, int epi, hipStream_t s, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
                              const float* resid = nullptr, float alpha = 1.f, int ldc = 0, int grp_rows = 0,
                              int grp_stride = 0, int grp_off = 0, const float* ln_stats = nullptr,
-                             float* ln_stats_out = nullptr, bool ln_inkernel = false) {
+                             float* ln_stats_out = nullptr, bool ln_inkernel = false, const int* grp_off_dev = nullptr,
+                             int grp_off_scale = 0) {
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   const bool split = e->compute == SF_COMPUTE_BF16X3;
@@ -538,7 +541,8 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   g.out_f32 = out_f32; g.out_hi = out_hi; g.out_lo = split ? out_lo : nullptr;
   g.ldc = ldc ? ldc : lin.N;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride; g.grp_off = grp_off;
-  if (grp_rows > 0 && grp_stride == grp_rows && grp_off == 0) g.grp_rows = 0;   // identity remap (full clip)
+  g.grp_off_dev = grp_off_dev; g.grp_off_scale = grp_off_scale;
+  if (grp_rows > 0 && grp_stride == grp_rows && grp_off == 0 && !grp_off_dev) g.grp_rows = 0;   // identity remap (full clip)
   g.ln_stats = ln_stats; g.ln_s = ln_stats ? lin.ln_s : nullptr; g.ln_eps = e->cfg.layer_norm_eps;
   g.ln_stats_out = ln_stats_out;
   if (ln_inkernel) { g.ln_inkernel = 1; g.ln_s = lin.ln_s; }
@@ -615,7 +619,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
                        float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
                        const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
                        hipStream_t s, float* attentions = nullptr, int stages = 7, int la = 0, int lb = -1,
-                       int ready = 0) {
+                       int ready = 0, const SfStreamParams* sp = nullptr) {
+  // sp (streaming, T == 1, graph capture): the cache position is read on the DEVICE from sp->t_past by the kernels that need
+  // it (time-embedding row, KV-cache append row, single-query attention); t_past here only selects kernel variants
   // ready: 1 = the patch matrix is already in the workspace (the streaming entry extracts it outside its graph),
   //        2 = ws.res_bf already holds bf16(residual) (a later layer range of the same call)
   const bool patches_ready = (ready & 1) != 0;
@@ -637,7 +643,8 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   SfRowIndex idx;
   int rc = time_rows(e, t_past, T, streaming, &idx);
   if (rc) return rc;
-  HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s));
+  if (sp) { for (int t = 0; t < T; ++t) idx.idx[t] = t; }
+  HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s, sp ? &sp->t_past : nullptr));
   // LN folding (decided here because the folded path lets the embedding GEMM emit bf16(x) + row statistics itself:
   // panel kernel, out = table[m % (T N)] + patches W^T + b with table = pos + time rows)
   bool embed_panel = false;
@@ -695,7 +702,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     const size_t tsz = tplanes ? 2 : esz;
     HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, tplanes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)tq, (bf16_t*)tq,
                        tplanes ? (bf16_t*)tq + (size_t)M * 3 * D : nullptr, nullptr, 1.f,
-                       3 * D, T * N, cap * N, t_past * N, fold_st, nullptr, sfold));
+                       3 * D, T * N, cap * N, sp ? 0 : t_past * N, fold_st, nullptr, sfold, sp ? &sp->t_past : nullptr, N));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
@@ -704,6 +711,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.B = B; a.Tq = T; a.Tk = t_past + T; a.Tcap = cap; a.t_past = t_past;
       a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = t_past;
+      a.t_past_dev = sp ? &sp->t_past : nullptr;
       a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
       HIP_TRY(sf_launch_temporal_attention(a, acc, s));
     }
@@ -903,6 +911,11 @@ extern "C" int sf_cache_create(sf_encoder* e, int B, int max_frames, int H, int 
     c->qkv.push_back(p);
   }
   c->bytes = per * e->L;
+  if (hipMalloc((void**)&c->dparams, sizeof(SfStreamParams)) != hipSuccess) {
+    for (void* q : c->qkv) (void)hipFree(q);
+    delete c;
+    return set_err(SF_ERR_HIP, "hipMalloc for the stream parameter block failed");
+  }
   *out = c;
   return SF_OK;
 }
@@ -923,6 +936,7 @@ extern "C" void sf_cache_destroy(sf_cache* c) {
   drop_graphs(c);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   for (void* q : c->qkv) (void)hipFree(q);
+  if (c->dparams) (void)hipFree(c->dparams);
   delete c;
 }
 extern "C" int sf_stream_workspace_bytes(sf_encoder* e, const sf_cache* c, int T_new, size_t* out) {
@@ -963,36 +977,64 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     return rc;
   }
   const int F = c->B * T_new, M = F * N;
-  const uint32_t key = ((uint32_t)c->len << 8) | (uint32_t)T_new;
+  // One new frame per call (the streaming step proper): ONE graph per cache serves every position.  The caller's tensors
+  // and the position reach the kernels through a 32-byte device block written by one tiny launch in front of the replay;
+  // only the number of 64-key passes of the single-query attention is compiled in (1 / 2 / 4 -> at most three graphs).
+  // Several frames per call keep one graph per (position, count): their attention kernels take the position by value.
+  static const bool posfree_off = getenv("SF_STREAM_GRAPH_PER_POSITION") != nullptr;
+  const bool posfree = T_new == 1 && !posfree_off && c->dparams != nullptr;
+  if (c->len + T_new > e->cfg.num_frames)
+    return set_err(SF_ERR_CAPACITY, "streaming needs time-embedding row %d but config.num_frames is %d", c->len + T_new - 1, e->cfg.num_frames);
+  const int kp = (c->len + T_new + 63) >> 6;
+  const int kcls = kp <= 1 ? 1 : (kp <= 2 ? 2 : 4);
+  const uint32_t key = posfree ? (0x80000000u | (uint32_t)kcls) : (((uint32_t)c->len << 8) | (uint32_t)T_new);
   sf_cache::GraphEntry& g = c->graphs[key];
   if (g.exec && (g.ws != workspace || g.pos != pos_dev || g.pooler != (pooler != nullptr))) {
     (void)hipGraphExecDestroy(g.exec);
     g.exec = nullptr;
   }
-  // patch extraction reads the caller's frames: outside the graph
-  HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels,
-                             c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm));
+  const int pk = pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0);
+  if (posfree && g.exec && g.pixel_kind != pk) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  if (!c->warmed) {
+    // first call of this cache: run eagerly once so that every lazy per-kernel set-up (hipFuncSetAttribute, device
+    // queries) has happened before a capture is opened
+    rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws, c->qkv.data(),
+                     c->cap, c->len, true, s);
+    if (rc == SF_OK) { c->len += T_new; c->warmed = true; }
+    if (!g.exec) c->graphs.erase(key);
+    return rc;
+  }
+  // patch extraction reads the caller's frames: outside the per-position graphs, inside the position-free one (indirect pointer)
+  if (!posfree)
+    HIP_TRY(sf_launch_patchify(pixels, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm));
   if (!g.exec) {
-    if (!c->warmed) {
-      // first call of this cache: run eagerly once so that every lazy per-kernel set-up (hipFuncSetAttribute, device
-      // queries) has happened before a capture is opened
-      rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws, c->qkv.data(),
-                       c->cap, c->len, true, s, nullptr, 7, 0, -1, 1);
-      if (rc == SF_OK) { c->len += T_new; c->warmed = true; }
-      c->graphs.erase(key);
-      return rc;
-    }
     hipGraph_t graph = nullptr;
     if (!c->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-    rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
-                     ws, c->qkv.data(), c->cap, c->len, true, c->cap_stream, nullptr, 7, 0, -1, 1);
+    hipError_t pe = hipSuccess;
+    if (posfree) {
+      // representative position of the class: selects the 64-key pass count; the kernels read the live one from dparams
+      int rep = kcls * 64 - T_new;
+      if (rep + T_new > c->cap) rep = c->cap - T_new;
+      if (rep + T_new > e->cfg.num_frames) rep = e->cfg.num_frames - T_new;
+      pe = sf_launch_patchify(nullptr, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, c->cap_stream,
+                              &e->pixel_norm, c->dparams);
+      rc = pe != hipSuccess ? SF_ERR_HIP :
+           run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
+                       ws, c->qkv.data(), c->cap, rep, true, c->cap_stream, nullptr, 7, 0, -1, 1, c->dparams);
+      if (rc == SF_OK)
+        pe = sf_launch_copy2(ws.lhs_stage, nullptr, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, nullptr, (size_t)F * e->D,
+                             c->cap_stream, c->dparams);
+    } else {
+      rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
+                       ws, c->qkv.data(), c->cap, c->len, true, c->cap_stream, nullptr, 7, 0, -1, 1);
+    }
     hipError_t ce = hipStreamEndCapture(c->cap_stream, &graph);
-    if (rc != SF_OK || ce != hipSuccess || !graph) {
+    if (rc != SF_OK || pe != hipSuccess || ce != hipSuccess || !graph) {
       if (graph) (void)hipGraphDestroy(graph);
       c->graphs.erase(key);
-      if (rc != SF_OK) return rc;
-      return set_err(SF_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+      if (rc != SF_OK && rc != SF_ERR_HIP) return rc;
+      return set_err(SF_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ce != hipSuccess ? ce : pe));
     }
     hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -1000,11 +1042,18 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
       c->graphs.erase(key);
       return set_err(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
     }
-    g.ws = workspace; g.pos = pos_dev; g.pooler = pooler != nullptr;
+    g.ws = workspace; g.pos = pos_dev; g.pooler = pooler != nullptr; g.pixel_kind = pk;
   }
-  // (Launching the embedding + first layers eagerly to cover the replay's host-side submit time measured no gain: 0.78 vs 0.77 ms.)
-  HIP_TRY(hipGraphLaunch(g.exec, s));
-  HIP_TRY(sf_launch_copy2(ws.lhs_stage, last_hidden, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, pooler, (size_t)F * e->D, s));
+  if (posfree) {
+    SfStreamParams v;
+    v.pixels = pixels; v.lhs = last_hidden; v.pooler = pooler; v.t_past = c->len; v.pad = 0;
+    HIP_TRY(sf_launch_stream_params(c->dparams, v, s));
+    HIP_TRY(hipGraphLaunch(g.exec, s));
+  } else {
+    // (Launching the embedding + first layers eagerly to cover the replay's host-side submit time measured no gain: 0.78 vs 0.77 ms.)
+    HIP_TRY(hipGraphLaunch(g.exec, s));
+    HIP_TRY(sf_launch_copy2(ws.lhs_stage, last_hidden, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, pooler, (size_t)F * e->D, s));
+  }
   c->len += T_new;
   return SF_OK;
 }

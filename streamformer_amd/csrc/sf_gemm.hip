@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NTHREADS) void sf_gemm_kernel(SfGemmArgs p) {
     const int m = m0 + wr * 64 + mt * 16 + l15;
     if (m >= p.M) continue;
     size_t orow = (size_t)m;
-    if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+    if (p.grp_rows > 0) orow = sf_out_row(p, m);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wc * 64 + nt * 16 + g * 4;

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
         const int m = m0 + r;
         if (m < p.M) {
           size_t orow = (size_t)m;
-          if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+          if (p.grp_rows > 0) orow = sf_out_row(p, m);
           const size_t o = orow * (size_t)p.ldc + n0 + c * 8;
           if (EPI == G256_EPI_BF16_AUX && p.aux_mode == 1) {               // training forward: the GELU of the (bf16) pre-activation
             u32x4_t a;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
             const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
             if (m < p.M && (r & 63) < (mq ? MT1 : 4) * 16) {
               size_t orow = (size_t)m;
-              if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+              if (p.grp_rows > 0) orow = sf_out_row(p, m);
               const size_t o = orow * (size_t)p.ldc + n0 + c2 * 8;
               u32x4_t h, l;
               h[0] = pack_bf2(v0[0], v0[1]); h[1] = pack_bf2(v0[2], v0[3]); h[2] = pack_bf2(v1[0], v1[1]); h[3] = pack_bf2(v1[2], v1[3]);
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
             const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
             if (m < p.M && (r & 63) < (mq ? MT1 : 4) * 16) {
               size_t orow = (size_t)m;
-              if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+              if (p.grp_rows > 0) orow = sf_out_row(p, m);
               const size_t o = orow * (size_t)p.ldc + n0 + c * 4;
               if (EPI == SF_EPI_RESID_F32) v = *reinterpret_cast<const f32x4_t*>(p.resid + o) + p.alpha * v;
               *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;

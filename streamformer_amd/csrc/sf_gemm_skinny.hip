@@ -99,11 +99,13 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       src_lo[i] = SPLIT ? p.w_lo + (size_t)gr * p.K + kc * 8 : nullptr;
     }
   }
+  const bool w_nt = p.w_nt != 0;
   auto issue = [&](int kt) {
     char* dst = smem + (kt % SK_STAGES) * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
+      if (i == 1 && w_nt) __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 2);   // W rows, nt
+      else __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
       if (SPLIT) __builtin_amdgcn_global_load_lds((gptr_t)(src_lo[i] + kt * SK_BK), (lptr_t)(dst + SK_PLANE + i * 4096), 16, 0, 0);
     }
   };
@@ -115,6 +117,16 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   const int mt = wave & 1, nt = wave >> 1;                // this wave's 16x16 output tile
 
   for (int s = 0; s < SK_STAGES - TPS && s < nkt; ++s) issue(s);
+  // epilogue operands (bias, folded-LayerNorm column sums, residual row) requested NOW, behind the first DMA stages: at one
+  // frame the launch is a chain of memory latencies, and each of these loads used to add its own at the very end
+  const int n_e = n0 + nt * 16 + g * 4, m_e = m0 + mt * 16 + l15;
+  const bool live_e = n_e < p.N && m_e < p.M;
+  f32x4_t pre_bias = {0.f, 0.f, 0.f, 0.f}, pre_lns = {0.f, 0.f, 0.f, 0.f}, pre_res = {0.f, 0.f, 0.f, 0.f};
+  if (live_e) {
+    if (p.bias) pre_bias = *reinterpret_cast<const f32x4_t*>(p.bias + n_e);
+    if (LNF) pre_lns = *reinterpret_cast<const f32x4_t*>(p.ln_s + n_e);
+    if (EPI == SF_EPI_RESID_F32 && p.grp_rows <= 0) pre_res = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m_e * p.ldc + n_e);
+  }
   for (int kt = 0; kt < nkt; kt += TPS) {
     // tiles kt .. kt+TPS-1 complete: at most the later in-flight tiles may remain outstanding
     switch (min(nkt - TPS - kt, SK_STAGES - 2 * TPS)) {
@@ -159,22 +171,21 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   const int n = n0 + nt * 16 + g * 4;
   const int m = m0 + mt * 16 + l15;
   if (n >= p.N || m >= p.M) return;
-  f32x4_t bias = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+  const f32x4_t bias = pre_bias;
   {
     size_t orow = (size_t)m;
-    if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+    if (p.grp_rows > 0) orow = sf_out_row(p, m);
     if (LNF) {
       float mean, rstd;
       sk_ln_finish(ln1, ln2, p.K, p.ln_eps, mean, rstd);
-      acc = rstd * (acc - mean * *reinterpret_cast<const f32x4_t*>(p.ln_s + n));
+      acc = rstd * (acc - mean * pre_lns);
     }
     f32x4_t v = acc + bias;
     const size_t o = orow * (size_t)p.ldc + n;
     if (EPI == SF_EPI_F32) {
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
     } else if (EPI == SF_EPI_RESID_F32) {
-      const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.resid + o);
+      const f32x4_t r = p.grp_rows <= 0 ? pre_res : *reinterpret_cast<const f32x4_t*>(p.resid + o);
       v = r + p.alpha * v;
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
       if (!SPLIT && p.out_hi)    // small-M LayerNorm fold producer: bf16 copy of the new residual rows
@@ -247,12 +258,14 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
     }
   }
   char* ring = smem + kgrp * RING;
+  const bool w_nt = p.w_nt != 0;
   auto issue = [&](int j) {                              // j = K-tile index inside the group's range
     char* dst = ring + (j % SKG_STAGES) * STAGE + w4 * 1024;
     const int kt = kt_base + j;
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
+      if (i == 1 && w_nt) __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 2);   // W rows, nt
+      else __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
       if (SPLIT) __builtin_amdgcn_global_load_lds((gptr_t)(src_lo[i] + kt * SK_BK), (lptr_t)(dst + SK_PLANE + i * 4096), 16, 0, 0);
     }
   };
@@ -260,6 +273,17 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   float ln1 = 0.f, ln2 = 0.f;
   const int mt = w4 & 1, nt = w4 >> 1;
+  // epilogue operands of group 0 (the group that finishes the tile), requested before the K loop: see sf_gemm_skinny_kernel
+  const int n_e = n0 + nt * 16 + g * 4, m_e = m0 + mt * 16 + l15;
+  const bool live_e = kgrp == 0 && n_e < p.N && m_e < p.M;
+  f32x4_t pre_bias = {0.f, 0.f, 0.f, 0.f}, pre_lns = {0.f, 0.f, 0.f, 0.f}, pre_res = {0.f, 0.f, 0.f, 0.f};
+  auto prefetch_epilogue = [&]() {
+    if (live_e) {
+      if (p.bias) pre_bias = *reinterpret_cast<const f32x4_t*>(p.bias + n_e);
+      if (LNF) pre_lns = *reinterpret_cast<const f32x4_t*>(p.ln_s + n_e);
+      if (EPI == SF_EPI_RESID_F32 && p.grp_rows <= 0) pre_res = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m_e * p.ldc + n_e);
+    }
+  };
   auto compute = [&](int j) {
     const char* img = ring + (j % SKG_STAGES) * STAGE;
 #pragma unroll
@@ -283,12 +307,14 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   // prefetch distance.)
   if (per_grp <= SKG_STAGES) {                           // the whole slice fits the ring (K = 768: 3 tiles): ONE step
     for (int j = 0; j < mine; ++j) issue(j);
+    prefetch_epilogue();
     sk_wait<0>();
     __builtin_amdgcn_s_barrier();
     for (int j = 0; j < mine; ++j) compute(j);
   } else {
     for (int j = 0; j < SKG_STAGES - 1 && j < mine; ++j) issue(j);
     for (int j = 0; j < per_grp; ++j) {
+      if (j == per_grp - 2 || per_grp == 1) prefetch_epilogue();      // late enough not to count against the vmcnt of the ring (vmcnt(0) tail)
       const int later = min(mine - 1 - j, SKG_STAGES - 2);
       if (later >= 2) sk_wait<2 * PER>(); else if (later == 1) sk_wait<PER>(); else sk_wait<0>();
       __builtin_amdgcn_s_barrier();
@@ -325,21 +351,20 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   const int n = n0 + nt * 16 + g * 4;
   const int m = m0 + mt * 16 + l15;
   if (n >= p.N || m >= p.M) return;
-  f32x4_t bias = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+  const f32x4_t bias = pre_bias;
   size_t orow = (size_t)m;
-  if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+  if (p.grp_rows > 0) orow = sf_out_row(p, m);
   if (LNF) {
     float mean, rstd;
     sk_ln_finish(ln1, ln2, p.K, p.ln_eps, mean, rstd);
-    acc = rstd * (acc - mean * *reinterpret_cast<const f32x4_t*>(p.ln_s + n));
+    acc = rstd * (acc - mean * pre_lns);
   }
   f32x4_t v = acc + bias;
   const size_t o = orow * (size_t)p.ldc + n;
   if (EPI == SF_EPI_F32) {
     *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
   } else if (EPI == SF_EPI_RESID_F32) {
-    const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p.resid + o);
+    const f32x4_t r = p.grp_rows <= 0 ? pre_res : *reinterpret_cast<const f32x4_t*>(p.resid + o);
     v = r + p.alpha * v;
     *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
     if (!SPLIT && p.out_hi)      // small-M LayerNorm fold producer: bf16 copy of the new residual rows
@@ -442,7 +467,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_mid_kernel(SfGemmArgs p) {
     const int m = m0 + wm * 32 + i * 16 + l15;
     if (m >= p.M) continue;
     size_t orow = (size_t)m;
-    if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+    if (p.grp_rows > 0) orow = sf_out_row(p, m);
     float mean = 0.f, rstd = 1.f;
     if (LNF) sk_ln_finish(ln1[i], ln2[i], p.K, p.ln_eps, mean, rstd);
 #pragma unroll
@@ -585,8 +610,13 @@ static hipError_t sk_launch_epi(const SfGemmArgs& a, dim3 grid, size_t lds, hipS
   return hipGetLastError();
 }
 
-hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s) {
-  if (!sf_gemm_skinny_supported(a, split)) return hipErrorInvalidValue;
+hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a_in, bool split, hipStream_t s) {
+  if (!sf_gemm_skinny_supported(a_in, split)) return hipErrorInvalidValue;
+  // non-temporal policy on the weight stream of a single streamed frame (each 32-row slab is read by the 7 row tiles of one
+  // XCD, once): config #5 p50 0.773 -> 0.751 ms; neutral from 8 streams on (M = 1568), where the default policy stays
+  static const int nt_env = getenv("SF_SKINNY_NT") ? atoi(getenv("SF_SKINNY_NT")) : -1;
+  SfGemmArgs a = a_in;
+  a.w_nt = nt_env >= 0 ? nt_env : (a.M <= 512 ? 1 : 0);
   if (mid_ok(a, split)) return mid_launch(a, s);
   const dim3 grid((a.N + SK_BN - 1) / SK_BN, (a.M + SK_BM - 1) / SK_BM);
   // every workgroup gets its own CU and the K loop is long: the K-parallel variant

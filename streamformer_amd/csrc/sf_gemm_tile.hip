@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
       const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + r * C::PITCH + c8 * 32);
       const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + r * C::PITCH + c8 * 32 + 16);
       size_t orow = (size_t)m;
-      if (p.grp_rows > 0) orow = (size_t)(m / p.grp_rows) * p.grp_stride + p.grp_off + (m % p.grp_rows);
+      if (p.grp_rows > 0) orow = sf_out_row(p, m);
       const size_t o = orow * (size_t)p.ldc + n;
       if (EPI == SF_EPI_RESID_F32 || EPI == SF_EPI_EMBED_F32 || EPI == SF_EPI_F32) {
         f32x4_t x0 = v0, x1 = v1;

@@ -92,7 +92,9 @@ template <int IN>
 __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict__ pixels,
                                                           bf16_t* __restrict__ out_hi,
                                                           bf16_t* __restrict__ out_lo, int F, int C, int H,
-                                                          int W, int P, int gh, int gw, SfPixelNorm norm) {
+                                                          int W, int P, int gh, int gw, SfPixelNorm norm,
+                                                          const SfStreamParams* __restrict__ sp) {
+  if (sp) pixels = sp->pixels;
   const int Kp = C * P * P;
   const int chunks_per_row = Kp >> 3;
   const size_t total = (size_t)F * gh * gw * chunks_per_row;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict
 }
 
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
-                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* pnorm) {
+                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* pnorm, const SfStreamParams* sp) {
   if (P % 8 || (pixel_kind == 2 && (W % 8 || C > 4))) return hipErrorInvalidValue;
   SfPixelNorm norm;
   for (int i = 0; i < 4; ++i) { norm.scale[i] = 1.0f / 127.5f; norm.shift[i] = -1.0f; }    // mean = std = 0.5, rescale 1/255
@@ -144,11 +146,11 @@ hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi
   if (!total) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (pixel_kind == 2)
-    hipLaunchKernelGGL(sf_patchify_kernel<2>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm);
+    hipLaunchKernelGGL(sf_patchify_kernel<2>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp);
   else if (pixel_kind == 1)
-    hipLaunchKernelGGL(sf_patchify_kernel<1>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm);
+    hipLaunchKernelGGL(sf_patchify_kernel<1>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp);
   else
-    hipLaunchKernelGGL(sf_patchify_kernel<0>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm);
+    hipLaunchKernelGGL(sf_patchify_kernel<0>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp);
   return hipGetLastError();
 }
 
@@ -203,15 +205,16 @@ hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sf_gather_rows_kernel(const float* __restrict__ table,
-                                                             float* __restrict__ out, SfRowIndex idx, int D) {
+                                                             float* __restrict__ out, SfRowIndex idx, int D,
+                                                             const int* __restrict__ base_dev) {
   const int t = blockIdx.x;
-  const float* src = table + (size_t)idx.idx[t] * D;
+  const float* src = table + (size_t)(idx.idx[t] + (base_dev ? *base_dev : 0)) * D;
   for (int i = threadIdx.x; i < D; i += blockDim.x) out[(size_t)t * D + i] = src[i];
 }
 
-hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s) {
+hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowIndex& idx, int D, hipStream_t s, const int* base_dev) {
   if (idx.n <= 0 || idx.n > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_gather_rows_kernel, dim3(idx.n), dim3(256), 0, s, table, out, idx, D);
+  hipLaunchKernelGGL(sf_gather_rows_kernel, dim3(idx.n), dim3(256), 0, s, table, out, idx, D, base_dev);
   return hipGetLastError();
 }
 
@@ -238,16 +241,27 @@ hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, fl
 }
 
 __global__ __launch_bounds__(256) void sf_copy2_kernel(const float* __restrict__ a_src, float* __restrict__ a_dst, size_t na4,
-                                                       const float* __restrict__ b_src, float* __restrict__ b_dst, size_t nb4) {
+                                                       const float* __restrict__ b_src, float* __restrict__ b_dst, size_t nb4,
+                                                       const SfStreamParams* __restrict__ sp) {
+  if (sp) { a_dst = sp->lhs; b_dst = sp->pooler; }
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < na4) reinterpret_cast<f32x4_t*>(a_dst)[i] = reinterpret_cast<const f32x4_t*>(a_src)[i];
   else if (i - na4 < nb4) reinterpret_cast<f32x4_t*>(b_dst)[i - na4] = reinterpret_cast<const f32x4_t*>(b_src)[i - na4];
 }
-hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s) {
+__global__ void sf_stream_params_kernel(SfStreamParams* dst, SfStreamParams v) {
+  if (threadIdx.x == 0) *dst = v;
+}
+hipError_t sf_launch_stream_params(SfStreamParams* dst, const SfStreamParams& v, hipStream_t s) {
+  hipLaunchKernelGGL(sf_stream_params_kernel, dim3(1), dim3(64), 0, s, dst, v);
+  return hipGetLastError();
+}
+
+hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s,
+                           const SfStreamParams* sp) {
   if ((na % 4) || (nb % 4)) return hipErrorInvalidValue;
-  if (!b_src || !b_dst) nb = 0;
+  if (!b_src || (!b_dst && !sp)) nb = 0;
   const size_t n4 = (na + nb) / 4;
   if (!n4) return hipSuccess;
-  hipLaunchKernelGGL(sf_copy2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a_src, a_dst, na / 4, b_src, b_dst, nb / 4);
+  hipLaunchKernelGGL(sf_copy2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a_src, a_dst, na / 4, b_src, b_dst, nb / 4, sp);
   return hipGetLastError();
 }

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 ACC_TOL = 1e-3
 ACC_CEIL = 5e-4
-BF16_LHS, BF16_POOL = 5e-2, 3e-2
+BF16_LHS, BF16_POOL = 4e-2, 3e-2          # measured 3.1e-2 / 2.7e-2 on the SigLIP-base clip of bench.py (the bf16 operand floor)
 
 
 @pytest.fixture(scope="module")

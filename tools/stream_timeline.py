@@ -4,8 +4,9 @@ import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 frames, cur = [], []
+first = "sf_stream_params_kernel" if any("sf_stream_params_kernel" in r[0] for r in rows) else "sf_patchify"   # first kernel of a frame
 for name, s, e in rows:
-    if "sf_gather_rows" in name and cur:
+    if first in name and cur:
         frames.append(cur); cur = []
     cur.append((name, s, e))
 frames.append(cur)
