@@ -21,7 +21,9 @@ Extra objects on that line:
   h2d_inclusive frames/s with the host -> device copy of the batch inside every step (pinned memory), for fp32 frames
                 and for raw uint8 frames (normalisation fused into the patch kernel); never the headline `value`
   streaming     BASELINE configs[4]: per-frame latency (p50 / p99) of the KV-cached streaming path, 64-frame online
-                clip at B = 1, and the achieved HBM rate against the algorithmic bytes of a frame
+                clip at B = 1, the achieved HBM rate against the algorithmic bytes of a frame, `first_pass` (a fresh cache)
+                and `roofline_streaming` (its dominant kernel, HIP-event timed)
+  latency_b1    README.md:55-71 is one clip per call: ms per call at 1 / 2 / 4 clips (bf16) and 1 clip (fp32-accurate)
   train_step    BASELINE configs[2]: frames/s of one multitask pre-training step (forward + loss + backward +
                 AdamW) on the same clip shape, with its own CPU baseline; `--mode train` makes that step THE
                 timed step (configs[2] at N=1, configs[3] with the gradient all-reduce at N>1)
@@ -240,15 +242,18 @@ def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
 def streaming_bench(dev):
     """Per-frame latency of the streaming path: num_frames = 64, B = 1, one frame per
     call, cache reset between repeats; p50 / p99 over the frames of 3 timed repeats, and the achieved HBM rate
-    against the algorithmic bytes of a frame (weights 255 MB + KV read 7.225 MB x (t+1) + KV write + activations)."""
+    against the algorithmic bytes of a frame (weights 255 MB + KV read 7.225 MB x (t+1) + KV write + activations).
+    `first_pass`: the same 64 calls on a FRESH cache (lazy kernel set-up on frame 0, the one graph capture on frame 1)."""
     import streamformer_amd as sa
+    from streamformer_amd import _native as nat
     cfg = sa.siglip_base(num_frames=64)
     m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
     m.load_state_dict(sa.make_state_dict(cfg, seed=0))
     m.to(dev)
     x = torch.randn(1, 64, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(64)).to(dev)
+    m(x[:, :2])                              # library warm-up outside the stream under test
     cache = m.new_cache(1, 64)
-    lat = []
+    lat, first = [], []
     for rep in range(4):
         cache.reset()
         for t in range(64):
@@ -256,11 +261,25 @@ def streaming_bench(dev):
             t0 = time.perf_counter()
             m(x[:, t:t + 1], use_cache=True, past_key_values=cache)
             torch.cuda.synchronize()
-            if rep:
-                lat.append(time.perf_counter() - t0)
+            (lat if rep else first).append(time.perf_counter() - t0)
     lat.sort()
     mean = sum(lat) / len(lat)
+    fs = sorted(first)
     gb = (255.0 + 7.225 * (64 + 1) / 2 + 7.225 + 12.0) / 1e3          # mean algorithmic GB per frame over t = 0..63
+    # the dominant kernel of a streamed frame (rocprof: profiles/r03_streaming_kernel_stats.txt): the K-parallel skinny GEMM of
+    # the N = 768 residual projections, 37 launches per frame; HIP-event timed here at M = 196 back to back (weights L2-warm:
+    # inside the stream each launch starts on cold weights and measures ~6.4 us)
+    ws = torch.randn(1 << 25, dtype=torch.bfloat16, device=dev).view(torch.uint8)
+    ms, fl = nat.C.c_float(), nat.C.c_double()
+    N1 = cfg.num_patches
+    dom = {}
+    for which, name, K in ((3, "out_proj_K768", 768), (1, "mlp_down_K3072", 3072)):
+        nat.check(nat.lib.sf_bench_gemm(m._handle, N1, which, 50, ws.data_ptr(), ws.numel(), nat.current_stream_handle(dev),
+                                        nat.C.byref(ms), nat.C.byref(fl)))
+        by = 768 * K * 2 + N1 * K * 2 + N1 * 768 * (4 + 4 + 2)          # W + A + fp32 residual in / out + bf16 copy
+        dom[name] = {"us": round(1e3 * ms.value, 2), "algorithmic_MB": round(by / 1e6, 2), "GBps": round(by / ms.value / 1e6, 1),
+                     "frac_of_hbm_peak": round(by / ms.value / 1e6 / PEAK_HBM_GBS, 4)}
+    del ws
     del cache
     # the serving shape of the vision tower (vqa_enc:1494-1500: one cache per stream): 8 streams advance one frame per call
     S = 8
@@ -282,10 +301,47 @@ def streaming_bench(dev):
     return {"p50_ms": round(1e3 * lat[len(lat) // 2], 3), "p99_ms": round(1e3 * lat[int(len(lat) * 0.99)], 3),
             "mean_ms": round(1e3 * mean, 3), "frames_per_s": round(1.0 / mean, 1), "algorithmic_GB_per_frame": round(gb, 3),
             "GBps": round(gb / mean, 1), "frac_of_hbm_peak": round(gb / mean / PEAK_HBM_GBS, 4),
+            "first_pass": {"p50_ms": round(1e3 * fs[len(fs) // 2], 3), "mean_ms": round(1e3 * sum(first) / len(first), 3),
+                           "frame0_ms": round(1e3 * first[0], 3), "frame1_ms": round(1e3 * first[1], 3), "max_ms": round(1e3 * fs[-1], 3),
+                           "note": "fresh cache: frame 0 runs eagerly (lazy per-kernel set-up), frame 1 captures the one "
+                                   "position-free hipGraph of the cache, every later frame replays it"},
             "config": "SigLIP-base, num_frames=64, B=1, one 224^2 frame per call, bf16 mode, KV-cache of 64 frames",
+            "roofline_streaming": {"bound": "hbm", "kernel": "sf_gemm_skinny_kg_kernel (N = 768 residual projections, 37 of 108 launches "
+                                   "per frame, ~32 % of its kernel time)", "launches": dom, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "whole_frame": {"achieved": round(gb / mean, 1), "frac": round(gb / mean / PEAK_HBM_GBS, 4)},
+                                   "note": "a streamed frame is ~100 dependent launches of 4-10 us: latency-bound, not bandwidth-bound "
+                                           "(DESIGN.md 4.1)"},
             "eight_streams": {"p50_ms_per_call": round(1e3 * lat8[len(lat8) // 2], 3),
                               "frames_per_s": round(S / (sum(lat8) / len(lat8)), 1),
                               "config": "same model, 8 independent streams advance one frame per call (one cache, B = 8)"}}
+
+
+def small_batch_latency(dev):
+    """README.md:55-71 is ONE clip per call: latency of 1 and 2 clips of 16 x 224^2 (bf16 mode), and of one clip in the
+    fp32-accurate mode."""
+    import streamformer_amd as sa
+    cfg = sa.siglip_base()
+    sd = sa.make_state_dict(cfg, seed=0)
+    out = {}
+    for mode, batches in (("bf16", (1, 2, 4)), ("fp32", (1,))):
+        m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+        m.load_state_dict(sd)
+        m.to(dev).eval()
+        for B in batches:
+            x = torch.randn(B, cfg.num_frames, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(B)).to(dev)
+            for _ in range(3):
+                m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                m(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            out[f"{'bf16' if mode == 'bf16' else 'bf16x3'}_B{B}"] = {"ms": round(1e3 * dt, 3), "frames_per_s": round(B * cfg.num_frames / dt, 1)}
+        del m
+    torch.cuda.empty_cache()
+    out["config"] = "SigLIP-base, B clips x 16 x 224^2 per call, 20 back-to-back calls after 3 warm-ups"
+    return out
 
 
 def self_launch(args):
@@ -420,27 +476,33 @@ def main():
         panel_flop = (2 * 2.0 * M * 768 * 768 + 2.0 * M * 768 * 3072)               # per layer
         panel_ms = 2 * gemms["out_proj"]["ms"] + gemms["mlp_down"]["ms"]
         panel_tflops = panel_flop / panel_ms / 1e9
-        traffic, traffic_note = None, "no PMC file"
-        try:   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        traffic, traffic_note, traffic_from = None, "no PMC file", None
+        try:   # HBM-side bytes per launch IMPORTED from the committed PMC passes (rocprofv3 cannot run inside the bench)
+            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            traffic_from = "profiles/" + pmc_file
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
             tr = next(v["traffic_bytes_corrected"] for k, v in pmc["kernels"].items() if k.startswith("void sf_gemm_panel_kernel<13>"))
             import hashlib
             hsrc = hashlib.sha256(open(os.path.join(ROOT, "streamformer_amd", "csrc", "sf_gemm_panel.hip"), "rb").read()).hexdigest()[:16]
             if pmc.get("panel_source_sha16") == hsrc:
                 traffic = tr
-                traffic_note = ("bytes/launch, mean over the panel launches of a forward = 2*FETCH_SIZE + WRITE_SIZE (profiles/r02_pmc_traffic.json, "
-                                "separate --pmc passes; FETCH includes Infinity-Cache hits); algorithmic bytes/launch: 231e6 at K = 768 "
+                traffic_note = ("IMPORTED, not measured by this run: bytes/launch, mean over the panel launches of a forward = 2*FETCH_SIZE + WRITE_SIZE "
+                                f"({traffic_from}, separate --pmc passes; FETCH includes Infinity-Cache hits); algorithmic bytes/launch: 231e6 at K = 768 "
                                 "(A 38.5 + W 1.2 + fp32 residual in/out 154 + bf16 copy 38.5 MB), 346e6 at K = 3072")
             else:
-                traffic_note = "profiles/r02_pmc_traffic.json was taken on an older sf_gemm_panel.hip: traffic withheld until the PMC passes are re-run"
+                traffic_note = f"{traffic_from} was taken on an older sf_gemm_panel.hip: traffic withheld until the PMC passes are re-run"
         except Exception as e:
             traffic_note = f"PMC file unreadable: {e!r}"
         out["roofline"] = {"kernel": "sf_gemm_panel_kernel<13> (N = 768 residual projections: 2 x attention out-proj K=768 + MLP down-proj K=3072 per layer, "
                                      "epilogue = fp32 residual RMW + bf16 copy + LayerNorm row sums; M=%d)" % M,
                            "bound": "mfma", "achieved": round(panel_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(panel_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                           "avg_launch_ms": round(panel_ms / 3, 4), "share_of_forward_kernel_time": "~38 % (rocprof)",
+                           "frac": round(panel_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_imported_from": traffic_from,
+                           "traffic_note": traffic_note, "avg_launch_ms": round(panel_ms / 3, 4),
+                           # live: the kernel's launches of one forward (per layer 2 x K=768 + 1 x K=3072, + the embedding GEMM, also
+                           # K = 768) at their HIP-event times of this run, over this run's ms_per_step
+                           "share_of_step_time_live": round((L * panel_ms + gemms["out_proj"]["ms"]) / (1e3 * dt / args.steps), 4),
+                           "share_from_profile": "39 % of kernel time (profiles/r02_forward_kernel_stats.txt; r03 re-profile in profiles/)",
                            "launches": {"out_proj_K768": gemms["out_proj"], "mlp_down_K3072": gemms["mlp_down"]},
                            "hbm_view_K768": {"algorithmic_GB": 0.2312, "GBps": round(0.2312 / gemms["out_proj"]["ms"] * 1e3, 1),
                                              "frac_of_hbm_peak": round(0.2312 / gemms["out_proj"]["ms"] * 1e3 / PEAK_HBM_GBS, 4)},
@@ -553,6 +615,10 @@ def main():
                 del mh
             except Exception as e:
                 out["h2d_inclusive"] = {"error": repr(e)}
+            try:
+                out["latency_b1"] = small_batch_latency(dev)
+            except Exception as e:
+                out["latency_b1"] = {"error": repr(e)}
             # BASELINE configs[4]: 64-frame online clip, one frame per call through the KV-cache (B = 1)
             try:
                 out["streaming"] = streaming_bench(dev)
