@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#define SF_ABI_VERSION 2
+#define SF_ABI_VERSION 3
 static const int kLoraRank = 32;  // modeling:1280-1281
 
 // ------------------------------------------------------------------------------------------------
