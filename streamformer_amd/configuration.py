@@ -121,14 +121,3 @@ def siglip_base(**overrides: Any) -> StreamformerConfig:
     kw = dict(enable_causal_temporal=True)
     kw.update(overrides)
     return StreamformerConfig(**kw)
-
-
-def tiny(**overrides: Any) -> StreamformerConfig:
-    """The smallest configuration the HIP library accepts (head_dim is fixed at 64): D=128, h=2, L=2, I=256,
-    32 px frames => N=4 patches.  Fixture F1 uses 48 px frames of the same width (tests/helpers.small_cfg)."""
-    kw = dict(
-        image_size=32, patch_size=16, num_frames=16, hidden_size=128, num_hidden_layers=2,
-        num_attention_heads=2, intermediate_size=256, enable_causal_temporal=True,
-    )
-    kw.update(overrides)
-    return StreamformerConfig(**kw)

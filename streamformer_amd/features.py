@@ -73,23 +73,32 @@ def resample_indices(num_frames: int, original_fps: float, target_fps: float = 2
     return np.linspace(0, num_frames - 1, int(num_frames / original_fps * target_fps)).astype(int)
 
 
+def resize_sizes(H: int, W: int, size: int) -> Tuple[int, int]:
+    """(new_h, new_w) of the reference's ``Resize(size)`` on numpy frames: short side to ``size``, long side truncated with
+    ``int()`` (functional.py:67-75; 854 x 480 -> 398 x 224, not 399)."""
+    if W < H:
+        return int(size * H / W), size
+    return size, int(size * W / H)
+
+
 def resize_center_crop(frames_u8: np.ndarray, size: int = 224) -> torch.Tensor:
-    """uint8 [n, H, W, 3] -> uint8 [n, 3, size, size]: short side to `size` (bilinear), centre crop
-    (Resize(224, 'bilinear') + CenterCrop(224), extract_oad_feature.py:42-46)."""
-    from PIL import Image
+    """uint8 [n, H, W, 3] -> uint8 [n, 3, size, size]: the reference's ``Resize(224, 'bilinear') + CenterCrop(224)``
+    (extract_oad_feature.py:42-46) on numpy frames, i.e. ``cv2.resize(..., INTER_LINEAR)`` — plain bilinear sampling at
+    half-pixel centres, NO antialiasing on downscale (PIL's BILINEAR low-pass filters there) — and the crop offset
+    ``int(round((dim - size) / 2.0))`` (video_transforms.py:1158-1159).  Computed in float32 and rounded: cv2's 8-bit path uses
+    11-bit fixed-point weights, so single pixels can differ by one grey level."""
     n, H, W, _ = frames_u8.shape
-    if H <= W:
-        nh, nw = size, max(size, int(round(W * size / H)))
-    else:
-        nh, nw = max(size, int(round(H * size / W))), size
-    top, left = (nh - size) // 2, (nw - size) // 2
-    out = np.empty((n, size, size, 3), np.uint8)
-    for i in range(n):
-        im = Image.fromarray(frames_u8[i])
-        if (H, W) != (nh, nw):
-            im = im.resize((nw, nh), resample=Image.BILINEAR)
-        out[i] = np.asarray(im)[top:top + size, left:left + size]
-    return torch.from_numpy(out).permute(0, 3, 1, 2).contiguous()
+    x = torch.from_numpy(np.ascontiguousarray(frames_u8)).permute(0, 3, 1, 2)
+    if not ((W <= H and W == size) or (H <= W and H == size)):          # functional.py:31-33: already at the minimal size
+        nh, nw = resize_sizes(H, W, size)
+        out = torch.empty(n, 3, nh, nw, dtype=torch.uint8)
+        for i in range(0, n, 64):                                         # chunks: a long video as fp32 is GBs
+            y = torch.nn.functional.interpolate(x[i:i + 64].float(), size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
+            out[i:i + 64] = y.round_().clamp_(0, 255).to(torch.uint8)
+        x = out
+    nh, nw = x.shape[-2:]
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    return x[:, :, top:top + size, left:left + size].contiguous()
 
 
 def shard_of_list(items: List[str], start_idx: Optional[float], end_idx: Optional[float]) -> List[str]:
@@ -150,7 +159,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     if args.enable_lora_spatial:
         model.add_lora_spatial()
     if args.ckpt_path:
-        ckpt = torch.load(args.ckpt_path, map_location="cpu", weights_only=True)
+        # the reference's save_model stores its argparse.Namespace under "args" (utils.py:608-636): allow exactly that class
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(args.ckpt_path, map_location="cpu", weights_only=True)
         ckpt = ckpt.get("model", ckpt)
         print("Loading checkpoint:", model.load_state_dict({k: v for k, v in ckpt.items() if "task_heads" not in k}, strict=False))
     model.eval()

@@ -215,6 +215,59 @@ def test_window_starts_match_reference_formula():
         assert (w[-1] == n) == (n // 6 > 1)        # with >1 windows the last start is n itself -> clamped to the final 6 frames
 
 
+def test_resize_center_crop_follows_the_reference_transform():
+    """Resize(224, 'bilinear') on numpy frames is cv2.INTER_LINEAR — no antialiasing on downscale, long side
+    int(size * W / H) (functional.py:26-75) — and CenterCrop offsets are int(round(./2)) (video_transforms.py:1158-1159)."""
+    import numpy as np
+    from streamformer_amd.features import resize_center_crop, resize_sizes
+    assert resize_sizes(480, 854, 224) == (224, 398)               # int(), not round(): 398.53 -> 398
+    assert resize_sizes(854, 480, 224) == (398, 224)
+    assert resize_sizes(224, 224, 224) == (224, 224)
+    rng = np.random.default_rng(3)
+    # downscale of a 2-pixel checkerboard: plain bilinear sampling keeps contrast, an antialiasing filter would flatten it
+    H, W = 96, 160
+    yy, xx = np.mgrid[0:H, 0:W]
+    board = (((yy // 2 + xx // 2) % 2) * 255).astype(np.uint8)
+    f = np.repeat(board[None, :, :, None], 3, axis=3)
+    out = resize_center_crop(f, 48)
+    assert out.shape == (1, 3, 48, 48) and out.dtype == torch.uint8
+    assert float(out.float().std()) > 60.0
+    # the same numbers as a direct evaluation of the bilinear formula at half-pixel centres
+    g = rng.integers(0, 256, (2, 60, 90, 3), dtype=np.uint8)
+    nh, nw = resize_sizes(60, 90, 48)
+    got = resize_center_crop(g, 48)
+    sy = (np.arange(nh) + 0.5) * (60 / nh) - 0.5
+    sx = (np.arange(nw) + 0.5) * (90 / nw) - 0.5
+    y0 = np.clip(np.floor(sy), 0, 59).astype(int); x0 = np.clip(np.floor(sx), 0, 89).astype(int)
+    y1 = np.minimum(y0 + 1, 59); x1 = np.minimum(x0 + 1, 89)
+    fy = np.clip(sy - np.floor(sy), 0, 1) * (sy >= 0); fx = np.clip(sx - np.floor(sx), 0, 1) * (sx >= 0)
+    a = g.astype(np.float64)
+    ref = ((a[:, y0][:, :, x0] * (1 - fx)[None, None, :, None] + a[:, y0][:, :, x1] * fx[None, None, :, None]) * (1 - fy)[None, :, None, None]
+           + (a[:, y1][:, :, x0] * (1 - fx)[None, None, :, None] + a[:, y1][:, :, x1] * fx[None, None, :, None]) * fy[None, :, None, None])
+    top, left = int(round((nh - 48) / 2.0)), int(round((nw - 48) / 2.0))
+    ref = np.clip(np.rint(ref), 0, 255)[:, top:top + 48, left:left + 48]
+    assert np.abs(got.permute(0, 2, 3, 1).numpy().astype(np.int32) - ref.astype(np.int32)).max() <= 1
+    # already at the minimal size: untouched apart from the crop (functional.py:31-33)
+    h = rng.integers(0, 256, (1, 48, 70, 3), dtype=np.uint8)
+    assert np.array_equal(resize_center_crop(h, 48)[0].permute(1, 2, 0).numpy(), h[0][:, 11:59])
+
+
+def test_feature_cli_reads_reference_style_checkpoints(tmp_path):
+    """the reference's save_model pickles its argparse.Namespace under "args" (utils.py:608-636); the
+    weights-only load of --ckpt_path must accept exactly that."""
+    import argparse
+    path = str(tmp_path / "checkpoint-3.pth")
+    torch.save({"model": {"timesformer.x": torch.ones(2)}, "epoch": 3, "args": argparse.Namespace(lr=1e-4, tasks=["a"])}, path)
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert ck["args"].lr == 1e-4 and "timesformer.x" in ck["model"]
+    import inspect
+    from streamformer_amd import features
+    assert "safe_globals([argparse.Namespace])" in inspect.getsource(features.main)
+
+
 # ---- training host logic (streamformer_amd/training.py; reference utils.py:574-605, run_finetuning_multi_task.py:386) ----
 def test_cosine_scheduler_table():
     import math
