@@ -33,6 +33,10 @@ SF_DEVICE f32x4_t tl_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
   typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
 }
+// Barrier between the staging passes of the epilogue: orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding GLOBAL store of the wave (vmcnt(0)): with one pass per 16 WM rows that put a store round trip into each pass
+// (MLP-up at M = 3136: 14 of 34 us were epilogue).
+SF_DEVICE void tl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N>
 SF_DEVICE void tl_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -68,9 +72,7 @@ struct TlCfg {
   static constexpr int NI_A = BM / ROWS_PER_INST, NI_W = (BN + ROWS_PER_INST - 1) / ROWS_PER_INST;
   static constexpr int NI = NI_A + NI_W;
   static constexpr int STAGE_BYTES = NI * TL_LOADERS * 16;
-  static constexpr int PITCH = BN * 4 + 16;                                   // staging row pitch (bytes)
-  static constexpr int STAGING_BYTES = 16 * WM * PITCH;
-  static constexpr int STATS_OFF = STAGING_BYTES > STAGES * STAGE_BYTES ? STAGING_BYTES : STAGES * STAGE_BYTES;
+  static constexpr int STATS_OFF = STAGES * STAGE_BYTES;                      // the epilogue stages the C tile inside the idle ring
   static constexpr int LDS_BYTES = STATS_OFF + BM * 8;
   static_assert(BM % ROWS_PER_INST == 0, "A rows must fill whole DMA instructions");
   static_assert(WM * WN * 64 == TL_CONSUMERS, "8 consumer waves");
@@ -80,7 +82,9 @@ struct TlCfg {
 };
 
 template <int MT, int NT, int WM, int WN, int BK, int STAGES, int EPI, bool LNF>
-__global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, int tiles_n, int ntiles, int per_xcd) {
+__global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, int tiles_n, int ntiles, int per_xcd, int lab) {
+  // lab (SF_TILE_LAB, measurements only; 0 in the product): 1 loader waves at raised priority, 2 consumers read their fragments but issue
+  // no MFMA, 4 consumers only take the barriers (pure ingest), 8 no epilogue
   using C = TlCfg<MT, NT, WM, WN, BK, STAGES>;
   constexpr int BM = C::BM, BN = C::BN, NI = C::NI, NI_A = C::NI_A;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (tl_lptr_t)(dst + i * (TL_LOADERS * 16)), 16, (int)off[i], kof, 0, 0);
       }
     };
+    if (lab & 1) __builtin_amdgcn_s_setprio(3);
     for (int s = 0; s < STAGES - 1 && s < nkt; ++s) issue(s);
     for (int kt = 0; kt < nkt; ++kt) {
       const int later = min(nkt - 1 - kt, STAGES - 2);            // stages that may stay in flight behind stage kt
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
   } else {
     for (int kt = 0; kt < nkt; ++kt) {
       __builtin_amdgcn_s_barrier();
+      if (lab & 4) continue;
       const char* img = smem + (kt % STAGES) * C::STAGE_BYTES;
 #pragma unroll
       for (int ks = 0; ks < BK / 32; ++ks) {
@@ -164,12 +170,21 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
           af[i] = tl_frag<BK>(img, (wm * MT + i) * 16 + l15, kc);
           if (LNF && (i % WN) == wn) tl_stats(af[i], ln1[i / WN], ln2[i / WN]);   // wave wn of a row block owns m-tiles i = wn (mod WN)
         }
+        if (lab & 2) {                                           // keep the reads alive without the matrix pipe
+#pragma unroll
+          for (int i = 0; i < MT; ++i) acc[i][0][0] += __builtin_bit_cast(float, (int)af[i][0] ^ (int)wf[i % NT][1]);
+          continue;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = tl_mfma(wf[j], af[i], acc[i][j]);
       }
     }
+  }
+  if (lab & 8) {
+    if (!loader && acc[0][0][0] == 123.456f) p.out_hi[tid] = 1;   // keeps the accumulators live
+    return;
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
@@ -194,41 +209,64 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
     bias4[j] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     lns4[j] = LNF ? *reinterpret_cast<const f32x4_t*>(p.ln_s + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
+  // Staging: as many m-tiles of every wave per pass as the (idle) ring holds — the whole tile for every shipped shape but
+  // 256 x 192 fp32 — as fp32 for the residual / embedding epilogues and as bf16 (half the LDS bytes) for the bf16 outputs.
+  // One pass = staging writes, ONE barrier, whole-row copy-out; with one 16-row m-tile per pass (first version) the MLP-up
+  // epilogue cost 14 of 34 us at M = 3136 (SF_TILE_LAB=8).
+  constexpr bool F32OUT = (EPI == SF_EPI_RESID_F32 || EPI == SF_EPI_EMBED_F32 || EPI == SF_EPI_F32);
+  constexpr int ES = F32OUT ? 4 : 2;
+  constexpr int PITCH = BN * ES + 16;
+  constexpr int RING = STAGES * C::STAGE_BYTES;
+  constexpr int MTP_FIT = RING / (16 * WM * PITCH);
+  constexpr int MTP = MTP_FIT >= MT ? MT : (MTP_FIT >= 1 ? MTP_FIT : 1);      // m-tiles per pass
+  static_assert(16 * WM * PITCH * MTP <= C::STATS_OFF, "staging must stay below the statistics block");
   constexpr int CH = BN / 8;                                     // 8-column chunks per row
-  constexpr int ITEMS = 16 * WM * CH;
   const float inv_k = 1.0f / (float)K;
 #pragma unroll
-  for (int q = 0; q < MT; ++q) {
-    // pass q: m-tile q of every wave -> staging image [16 WM rows][BN] fp32
-    float mean = 0.f, rstd = 1.f;
-    if (LNF) {
-      const float2 s = st[(wm * MT + q) * 16 + l15];
-      mean = s.x * inv_k;
-      rstd = __builtin_amdgcn_rsqf(fmaxf(s.y * inv_k - mean * mean, 0.f) + p.ln_eps);
-    }
+  for (int q0 = 0; q0 < MT; q0 += MTP) {
+    if (!loader) {
 #pragma unroll
-    for (int j = 0; j < NT && !loader; ++j) {
-      f32x4_t v = acc[q][j];
-      if (LNF) v = rstd * (v - mean * lns4[j]);
-      v += bias4[j];
-      if (EPI == SF_EPI_ACT_BF16) {
+      for (int qq = 0; qq < MTP; ++qq) {
+        const int q = q0 + qq;
+        if (q >= MT) break;
+        float mean = 0.f, rstd = 1.f;
+        if (LNF) {
+          const float2 sv = st[(wm * MT + q) * 16 + l15];
+          mean = sv.x * inv_k;
+          rstd = __builtin_amdgcn_rsqf(fmaxf(sv.y * inv_k - mean * mean, 0.f) + p.ln_eps);
+        }
+        char* srow = smem + ((wm * MTP + qq) * 16 + l15) * PITCH;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act_fast(v[e], p.act);
+        for (int j = 0; j < NT; ++j) {
+          f32x4_t v = acc[q][j];
+          if (LNF) v = rstd * (v - mean * lns4[j]);
+          v += bias4[j];
+          if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_fast(v[e], p.act);
+          }
+          const int col = (wn * NT + j) * 16 + g * 4;
+          if (F32OUT) *reinterpret_cast<f32x4_t*>(srow + col * 4) = v;
+          else *reinterpret_cast<u32x2_t*>(srow + col * 2) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        }
       }
-      *reinterpret_cast<f32x4_t*>(smem + (wm * 16 + l15) * C::PITCH + ((wn * NT + j) * 16 + g * 4) * 4) = v;
     }
-    __syncthreads();
-    for (int it = tid; it < ITEMS; it += TL_THREADS) {
-      const int r = it / CH, c8 = it % CH;
-      const int m = m0 + ((r >> 4) * MT + q) * 16 + (r & 15);
+    tl_lds_barrier();
+    const int mtp = (MT - q0) < MTP ? (MT - q0) : MTP;            // m-tiles staged in this pass
+    const int items = 16 * WM * mtp * CH;
+    for (int it = tid; it < items; it += TL_THREADS) {
+      const int rr = it / CH, c8 = it % CH;                      // rr = (wm, qq, l) packed as ((wm * mtp + qq) * 16 + l) over the staged rows
+      const int w_ = rr / (16 * mtp), qq = (rr >> 4) % mtp, l = rr & 15;
+      const int m = m0 + (w_ * MT + q0 + qq) * 16 + l;
       if (m >= p.M) continue;
       const int n = n0 + c8 * 8;
-      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + r * C::PITCH + c8 * 32);
-      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + r * C::PITCH + c8 * 32 + 16);
+      const char* srow = smem + ((w_ * MTP + qq) * 16 + l) * PITCH;
       size_t orow = (size_t)m;
       if (p.grp_rows > 0) orow = sf_out_row(p, m);
       const size_t o = orow * (size_t)p.ldc + n;
-      if (EPI == SF_EPI_RESID_F32 || EPI == SF_EPI_EMBED_F32 || EPI == SF_EPI_F32) {
+      if (F32OUT) {
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(srow + c8 * 32);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(srow + c8 * 32 + 16);
         f32x4_t x0 = v0, x1 = v1;
         if (EPI == SF_EPI_RESID_F32) {
           const float* rp = p.resid + o;
@@ -246,11 +284,10 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
           *reinterpret_cast<u32x4_t*>(p.out_hi + o) =
               (u32x4_t){pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
       } else {
-        *reinterpret_cast<u32x4_t*>(p.out_hi + o) =
-            (u32x4_t){pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4_t*>(p.out_hi + o) = *reinterpret_cast<const u32x4_t*>(srow + c8 * 16);
       }
     }
-    __syncthreads();
+    if (q0 + MTP < MT) tl_lds_barrier();
   }
 }
 
@@ -273,10 +310,11 @@ int sf_tile_min_rows() {
 }
 int sf_tile_max_rows() {
   // above: panel / 256^2 kernels.  Measured (us per launch, tile vs panel / 256^2; tools/tile_lab.py): M = 3136 qkv 17 / 24,
-  // MLP-up 34 / 29, out-proj 12 / 18, MLP-down 25 / 57 -> 1.89 against 2.64 ms per clip; M = 6272: 31 / 24, 64 / 55, 19 / 23,
-  // 39 / 64: the narrow producers still win but the LayerNorm-folded consumers lose to the 256^2 kernel, and the two folds
-  // (in-kernel statistics vs statistics buffer) do not mix -> 5 % slower end to end; M = 12544: level or slower everywhere.
-  static const int m = getenv("SF_TILE_MAX_M") ? atoi(getenv("SF_TILE_MAX_M")) : 4704;
+  // MLP-up 34 / 29, out-proj 12 / 18, MLP-down 26 / 57 -> 1.83 against 2.64 ms per clip; M = 6272: 31 / 24, 63 / 55, 19 / 23,
+  // 39 / 64 -> 3.02 against 3.36 ms for two clips (the narrow producers carry it; the two LayerNorm folds — in-kernel
+  // statistics here, statistics buffer on the 256^2 kernel — do not mix, so the consumers come along); M = 12544: level or
+  // slower everywhere.
+  static const int m = getenv("SF_TILE_MAX_M") ? atoi(getenv("SF_TILE_MAX_M")) : 6272;
   return m;
 }
 
@@ -340,8 +378,9 @@ static hipError_t tl_go(const SfGemmArgs& a, hipStream_t s) {
   const int tiles_n = a.N / C::BN, tiles_m = (a.M + C::BM - 1) / C::BM;
   const int ntiles = tiles_n * tiles_m;
   const int per_xcd = (ntiles + 7) / 8;
+  static const int lab_env = getenv("SF_TILE_LAB") ? atoi(getenv("SF_TILE_LAB")) : 0;
   hipLaunchKernelGGL((sf_gemm_tile_kernel<MT, NT, WM, WN, BK, STAGES, EPI, LNF>), dim3(per_xcd * 8), dim3(TL_THREADS), C::LDS_BYTES, s,
-                     a, tiles_n, ntiles, per_xcd);
+                     a, tiles_n, ntiles, per_xcd, lab_env);
   return hipGetLastError();
 }
 
