@@ -9,7 +9,7 @@ cfg = sa.siglip_base()
 m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
 m.load_state_dict(sa.make_state_dict(cfg, 0)); m.to("cuda").eval()
 m(torch.randn(1, 2, 3, 224, 224).cuda())
-ws = torch.randn(1 << 28, dtype=torch.bfloat16, device="cuda").view(torch.uint8)
+ws = torch.randn(1 << 30, dtype=torch.bfloat16, device="cuda").view(torch.uint8)
 ms, fl = nat.C.c_float(), nat.C.c_double()
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SF_"))
 for M in [int(a) for a in sys.argv[1:]]:
