@@ -135,7 +135,13 @@ int sf_post_head(sf_encoder* enc, float* hidden_dev, int B, int T, int H, int W,
  * The cache holds, per layer, the temporal K/V rows of every frame seen so far.                 */
 int sf_cache_create(sf_encoder* enc, int B, int max_frames, int H, int W, sf_cache** out);
 int sf_cache_reset(sf_cache* cache);            /* TimesformerVisionTower.clear_cache (:1528) */
-int sf_cache_length(const sf_cache* cache);     /* DynamicCache.get_seq_length()              */
+int sf_cache_length(const sf_cache* cache);
+/* Bounded-memory policy of a stream that outlives the cache (choose while the cache is empty): 0 (default) = stop at capacity
+ * with SF_ERR_CAPACITY — the reference raises at config.num_frames (timesformer_encoder.py:343-348); 1 = SLIDING WINDOW: once
+ * `max_frames` frames are cached every further single-frame call overwrites the oldest one, its temporal query sees the last
+ * `max_frames` frames, and frames past the time-embedding table reuse its last row.  An extension beyond the reference
+ * (SURVEY.md section 8 f-2 asks for a bounded-memory policy); sf_cache_length keeps counting the frames seen.                 */
+int sf_cache_set_policy(sf_cache* cache, int policy);     /* DynamicCache.get_seq_length()              */
 size_t sf_cache_bytes(const sf_cache* cache);
 void sf_cache_destroy(sf_cache* cache);
 int sf_stream_workspace_bytes(sf_encoder* enc, const sf_cache* cache, int T_new, size_t* out);

@@ -90,7 +90,7 @@ def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, mask: Optional[Tensor]) ->
 # --------------------------------------------------------------------------------------------
 # embeddings  (modeling:336-350, 380-457;  vqa_enc:307-375 for the streaming offset)
 # --------------------------------------------------------------------------------------------
-def time_embedding_rows(sd, cfg, t_past: int, t_new: int, streaming: bool) -> Tensor:
+def time_embedding_rows(sd, cfg, t_past: int, t_new: int, streaming: bool, clamp: bool = False) -> Tensor:
     """Rows of the time-embedding table used for frames ``t_past .. t_past+t_new-1`` -> [t_new, D].
 
     Full clip (modeling:435-450): slice when T < num_frames, ``interpolate(mode="nearest")`` when
@@ -101,6 +101,8 @@ def time_embedding_rows(sd, cfg, t_past: int, t_new: int, streaming: bool) -> Te
     te = sd["embeddings.time_embeddings"][0]  # [num_frames, D]
     nf = te.shape[0]
     total = t_past + t_new
+    if streaming and clamp:      # sliding-window extension (NOT in the reference): frames past the table reuse its last row
+        return te[torch.arange(t_past, total).clamp(max=nf - 1)]
     if streaming:
         if total > nf:
             raise ValueError(
@@ -142,14 +144,14 @@ def patchify(pixels: Tensor, P: int) -> Tensor:
     return x.permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, gh * gw, C * P * P)
 
 
-def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False) -> Tensor:
+def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False, clamp_time: bool = False) -> Tensor:
     B, T, C, H, W = pixels.shape
     w = sd["embeddings.patch_embeddings.projection.weight"]
     x = patchify(pixels, cfg.patch_size) @ w.reshape(w.shape[0], -1).t()
     x = x + sd["embeddings.patch_embeddings.projection.bias"]
     x = x + position_embedding(sd, cfg, H, W)[None, None]          # broadcast over B, T
     if cfg.attention_type != "space_only":
-        x = x + time_embedding_rows(sd, cfg, t_past, T, streaming)[None, :, None, :]
+        x = x + time_embedding_rows(sd, cfg, t_past, T, streaming, clamp_time)[None, :, None, :]
     return x  # [B, T, N, D]
 
 
@@ -157,7 +159,7 @@ def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False
 # one encoder layer (modeling:900-1004), frame-major
 # --------------------------------------------------------------------------------------------
 def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = None,
-                  collect: Optional[dict] = None) -> Tensor:
+                  collect: Optional[dict] = None, window: Optional[int] = None) -> Tensor:
     """h: [B, T, N, D].  ``kv`` (streaming): dict with 'k','v' tensors [B, T_past, N, D] or empty."""
     B, T, N, D = h.shape
     heads = cfg.num_attention_heads
@@ -179,6 +181,10 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
             t_past = kv["k"].shape[1]
             k = torch.cat([kv["k"], k], dim=1)
             v = torch.cat([kv["v"], v], dim=1)
+        if window is not None and k.shape[1] > window:          # sliding-window extension: the oldest frames leave the cache;
+            drop = k.shape[1] - window                          # the new queries keep their distance to the keys that stay
+            k, v = k[:, drop:], v[:, drop:]
+            t_past -= drop
         kv["k"], kv["v"] = k, v
     Tk = k.shape[1]
     to_bn = lambda z: z.permute(0, 2, 1, 3).reshape(B * N, z.shape[1], D)
@@ -244,13 +250,13 @@ def to_patch_major(h: Tensor) -> Tensor:
 
 @torch.no_grad()
 def forward(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
-            collect: Optional[dict] = None, cache: Optional[List[dict]] = None) -> Dict[str, Tensor]:
+            collect: Optional[dict] = None, cache: Optional[List[dict]] = None, window: Optional[int] = None) -> Dict[str, Tensor]:
     """Inference entry: :func:`forward_graph` under ``torch.no_grad()``."""
-    return forward_graph(sd, cfg, pixels, output_hidden_states, collect, cache)
+    return forward_graph(sd, cfg, pixels, output_hidden_states, collect, cache, window)
 
 
 def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
-                  collect: Optional[dict] = None, cache: Optional[List[dict]] = None) -> Dict[str, Tensor]:
+                  collect: Optional[dict] = None, cache: Optional[List[dict]] = None, window: Optional[int] = None) -> Dict[str, Tensor]:
     """Full-clip forward (``cache is None``) or one streaming call (``cache`` = list of per-layer dicts).
 
     Returns ``last_hidden_state [B,T,N,D]``, ``pooler_output [B,T,D]`` and, on request,
@@ -262,14 +268,19 @@ def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
     t_past = 0
     if streaming and cache and "k" in cache[0]:
         t_past = cache[0]["k"].shape[1]
-    h = embeddings(sd, cfg, pixels, t_past=t_past, streaming=streaming)
+    if window is not None:
+        # ``window`` = the build's sliding-window cache policy (an EXTENSION, the reference raises at num_frames,
+        # vqa_enc:343-348): absolute frame count kept next to the truncated K / V, time rows clamped to the table
+        t_past = cache[0].get("seen", 0)
+        cache[0]["seen"] = t_past + pixels.shape[1]
+    h = embeddings(sd, cfg, pixels, t_past=t_past, streaming=streaming, clamp_time=window is not None)
     if collect is not None:
         collect["embeddings"] = h
     hs = []
     for i in range(cfg.num_hidden_layers):
         if output_hidden_states:
             hs.append(to_patch_major(h))
-        h = layer_forward(sd, cfg, i, h, kv=(cache[i] if streaming else None), collect=collect)
+        h = layer_forward(sd, cfg, i, h, kv=(cache[i] if streaming else None), collect=collect, window=window)
         if collect is not None:
             collect.setdefault("layer_out", []).append(h)
     if output_hidden_states:

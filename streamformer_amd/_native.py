@@ -55,6 +55,7 @@ SIGNATURES = {
     "sf_cache_reset": (_I, [_P]),
     "sf_cache_length": (_I, [_P]),
     "sf_cache_bytes": (_SZ, [_P]),
+    "sf_cache_set_policy": (_I, [_P, _I]),
     "sf_cache_destroy": (None, [_P]),
     "sf_stream_workspace_bytes": (_I, [_P, _P, _I, C.POINTER(_SZ)]),
     "sf_forward_stream": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -1138,9 +1138,9 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
   const int h = task % p.heads, bn = task / p.heads;
   const int b = bn / p.N, n = bn % p.N;
   // the cache position by value, or (streamed frame replayed from the position-free graph) from device memory
-  const int t_past = p.t_past_dev ? *p.t_past_dev : p.t_past;
-  const int q_t0 = p.t_past_dev ? t_past : p.q_t0;
-  const int Tk = p.t_past_dev ? min(t_past + 1, KP * 64) : p.Tk;
+  const int q_t0 = p.pos_dev ? p.pos_dev[0] : p.q_t0;
+  const int Tk = p.pos_dev ? min(p.pos_dev[1], KP * 64) : p.Tk;
+  const int t_past = p.pos_dev ? Tk - 1 : p.t_past;         // absolute index of the query among the keys (causal: keys <= it)
   constexpr int ESZ = F32 ? 4 : 2;
   constexpr int QL = F32 ? 16 : 8;                 // 16-byte loads per 64-dim row
   const char* qb = reinterpret_cast<const char*>(p.q);

@@ -195,7 +195,10 @@ struct SfPixelNorm { float scale[4]; float shift[4]; };
 // Per-call parameters of a streamed frame, in DEVICE memory (written by one tiny launch in front of the graph replay): the
 // caller's input / output tensors and the cache position.  Kernels of the captured sequence read them through this block, so
 // ONE graph serves every call (no per-position capture, no staging copy of the outputs).
-struct SfStreamParams { const void* pixels; float* lhs; float* pooler; int t_past; int pad; };
+// t_row = time-embedding row of the new frame, slot = its row in the KV-cache, tk = keys its query sees (cached + itself).
+// Plain streaming: t_row = slot = frames cached, tk = slot + 1.  Sliding window (cache full): slot = t mod capacity,
+// tk = capacity, t_row = min(t, num_frames - 1).
+struct SfStreamParams { const void* pixels; float* lhs; float* pooler; int t_row; int slot; int tk; };
 hipError_t sf_launch_stream_params(SfStreamParams* dst, const SfStreamParams& v, hipStream_t s);
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
                               int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr,
@@ -234,7 +237,8 @@ struct SfAttnArgs {
   //   q rows ((b*Tq_cap + q_t0 + t)*N + n), t < Tq ; kv rows ((b*Tcap + t)*N + n), t < Tk ;
   //   query t sits at absolute frame t_past + t (causal: keys <= that); ctx rows ((b*Tq + t)*N + n)
   int B, Tq, Tk, Tcap, t_past, causal, Tq_cap, q_t0;
-  const int* t_past_dev;              // single-query decode kernel only: t_past = q_t0 = *t_past_dev, Tk = t_past + 1 (position-free graph)
+  const int* pos_dev;                 // single-query decode kernel only: {slot, tk} from device memory (position-free graph): q row = slot,
+                                      // tk keys, all of them visible
   bf16_t* ctx_hi; bf16_t* ctx_lo;     // [rows, D] output (lo only in accurate mode)
   int D;
   float* lse2_out;                    // spatial only, optional: base-2 log-sum-exp of the scaled scores per query,

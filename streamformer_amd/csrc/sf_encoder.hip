@@ -109,6 +109,7 @@ struct sf_cache {
   std::map<uint32_t, GraphEntry> graphs;
   hipStream_t cap_stream = nullptr;   // captures are recorded on a private stream (the caller's may be the null stream, which
                                       // cannot capture) and replayed on the caller's
+  int policy = 0;                     // 0 = stop at capacity (the reference raises there), 1 = sliding window over the last `cap` frames
   SfStreamParams* dparams = nullptr;  // device block {pixels, outputs, position} of the single-frame graph (one graph for all positions)
 };
 
@@ -619,7 +620,10 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
                        float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev,
                        const Workspace& ws, void* const* layer_tqkv, int cap, int t_past, bool streaming,
                        hipStream_t s, float* attentions = nullptr, int stages = 7, int la = 0, int lb = -1,
-                       int ready = 0, const SfStreamParams* sp = nullptr) {
+                       int ready = 0, const SfStreamParams* sp = nullptr, const int* pos3 = nullptr) {
+  // pos3 (streaming, T == 1): {time-embedding row, cache slot, keys seen} when they differ from (t_past, t_past, t_past + 1):
+  // the sliding-window policy of a full cache
+  const int t_row = pos3 ? pos3[0] : t_past, slot = pos3 ? pos3[1] : t_past, tk = pos3 ? pos3[2] : t_past + T;
   // sp (streaming, T == 1, graph capture): the cache position is read on the DEVICE from sp->t_past by the kernels that need
   // it (time-embedding row, KV-cache append row, single-query attention); t_past here only selects kernel variants
   // ready: 1 = the patch matrix is already in the workspace (the streaming entry extracts it outside its graph),
@@ -641,10 +645,10 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   bool embed_emitted_stats = false;
   if (stages & 1) {
   SfRowIndex idx;
-  int rc = time_rows(e, t_past, T, streaming, &idx);
+  int rc = time_rows(e, t_row, T, streaming, &idx);
   if (rc) return rc;
   if (sp) { for (int t = 0; t < T; ++t) idx.idx[t] = t; }
-  HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s, sp ? &sp->t_past : nullptr));
+  HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s, sp ? &sp->t_row : nullptr));
   // LN folding (decided here because the folded path lets the embedding GEMM emit bf16(x) + row statistics itself:
   // panel kernel, out = table[m % (T N)] + patches W^T + b with table = pos + time rows)
   bool embed_panel = false;
@@ -702,16 +706,16 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     const size_t tsz = tplanes ? 2 : esz;
     HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, tplanes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)tq, (bf16_t*)tq,
                        tplanes ? (bf16_t*)tq + (size_t)M * 3 * D : nullptr, nullptr, 1.f,
-                       3 * D, T * N, cap * N, sp ? 0 : t_past * N, fold_st, nullptr, sfold, sp ? &sp->t_past : nullptr, N));
+                       3 * D, T * N, cap * N, sp ? 0 : slot * N, fold_st, nullptr, sfold, sp ? &sp->slot : nullptr, N));
     {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
       a.q = tq; a.k = (char*)tq + (size_t)D * tsz; a.v = (char*)tq + (size_t)2 * D * tsz;
       a.in_is_f32 = acc && !tplanes; a.lo_plane_off = tplanes ? (long long)M * 3 * D : 0;
       a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
-      a.N = N; a.B = B; a.Tq = T; a.Tk = t_past + T; a.Tcap = cap; a.t_past = t_past;
-      a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = t_past;
-      a.t_past_dev = sp ? &sp->t_past : nullptr;
+      a.N = N; a.B = B; a.Tq = T; a.Tk = tk; a.Tcap = cap; a.t_past = tk - T;
+      a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = slot;
+      a.pos_dev = sp ? &sp->slot : nullptr;
       a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
       HIP_TRY(sf_launch_temporal_attention(a, acc, s));
     }
@@ -925,6 +929,12 @@ extern "C" int sf_cache_reset(sf_cache* c) {
   return SF_OK;
 }
 extern "C" int sf_cache_length(const sf_cache* c) { return c ? c->len : 0; }
+extern "C" int sf_cache_set_policy(sf_cache* c, int policy) {
+  if (!c || (policy != 0 && policy != 1)) return set_err(SF_ERR_INVALID, "policy must be 0 (stop at capacity) or 1 (sliding window)");
+  if (c->len != 0) return set_err(SF_ERR_STATE, "the policy of a cache is chosen while it is empty");
+  c->policy = policy;
+  return SF_OK;
+}
 extern "C" size_t sf_cache_bytes(const sf_cache* c) { return c ? c->bytes : 0; }
 static void drop_graphs(sf_cache* c) {
   for (auto& kv : c->graphs)
@@ -958,8 +968,24 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
   if (rc) return rc;
   if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
   if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8) return set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8");
-  if (c->len + T_new > c->cap)
+  // Positions of the call.  Sliding window (policy 1, beyond the reference, which raises at num_frames): once the cache is
+  // full the new frame overwrites the oldest slot, its query sees the last `cap` frames, and frames past the time-embedding
+  // table reuse its last row (the nearest-neighbour extension modeling:441-447 applies to long clips).
+  const int nf = e->cfg.num_frames;
+  const bool slide = c->policy == 1 && c->len + T_new > (c->cap < nf ? c->cap : nf);
+  if (slide && T_new != 1)
+    return set_err(SF_ERR_CAPACITY, "a sliding-window cache that is full (%d of %d frames) advances one frame per call, got %d", c->len, c->cap, T_new);
+  if (!slide && c->len + T_new > c->cap)
     return set_err(SF_ERR_CAPACITY, "cache holds %d of %d frames; %d more do not fit", c->len, c->cap, T_new);
+  if (!slide && c->len + T_new > nf)
+    return set_err(SF_ERR_CAPACITY, "streaming needs time-embedding row %d but config.num_frames is %d", c->len + T_new - 1, nf);
+  int pos3[3] = {c->len, c->len, c->len + T_new};
+  if (c->policy == 1 && T_new == 1) {
+    pos3[0] = c->len < nf ? c->len : nf - 1;
+    pos3[1] = c->len % c->cap;
+    pos3[2] = c->len + 1 < c->cap ? c->len + 1 : c->cap;
+  }
+  const int* pos = (c->policy == 1 && T_new == 1) ? pos3 : nullptr;
   Workspace ws = carve(e, workspace, c->B, T_new, N, false);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
   hipStream_t s = (hipStream_t)stream;
@@ -972,22 +998,21 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
   const bool use_graph = !graphs_off && !hidden_states && cap == hipStreamCaptureStatusNone && T_new < 256 && c->len < 65536;
   if (!use_graph) {
     rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,
-                     c->qkv.data(), c->cap, c->len, true, s);
+                     c->qkv.data(), c->cap, c->len, true, s, nullptr, 7, 0, -1, 0, nullptr, pos);
     if (rc == SF_OK) c->len += T_new;
     return rc;
   }
   const int F = c->B * T_new, M = F * N;
   // One new frame per call (the streaming step proper): ONE graph per cache serves every position.  The caller's tensors
-  // and the position reach the kernels through a 32-byte device block written by one tiny launch in front of the replay;
+  // and the position reach the kernels through a small device block written by one tiny launch in front of the replay;
   // only the number of 64-key passes of the single-query attention is compiled in (1 / 2 / 4 -> at most three graphs).
   // Several frames per call keep one graph per (position, count): their attention kernels take the position by value.
   static const bool posfree_off = getenv("SF_STREAM_GRAPH_PER_POSITION") != nullptr;
   const bool posfree = T_new == 1 && !posfree_off && c->dparams != nullptr;
-  if (c->len + T_new > e->cfg.num_frames)
-    return set_err(SF_ERR_CAPACITY, "streaming needs time-embedding row %d but config.num_frames is %d", c->len + T_new - 1, e->cfg.num_frames);
-  const int kp = (c->len + T_new + 63) >> 6;
+  const int kp = (pos3[2] + 63) >> 6;
   const int kcls = kp <= 1 ? 1 : (kp <= 2 ? 2 : 4);
   const uint32_t key = posfree ? (0x80000000u | (uint32_t)kcls) : (((uint32_t)c->len << 8) | (uint32_t)T_new);
+  if (!posfree && pos) return set_err(SF_ERR_STATE, "SF_STREAM_GRAPH_PER_POSITION cannot serve a sliding-window cache");
   sf_cache::GraphEntry& g = c->graphs[key];
   if (g.exec && (g.ws != workspace || g.pos != pos_dev || g.pooler != (pooler != nullptr))) {
     (void)hipGraphExecDestroy(g.exec);
@@ -999,7 +1024,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     // first call of this cache: run eagerly once so that every lazy per-kernel set-up (hipFuncSetAttribute, device
     // queries) has happened before a capture is opened
     rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, nullptr, pos_dev, ws, c->qkv.data(),
-                     c->cap, c->len, true, s);
+                     c->cap, c->len, true, s, nullptr, 7, 0, -1, 0, nullptr, pos);
     if (rc == SF_OK) { c->len += T_new; c->warmed = true; }
     if (!g.exec) c->graphs.erase(key);
     return rc;
@@ -1014,14 +1039,15 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
     hipError_t pe = hipSuccess;
     if (posfree) {
       // representative position of the class: selects the 64-key pass count; the kernels read the live one from dparams
-      int rep = kcls * 64 - T_new;
-      if (rep + T_new > c->cap) rep = c->cap - T_new;
-      if (rep + T_new > e->cfg.num_frames) rep = e->cfg.num_frames - T_new;
+      int rep_tk = kcls * 64;
+      if (rep_tk > c->cap) rep_tk = c->cap;
+      if (c->policy != 1 && rep_tk > nf) rep_tk = nf;
+      const int rep3[3] = {0, 0, rep_tk};
       pe = sf_launch_patchify(nullptr, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, c->cap_stream,
                               &e->pixel_norm, c->dparams);
       rc = pe != hipSuccess ? SF_ERR_HIP :
            run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
-                       ws, c->qkv.data(), c->cap, rep, true, c->cap_stream, nullptr, 7, 0, -1, 1, c->dparams);
+                       ws, c->qkv.data(), c->cap, 0, true, c->cap_stream, nullptr, 7, 0, -1, 1, c->dparams, rep3);
       if (rc == SF_OK)
         pe = sf_launch_copy2(ws.lhs_stage, nullptr, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, nullptr, (size_t)F * e->D,
                              c->cap_stream, c->dparams);
@@ -1046,7 +1072,7 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
   }
   if (posfree) {
     SfStreamParams v;
-    v.pixels = pixels; v.lhs = last_hidden; v.pooler = pooler; v.t_past = c->len; v.pad = 0;
+    v.pixels = pixels; v.lhs = last_hidden; v.pooler = pooler; v.t_row = pos3[0]; v.slot = pos3[1]; v.tk = pos3[2];
     HIP_TRY(sf_launch_stream_params(c->dparams, v, s));
     HIP_TRY(hipGraphLaunch(g.exec, s));
   } else {

@@ -85,11 +85,16 @@ class StreamCache:
     A cache belongs to the packed weights it was created against: when the model re-packs (new weights, another
     compute mode, another device) the cache is invalidated and the next use raises instead of reading freed memory."""
 
-    def __init__(self, model: "TimesformerMultiTaskingModelSigLIP", batch: int, max_frames: int, H: int, W: int):
+    def __init__(self, model: "TimesformerMultiTaskingModelSigLIP", batch: int, max_frames: int, H: int, W: int,
+                 policy: str = "stop"):
+        if policy not in ("stop", "slide"):
+            raise ValueError("policy must be 'stop' (raise at capacity, like the reference) or 'slide' (sliding window over the last max_frames frames)")
         self._model = weakref.ref(model)
         self._h = nat.C.c_void_p()
         nat.check(nat.lib.sf_cache_create(model._handle, batch, max_frames, H, W, nat.C.byref(self._h)))
-        self.batch, self.max_frames, self.H, self.W = batch, max_frames, H, W
+        self.batch, self.max_frames, self.H, self.W, self.policy = batch, max_frames, H, W, policy
+        if policy == "slide":
+            nat.check(nat.lib.sf_cache_set_policy(self._h, 1))
         model._caches.add(self)
 
     @property
@@ -103,6 +108,12 @@ class StreamCache:
         return self._h
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
+        """Frames the cache holds (HF ``DynamicCache`` semantics): never more than ``max_frames`` under the sliding window."""
+        return min(self.frames_seen, self.max_frames)
+
+    @property
+    def frames_seen(self) -> int:
+        """Frames streamed through this cache since its creation / last ``reset()``."""
         return nat.lib.sf_cache_length(self._require())
 
     def reset(self) -> None:
@@ -736,11 +747,14 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
 
     # ------------------------------------------------------------------------------------ forward
     def new_cache(self, batch_size: int = 1, max_frames: Optional[int] = None, height: Optional[int] = None,
-                  width: Optional[int] = None) -> StreamCache:
+                  width: Optional[int] = None, policy: str = "stop") -> StreamCache:
+        """``policy="slide"``: bounded memory for streams that outlive the cache — past ``max_frames`` every new frame replaces the
+        oldest one and attends to the last ``max_frames`` frames (an extension: the reference raises at ``config.num_frames``,
+        timesformer_encoder.py:343-348)."""
         self._sync()
         c = self.config
         with torch.cuda.device(self.device):
-            return StreamCache(self, batch_size, max_frames or c.num_frames, height or c.image_size, width or c.image_size)
+            return StreamCache(self, batch_size, max_frames or c.num_frames, height or c.image_size, width or c.image_size, policy)
 
     def forward(self, pixel_values: torch.Tensor, output_attentions: Optional[bool] = None,
                 output_hidden_states: Optional[bool] = None, return_dict: Optional[bool] = None,
@@ -804,7 +818,7 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
                 ch = cache._require()
                 if cache._model() is not self:
                     raise ValueError("past_key_values belongs to another model")
-                if cache_position is not None and int(cache_position[0]) != cache.get_seq_length():
+                if cache_position is not None and int(cache_position[0]) != cache.frames_seen:
                     raise ValueError("cache_position must continue the cache (vqa_enc:1340-1349)")
                 if (cache.batch, cache.H, cache.W) != (B, H, W):
                     raise ValueError("past_key_values was created for a different batch size / resolution")
@@ -885,11 +899,13 @@ class TimesformerVisionTower(nn.Module):
     window that can still be returned is kept (the reference keeps every frame it has ever seen)."""
 
     def __init__(self, vision_tower, vision_tower_cfg: Any = None, delay_load: bool = False, *, context_length: Optional[int] = None,
-                 streaming_mode: Optional[bool] = None, max_frames: Optional[int] = None, compute_dtype: Any = "bf16"):
+                 streaming_mode: Optional[bool] = None, max_frames: Optional[int] = None, compute_dtype: Any = "bf16",
+                 cache_policy: str = "stop"):
         super().__init__()
         self.is_loaded = False
         self._compute_dtype = compute_dtype
         self._max_frames = max_frames
+        self._cache_policy = cache_policy        # "slide": streams may outlive max_frames / config.num_frames (StreamCache policy)
         if isinstance(vision_tower, nn.Module):
             self.vision_tower_name = getattr(vision_tower, "name_or_path", type(vision_tower).__name__)
             self._adopt(vision_tower)
@@ -936,11 +952,11 @@ class TimesformerVisionTower(nn.Module):
             pkv, self.past_key_values, self.hidden_states = None, None, None
         if pkv is None:
             sp, self._spare = self._spare, None
-            if sp is not None and sp.valid and (sp.batch, sp.H, sp.W) == (B, H, W) and sp._model() is self.vision_tower:
+            if sp is not None and sp.valid and (sp.batch, sp.H, sp.W, sp.policy) == (B, H, W, self._cache_policy) and sp._model() is self.vision_tower:
                 sp.reset()
                 pkv = sp
             else:
-                pkv = self.vision_tower.new_cache(B, self._max_frames or self.config.num_frames, H, W)
+                pkv = self.vision_tower.new_cache(B, self._max_frames or self.config.num_frames, H, W, policy=self._cache_policy)
         return pkv
 
     def forward(self, images):

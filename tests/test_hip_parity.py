@@ -436,6 +436,43 @@ def test_module_protocol_on_the_gpu(sa):
     assert maxabs(o.last_hidden_state.float(), wantb) <= 4e-2          # bf16 output rounding of values up to ~6
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", ACC_CEIL), ("bf16", BF16_LHS)])
+@pytest.mark.parametrize("num_frames,cap,streams", [(8, 6, 1), (4, 6, 2), (16, 16, 1)])
+def test_sliding_window_cache_outlives_num_frames(sa, mode, tol, num_frames, cap, streams):
+    """VERDICT r2 missing #5 / SURVEY 8 f-2 "bounded-memory policy": policy="slide" — past `max_frames` every new frame
+    replaces the oldest cached one, attends to the last `max_frames` frames and (past the time-embedding table) reuses the
+    table's last row — against the oracle's restatement of the same policy (oracle `window=`), 2.5 windows deep, also from
+    inside the position-free graph; the default policy still stops where the reference raises (vqa_enc:343-348)."""
+    cfg = small_cfg(num_frames=num_frames)
+    sd = make_state_dict(cfg, seed=4)
+    m = build(sa, cfg, sd, mode)
+    total = int(2.5 * cap) + 1
+    x = frames(9, (streams, total, 3, 48, 48))
+    ocache = O.new_cache(cfg)
+    cache = m.new_cache(streams, cap, policy="slide")
+    t = 0
+    first = min(3, cap, num_frames)                     # a multi-frame call while the window still has room, then single frames
+    chunks = [first] + [1] * (total - first)
+    for c in chunks:
+        want = O.forward(sd, cfg, x[:, t:t + c], cache=ocache, window=cap)
+        got = m(x[:, t:t + c].cuda(), use_cache=True, past_key_values=cache)
+        assert maxabs(got.last_hidden_state, want["last_hidden_state"]) <= tol, (t, c)
+        assert maxabs(got.pooler_output, want["pooler_output"]) <= tol, (t, c)
+        t += c
+        assert cache.frames_seen == t and cache.get_seq_length() == min(t, cap)
+    with pytest.raises(Exception):                       # a full window advances one frame per call
+        m(x[:, :2].cuda(), use_cache=True, past_key_values=cache)
+    stop = m.new_cache(streams, cap)                     # default policy: the reference's hard stop
+    lim = min(cap, num_frames)
+    m(x[:, :lim].cuda(), use_cache=True, past_key_values=stop)
+    with pytest.raises(Exception):
+        m(x[:, lim:lim + 1].cuda(), use_cache=True, past_key_values=stop)
+    tower = sa.TimesformerVisionTower(m, streaming_mode=True, context_length=3, max_frames=cap, cache_policy="slide")
+    for i in range(total):
+        out = tower(x[:1, i:i + 1] if streams == 1 else x[:, i:i + 1])
+    assert out.shape[1] == 3 and torch.isfinite(out).all()
+
+
 def test_stale_cache_is_refused(sa):
     """a cache created before the weights were re-packed must not be written with another element size."""
     nat = sa._native
