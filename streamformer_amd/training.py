@@ -475,14 +475,15 @@ class StreamformerTrainer:
         """One micro-batch of ``train_one_epoch_multi_task``; returns the (unscaled) loss tensor [1]."""
         _, pooler = self.forward(pixel_values)
         loss, gp, gs = self.loss_and_grad(task, pooler, task_input)
+        # d loss / d (scale, bias) into the two scalar slots of this head: ONE in-place multi-tensor add with the 1 / update_freq
+        # factor folded in (no temporaries, no separate scaling launches); d pooler is scaled only when update_freq > 1
         inv = 1.0 / update_freq
-        gs = gs * inv
-        self.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
-        self.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+        torch._foreach_add_([self.grad(f"task_heads.{task}.logit_scale"), self.grad(f"task_heads.{task}.logit_bias")],
+                            [gs[0], gs[1]], alpha=inv)
         self._touched.add(task)
         self.micro += 1
         last = self.micro % update_freq == 0
-        self.backward(gp * inv, reduce=last)
+        self.backward(gp if update_freq == 1 else gp.mul_(inv), reduce=last)
         if last:
             self.optimizer_step(lr=lr, weight_decay=weight_decay, clip_grad=clip_grad)
         return loss

@@ -5,9 +5,9 @@ torch autograd for the single backward operators.  Everything goes through the C
 Tolerances (bf16 MFMA operands, fp32 accumulation — the `dtype` of BASELINE configs #3/#4):
   single operators : max-abs error <= 2e-2 of the tensor's max-abs (inputs pre-rounded to bf16, so the
                      only differences are the bf16 rounding of P/dS/outputs and summation order)
-  whole-model grads: relative L2 error per tensor <= 5e-2, cosine >= 0.998 vs the fp32 oracle; 0-dim
+  whole-model grads: relative L2 error per tensor <= 2.6e-2 (measured 1.7e-2), cosine >= 0.9995 vs the fp32 oracle; 0-dim
                      parameters (temporal gates, logit scale / bias) are single sums over ~1e6 bf16-rounded
-                     products with heavy cancellation: <= 15 % of the value
+                     products with heavy cancellation: <= 10 % of the value (measured 6.7 %)
 """
 import math
 import os
@@ -21,9 +21,9 @@ from tests.helpers import load_npz, small_cfg
 pytestmark = pytest.mark.gpu
 
 OP_TOL = 2e-2
-GRAD_REL_L2 = 5e-2
-GRAD_COS = 0.998
-SCALAR_REL = 0.15
+GRAD_REL_L2 = 2.6e-2        # measured worst 1.7e-2 (head.probe, small model), 1.1e-2 on SigLIP-base; + 50 %
+GRAD_COS = 0.9995           # measured lowest 0.99987
+SCALAR_REL = 0.10           # measured worst 6.7e-2 (a temporal gate: one sum over ~1e6 bf16-rounded products)
 
 
 def _dev():
@@ -188,8 +188,10 @@ def _compare_grads(tr, orc, floor=1e-3):
     for n, r in scalars.items():
         assert r[0] < SCALAR_REL, (n, r)
     worst = max(report.items(), key=lambda kv: kv[1][0])
-    assert worst[1][0] < GRAD_REL_L2, worst
     wc = min(report.items(), key=lambda kv: kv[1][1])
+    ws = max(scalars.items(), key=lambda kv: kv[1][0]) if scalars else ("-", (0.0, 1.0))
+    print(f"[grad parity] worst rel-L2 {worst[1][0]:.3e} ({worst[0]}), lowest cosine {wc[1][1]:.6f} ({wc[0]}), worst 0-dim rel {ws[1][0]:.3e} ({ws[0]})")
+    assert worst[1][0] < GRAD_REL_L2, worst
     assert wc[1][1] > GRAD_COS, wc
     return report
 
