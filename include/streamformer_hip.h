@@ -234,6 +234,12 @@ int sf_trainer_stage_range(const sf_trainer* tr, int stage, int64_t* offset_out,
  * every optimizer step; params_dev must stay valid until the next call.                          */
 int sf_trainer_sync_weights(sf_trainer* tr, const float* params_dev, sf_stream stream);
 int sf_trainer_workspace_bytes(const sf_trainer* tr, int B, int T, size_t* out);
+/* drop_path (stochastic depth, modeling:460-486, 846-856) of the forwards that follow: scales_dev = DEVICE array, per layer
+ * [B*N temporal | B*T spatial | B MLP] factors (0 = branch dropped for that sample group, 1 / keep_prob = kept), L layers back to
+ * back; the reference draws one Bernoulli per dim-0 entry of the tensor each branch returns ((B*N,T,D), (B*T,N,D), (B,N*T,D)).
+ * The backward of a forward applies the factors that forward used.  NULL = none (eval, or drop_path_rate 0).  The array is
+ * caller-owned and must stay valid until the matching backward has run.                                                        */
+int sf_trainer_set_drop_path(sf_trainer* tr, const float* scales_dev, int B, int T);
 /* forward with every activation the backward needs kept in the workspace                         */
 int sf_trainer_forward(sf_trainer* tr, const void* pixels_dev, int pixel_dtype, int B, int T,
                        float* last_hidden_dev, float* pooler_dev, void* workspace_dev,

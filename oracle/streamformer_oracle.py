@@ -159,8 +159,11 @@ def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False
 # one encoder layer (modeling:900-1004), frame-major
 # --------------------------------------------------------------------------------------------
 def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = None,
-                  collect: Optional[dict] = None, window: Optional[int] = None) -> Tensor:
-    """h: [B, T, N, D].  ``kv`` (streaming): dict with 'k','v' tensors [B, T_past, N, D] or empty."""
+                  collect: Optional[dict] = None, window: Optional[int] = None, drop_path: Optional[Tensor] = None) -> Tensor:
+    """h: [B, T, N, D].  ``kv`` (streaming): dict with 'k','v' tensors [B, T_past, N, D] or empty.
+    ``drop_path`` (training): this layer's factors [B*N + B*T + B] — 0 or 1/keep per dim-0 entry of the tensor each residual
+    branch returns in the reference ((B*N,T,D) temporal, (B*T,N,D) spatial, (B,N*T,D) MLP; modeling:460-486, 949, 980, 1000);
+    the reference draws them with torch.rand, here they are an input so that both sides of a test use the same draw."""
     B, T, N, D = h.shape
     heads = cfg.num_attention_heads
     eps = cfg.layer_norm_eps
@@ -194,7 +197,10 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
         mask = torch.arange(Tk)[None, :] <= qi                      # [T, Tk] True = keep
     ctx, _ = _mha(to_bn(q), to_bn(k), to_bn(v), heads, mask)
     ctx = ctx.reshape(B, N, T, D).permute(0, 2, 1, 3)
-    res_t = _lin(_lin(ctx, sd, p + "temporal_attention.output.dense"), sd, p + "temporal_dense")
+    att_t = _lin(ctx, sd, p + "temporal_attention.output.dense")
+    if drop_path is not None:                                        # modeling:949: between the attention output and temporal_dense
+        att_t = att_t * drop_path[:B * N].reshape(B, 1, N, 1).to(att_t.dtype)
+    res_t = _lin(att_t, sd, p + "temporal_dense")
     h1 = h + torch.tanh(sd[p + "temporal_attention_gating"]) * res_t   # modeling:955-958
 
     # ---- spatial attention over N for each (b, t): modeling:962-996 --------------------------
@@ -203,11 +209,16 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
     q, k, v = qkv.split(D, dim=-1)
     ctx, probs = _mha(q, k, v, heads, None)
     xs = _lora_lin(ctx, sd, p + "attention.output.dense", p + "attention.output.dense")
-    h2 = h1 + xs.reshape(B, T, N, D)                                 # residual onto h1 (modeling:993-996)
+    xs = xs.reshape(B, T, N, D)
+    if drop_path is not None:                                        # modeling:980
+        xs = xs * drop_path[B * N:B * N + B * T].reshape(B, T, 1, 1).to(xs.dtype)
+    h2 = h1 + xs                                                     # residual onto h1 (modeling:993-996)
 
     # ---- MLP: modeling:997-1000, 819-837 ---------------------------------------------------------
     y = _lin(_act(cfg, _lin(_ln(h2, sd, p + "layernorm_after", eps), sd, p + "intermediate.dense")),
              sd, p + "output.dense")
+    if drop_path is not None:                                        # modeling:1000
+        y = y * drop_path[B * N + B * T:].reshape(B, 1, 1, 1).to(y.dtype)
     out = h2 + y
     if collect is not None:
         collect.setdefault("h1", []).append(h1)
@@ -252,11 +263,13 @@ def to_patch_major(h: Tensor) -> Tensor:
 def forward(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
             collect: Optional[dict] = None, cache: Optional[List[dict]] = None, window: Optional[int] = None) -> Dict[str, Tensor]:
     """Inference entry: :func:`forward_graph` under ``torch.no_grad()``."""
-    return forward_graph(sd, cfg, pixels, output_hidden_states, collect, cache, window)
+    with torch.no_grad():
+        return forward_graph(sd, cfg, pixels, output_hidden_states, collect, cache, window)
 
 
 def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
-                  collect: Optional[dict] = None, cache: Optional[List[dict]] = None, window: Optional[int] = None) -> Dict[str, Tensor]:
+                  collect: Optional[dict] = None, cache: Optional[List[dict]] = None, window: Optional[int] = None,
+                  drop_path: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """Full-clip forward (``cache is None``) or one streaming call (``cache`` = list of per-layer dicts).
 
     Returns ``last_hidden_state [B,T,N,D]``, ``pooler_output [B,T,D]`` and, on request,
@@ -280,7 +293,8 @@ def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
     for i in range(cfg.num_hidden_layers):
         if output_hidden_states:
             hs.append(to_patch_major(h))
-        h = layer_forward(sd, cfg, i, h, kv=(cache[i] if streaming else None), collect=collect, window=window)
+        h = layer_forward(sd, cfg, i, h, kv=(cache[i] if streaming else None), collect=collect, window=window,
+                          drop_path=None if drop_path is None else drop_path[i])
         if collect is not None:
             collect.setdefault("layer_out", []).append(h)
     if output_hidden_states:

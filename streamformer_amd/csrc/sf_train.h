@@ -54,6 +54,10 @@ hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const 
 // ------------------------------------------------------------------------------------------------
 // act = gelu(pre)   (erf form, modeling:819-824)
 hipError_t sf_launch_gelu_fwd(const bf16_t* pre, bf16_t* act, size_t n, hipStream_t s);
+// drop_path factors per sample group (mode 0 temporal (b, n), 1 spatial (b, t), 2 MLP (b)); see sf_train_kernels.hip
+hipError_t sf_launch_rowscale_bf16(const bf16_t* in, bf16_t* out, const float* scales, int rows, int D, int mode, int T, int N, hipStream_t s);
+hipError_t sf_launch_resid_rowscale(float* out, const float* resid, const float* y, const float* scales, int rows, int D, int mode, int T, int N,
+                                    hipStream_t s);
 // d = d * gelu'(pre)   in place
 hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_t s);
 // LayerNorm backward over rows of x (statistics recomputed): g_out = (g_in ? g_in : 0) + dL/dx, optionally

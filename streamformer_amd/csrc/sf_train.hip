@@ -67,6 +67,9 @@ struct sf_trainer {
   int n_prep_jobs = 0, prep_tiles = 0;
   const float* params_dev = nullptr;
   int fB = 0, fT = 0;               // geometry of the last forward (0 = none)
+  const float* dp_scales = nullptr; // drop_path factors of the next forward (device, caller-owned), nullptr = none
+  int dp_B = 0, dp_T = 0;
+  const float* f_dp = nullptr;      // the factors the last forward used: its backward applies the same ones
   int n_extra = 0, extra_seg0 = 0;  // the scalar slots are the last n_extra trainable segments
   bool extra_steps_set = false;
   int extra_steps[64] = {};
@@ -549,6 +552,10 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
     HIP_TRY(sf_launch_gemm(g, false, s));
   }
   const float scale = 0.125f;
+  if (t->dp_scales && (t->dp_B != B || t->dp_T != T))
+    return sf_set_err(SF_ERR_INVALID, "drop_path factors were set for B=%d T=%d, the forward runs B=%d T=%d", t->dp_B, t->dp_T, B, T);
+  const float* dp = t->dp_scales;
+  const size_t dp_per_layer = (size_t)B * N + (size_t)B * T + (size_t)B;
   for (int li = 0; li < t->L; ++li) {
     const TLayer& l = t->layers[li];
     const TSavedLayer& sv = ws.sl[li];
@@ -566,6 +573,8 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
       HIP_TRY(sf_launch_temporal_attention(a, false, s));
     }
     HIP_TRY(lin_fwd(t, l.t_out, sv.ctx_t, M, SF_EPI_BF16, s, nullptr, sv.t_out));
+    // drop_path (modeling:949) sits between the attention output and temporal_dense: the saved t_out IS the dropped tensor
+    if (dp) HIP_TRY(sf_launch_rowscale_bf16(sv.t_out, sv.t_out, dp + (size_t)li * dp_per_layer, M, D, 0, T, N, s));
     HIP_TRY(lin_fwd(t, l.t_dense, sv.t_out, M, SF_EPI_RESID_F32, s, sv.h1, nullptr, h));      // h1 = h + tanh(g) * dense(.)
     // spatial attention (modeling:962-996)
     HIP_TRY(sf_launch_layernorm(sv.h1, PP(t, P0, l.ln_b_g), PP(t, P0, l.ln_b_b), nullptr, sv.ln_b, nullptr, M, D, eps, s));
@@ -578,11 +587,21 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
       a.N = N; a.frames = F; a.ctx_hi = sv.ctx_s; a.D = D; a.lse2_out = sv.lse_s;
       HIP_TRY(sf_launch_spatial_attention(a, false, s));
     }
-    HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_RESID_F32, s, sv.h2, nullptr, sv.h1));
+    if (dp) {     // h2 = h1 + drop_path(out(ctx)) (modeling:980): the branch leaves the GEMM as fp32, the residual add applies the factor
+      HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_F32, s, ws.g, nullptr));
+      HIP_TRY(sf_launch_resid_rowscale(sv.h2, sv.h1, ws.g, dp + (size_t)li * dp_per_layer + (size_t)B * N, M, D, 1, T, N, s));
+    } else {
+      HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_RESID_F32, s, sv.h2, nullptr, sv.h1));
+    }
     // MLP (modeling:997-1000)
     HIP_TRY(sf_launch_layernorm(sv.h2, PP(t, P0, l.ln_a_g), PP(t, P0, l.ln_a_b), nullptr, sv.ln_a, nullptr, M, D, eps, s));
     HIP_TRY(lin_fwd_gelu(t, l.up, sv.ln_a, M, s, sv.pre, sv.act));
-    HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_RESID_F32, s, ws.h[li + 1], nullptr, sv.h2));
+    if (dp) {     // out = h2 + drop_path(mlp) (modeling:1000)
+      HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_F32, s, ws.g, nullptr));
+      HIP_TRY(sf_launch_resid_rowscale(ws.h[li + 1], sv.h2, ws.g, dp + (size_t)li * dp_per_layer + (size_t)B * N + (size_t)B * T, M, D, 2, T, N, s));
+    } else {
+      HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_RESID_F32, s, ws.h[li + 1], nullptr, sv.h2));
+    }
   }
   // post LayerNorm + pooling head (modeling:1330-1340, 1141-1154)
   HIP_TRY(sf_launch_layernorm(ws.h[t->L], PP(t, P0, t->post_g), PP(t, P0, t->post_b), last_hidden, ws.xn, nullptr, M, D, eps, s));
@@ -593,7 +612,7 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
   HIP_TRY(lin_fwd(t, t->fc1, ws.hn, F, SF_EPI_BF16, s, nullptr, ws.hm_pre));
   HIP_TRY(sf_launch_gelu_fwd(ws.hm_pre, ws.hm, (size_t)F * I, s));
   HIP_TRY(lin_fwd(t, t->fc2, ws.hm, F, SF_EPI_RESID_F32, s, pooler, nullptr, ws.attn_out));
-  t->fB = B; t->fT = T;
+  t->fB = B; t->fT = T; t->f_dp = dp;
   return SF_OK;
 }
 
@@ -686,17 +705,23 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   const float eps = t->cfg.layer_norm_eps;
   const float* P0 = t->params_dev;
 
+  // drop_path: the gradient entering a dropped branch carries the branch's factor (0 or 1 / keep per sample group)
+  const float* dp = t->f_dp ? t->f_dp + (size_t)li * ((size_t)B * N + (size_t)B * T + (size_t)B) : nullptr;
   // g (fp32) and g_bf (its bf16 copy) are both written by the LayerNorm backward that produced them
   // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
-  HIP_TRY(lin_dgrad_dgelu(l.down, ws.g_bf, M, s, ws.d_wide, sv.pre));            // d pre = (g W_down) * gelu'(pre)  [M,I]
-  HIP_TRY(lin_wgrad(c, l.down, ws.g_bf, sv.act, M));
+  const bf16_t* gy = ws.g_bf;
+  if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf, ws.d_ctx, dp + (size_t)B * N + (size_t)B * T, M, D, 2, T, N, s)); gy = ws.d_ctx; }
+  HIP_TRY(lin_dgrad_dgelu(l.down, gy, M, s, ws.d_wide, sv.pre));            // d pre = (g W_down) * gelu'(pre)  [M,I]
+  HIP_TRY(lin_wgrad(c, l.down, gy, sv.act, M));
   HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
   HIP_TRY(lin_wgrad(c, l.up, ws.d_wide, sv.ln_a, M));
   HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln_bf, 1, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- spatial: h2 = h1 + out(attn(qkv(LN_b(h1)))) ---------------------------------------------------------
-  HIP_TRY(lin_dgrad(l.s_out, ws.g_bf, M, s, nullptr, ws.d_ctx));
-  HIP_TRY(lin_wgrad(c, l.s_out, ws.g_bf, sv.ctx_s, M));
+  gy = ws.g_bf;
+  if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf, ws.d_tout, dp + (size_t)B * N, M, D, 1, T, N, s)); gy = ws.d_tout; }
+  HIP_TRY(lin_dgrad(l.s_out, gy, M, s, nullptr, ws.d_ctx));
+  HIP_TRY(lin_wgrad(c, l.s_out, gy, sv.ctx_s, M));
   {
     SfAttnBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -723,6 +748,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
                                 GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   }
+  if (dp) HIP_TRY(sf_launch_rowscale_bf16(ws.d_tout, ws.d_tout, dp, M, D, 0, T, N, s));     // through the drop_path in front of temporal_dense
   HIP_TRY(lin_dgrad(l.t_out, ws.d_tout, M, s, nullptr, ws.d_ctx));
   HIP_TRY(lin_wgrad(c, l.t_out, ws.d_tout, sv.ctx_t, M));
   {
@@ -797,6 +823,13 @@ extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, float* grads,
   for (int i = 0; i < 64; ++i) a.extra_steps[i] = t->extra_steps[i];
   if (grad_sumsq_dev && !(clip_norm > 0.f)) return sf_set_err(SF_ERR_INVALID, "clip_norm must be positive");
   HIP_TRY(sf_launch_adamw(a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_set_drop_path(sf_trainer* t, const float* scales_dev, int B, int T) {
+  if (!t) return sf_set_err(SF_ERR_INVALID, "null argument");
+  if (scales_dev && (B <= 0 || T <= 0)) return sf_set_err(SF_ERR_INVALID, "bad geometry B=%d T=%d", B, T);
+  t->dp_scales = scales_dev; t->dp_B = B; t->dp_T = T;
   return SF_OK;
 }
 

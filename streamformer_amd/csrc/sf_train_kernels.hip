@@ -56,6 +56,54 @@ static int ew_grid(size_t nchunks) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// ------------------------------------------------------------------------------------------------
+// drop_path (stochastic depth, modeling:460-486, 846-856): the per-"sample" keep / drop factor of a residual branch, 0 or
+// 1 / keep_prob, where the reference's sample axis is dim 0 of the tensor the branch returns:
+//   mode 0 temporal (B*N, T, D)  -> group = b * N + n      mode 1 spatial (B*T, N, D) -> group = b * T + t = row / N
+//   mode 2 MLP      (B, N*T, D)  -> group = b = row / (T * N)                (token row = (b * T + t) * N + n)
+// ------------------------------------------------------------------------------------------------
+SF_DEVICE int dp_group(int row, int mode, int T, int N) {
+  if (mode == 1) return row / N;
+  if (mode == 2) return row / (T * N);
+  return (row / (T * N)) * N + row % N;
+}
+__global__ __launch_bounds__(256) void sf_rowscale_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                               const float* __restrict__ scales, size_t nchunks, int D8, int mode, int T, int N) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / D8);
+    const float sc = scales[dp_group(row, mode, T, N)];
+    const u32x4_t v = reinterpret_cast<const u32x4_t*>(in)[i];
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf2f(v[j] & 0xffffu) * sc, __uint_as_float(v[j] & 0xffff0000u) * sc);
+    reinterpret_cast<u32x4_t*>(out)[i] = o;
+  }
+}
+hipError_t sf_launch_rowscale_bf16(const bf16_t* in, bf16_t* out, const float* scales, int rows, int D, int mode, int T, int N, hipStream_t s) {
+  if (D % 8) return hipErrorInvalidValue;
+  const size_t n = (size_t)rows * (D / 8);
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(sf_rowscale_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, scales, n, D / 8, mode, T, N);
+  return hipGetLastError();
+}
+// out = resid + scale[group(row)] * y        (out may alias resid)
+__global__ __launch_bounds__(256) void sf_resid_rowscale_kernel(float* __restrict__ out, const float* __restrict__ resid, const float* __restrict__ y,
+                                                                const float* __restrict__ scales, size_t nchunks, int D4, int mode, int T, int N) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / D4);
+    const float sc = scales[dp_group(row, mode, T, N)];
+    reinterpret_cast<f32x4_t*>(out)[i] = reinterpret_cast<const f32x4_t*>(resid)[i] + sc * reinterpret_cast<const f32x4_t*>(y)[i];
+  }
+}
+hipError_t sf_launch_resid_rowscale(float* out, const float* resid, const float* y, const float* scales, int rows, int D, int mode, int T, int N,
+                                    hipStream_t s) {
+  if (D % 4) return hipErrorInvalidValue;
+  const size_t n = (size_t)rows * (D / 4);
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(sf_resid_rowscale_kernel, dim3(ew_grid(n)), dim3(256), 0, s, out, resid, y, scales, n, D / 4, mode, T, N);
+  return hipGetLastError();
+}
+
 hipError_t sf_launch_gelu_fwd(const bf16_t* pre, bf16_t* act, size_t n, hipStream_t s) {
   if (n % 8) return hipErrorInvalidValue;
   if (!n) return hipSuccess;

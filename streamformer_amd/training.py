@@ -57,6 +57,23 @@ def scaled_lr(lr: float, batch_size: int, update_freq: int, world_size: int) -> 
     return lr * batch_size * update_freq * world_size / 256.0
 
 
+def drop_path_factors(rate: float, num_layers: int, B: int, T: int, N: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """Keep / drop factors of one training forward, [L, B*N + B*T + B] fp32 on the CPU.
+
+    The reference (modeling:846-856, 460-486) gives layer i the rate ``linspace(0, drop_path_rate, L)[i]`` and draws, per
+    residual branch, one Bernoulli(keep) per dim-0 entry of the tensor the branch returns — (B*N, T, D) temporal,
+    (B*T, N, D) spatial, (B, N*T, D) MLP — as ``floor(keep + rand)``, dividing the kept entries by ``keep``."""
+    per = B * N + B * T + B
+    out = torch.ones(num_layers, per, dtype=torch.float32)
+    rates = torch.linspace(0, rate, num_layers).tolist()
+    for i, r in enumerate(rates):
+        if r <= 0.0:
+            continue
+        keep = 1.0 - r
+        out[i] = torch.floor(keep + torch.rand(per, generator=generator)) / keep
+    return out
+
+
 def bucket_ranges(stage_ranges: Sequence[Tuple[int, int]], min_floats: int) -> List[Tuple[int, int, int]]:
     """Group consecutive backward stages into all-reduce buckets of at least ``min_floats`` floats.
 
@@ -83,18 +100,24 @@ class StreamformerTrainer:
     def __init__(self, config: StreamformerConfig, state_dict: Dict[str, torch.Tensor], task_heads: Sequence[str],
                  freeze_spatial: bool = True, device="cuda", lr: float = 1e-3, weight_decay: float = 0.05,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0,
-                 grad_reduce_dtype: str = "fp32", collectives_at_world_1: bool = False, with_optimizer: bool = True):
+                 grad_reduce_dtype: str = "fp32", collectives_at_world_1: bool = False, with_optimizer: bool = True,
+                 drop_path_seed: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamformerTrainer needs an AMD GPU: the training step runs only on the HIP library")
         if config.hidden_act not in _ACT:
             raise NotImplementedError(f"training supports hidden_act in {sorted(_ACT)}")
         if config.attention_type != "divided_space_time":
             raise NotImplementedError("only divided_space_time is implemented")
-        stochastic = {k: float(getattr(config, k, 0.0) or 0.0) for k in ("drop_path_rate", "hidden_dropout_prob", "attention_probs_dropout_prob")}
+        stochastic = {k: float(getattr(config, k, 0.0) or 0.0) for k in ("hidden_dropout_prob", "attention_probs_dropout_prob")}
         if any(v > 0 for v in stochastic.values()):
-            # the reference applies these in train mode (modeling:852-856, 605, 762); the shipped recipe sets all three
-            # to 0 (scripts/pretrain_streamformer.sh), which is the only configuration this step reproduces
-            raise NotImplementedError(f"stochastic regularisation is not implemented in the HIP training step: {stochastic}")
+            # the reference applies these in train mode (modeling:605, 762); the shipped recipe sets both to 0
+            # (scripts/pretrain_streamformer.sh never overrides the config), which is what this step reproduces.  drop_path
+            # (modeling:852-856) IS implemented: config.drop_path_rate > 0 draws per-sample keep / drop factors per forward.
+            raise NotImplementedError(f"dropout is not implemented in the HIP training step (drop_path is): {stochastic}")
+        self.drop_path_rate = float(getattr(config, "drop_path_rate", 0.0) or 0.0)
+        self.drop_path = True                       # False: forwards without stochastic depth (evaluation through the trainer)
+        self.last_drop_path: Optional[torch.Tensor] = None     # the factors of the last forward (CPU), for replay in tests
+        self._dp_dev = None
         if grad_reduce_dtype not in ("fp32", "bf16"):
             raise ValueError("grad_reduce_dtype must be 'fp32' or 'bf16'")
         self.grad_reduce_dtype = grad_reduce_dtype
@@ -108,6 +131,7 @@ class StreamformerTrainer:
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size(process_group) if dist_on else 1
         self.rank = torch.distributed.get_rank(process_group) if dist_on else 0
+        self._dp_gen = torch.Generator().manual_seed(int(drop_path_seed) * 1000003 + self.rank)      # ranks draw different masks
         # world_size 1 normally skips every collective; with this flag they are issued anyway (a 1-rank all-reduce /
         # all-gather is the identity), which is how the RCCL branches get executed and tested on a one-GPU box
         self._collectives = dist_on and (self.world > 1 or bool(collectives_at_world_1))
@@ -390,6 +414,13 @@ class StreamformerTrainer:
             raise ValueError(f"training takes {c.num_channels}x{c.image_size}x{c.image_size} frames, got {Cc}x{H}x{W}")
         N = (H // c.patch_size) * (W // c.patch_size)
         ws = self._workspace(B, T)
+        if self.drop_path_rate > 0.0 and self.drop_path:
+            self.last_drop_path = drop_path_factors(self.drop_path_rate, c.num_hidden_layers, B, T, N, self._dp_gen)
+            self._dp_dev = self.last_drop_path.to(self.device, non_blocking=False)       # kept alive until the backward has run
+            nat.check(nat.lib.sf_trainer_set_drop_path(self._h, self._dp_dev.data_ptr(), B, T))
+        else:
+            self.last_drop_path = None
+            nat.check(nat.lib.sf_trainer_set_drop_path(self._h, None, 0, 0))
         lhs = torch.empty(B, T, N, c.hidden_size, dtype=torch.float32, device=self.device)
         pool = torch.empty(B, T, c.hidden_size, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

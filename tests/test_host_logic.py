@@ -268,6 +268,24 @@ def test_feature_cli_reads_reference_style_checkpoints(tmp_path):
     assert "safe_globals([argparse.Namespace])" in inspect.getsource(features.main)
 
 
+def test_drop_path_factors_follow_the_reference_rule():
+    """modeling:846-856 (layer i: linspace(0, rate, L)[i]) and :460-486 (floor(keep + rand) / keep per dim-0 entry)."""
+    from streamformer_amd.training import drop_path_factors
+    g = torch.Generator().manual_seed(3)
+    f = drop_path_factors(0.5, 5, B=64, T=4, N=9, generator=g)
+    assert tuple(f.shape) == (5, 64 * 9 + 64 * 4 + 64)
+    assert torch.all(f[0] == 1.0)                                         # first layer never drops
+    for i, r in enumerate(torch.linspace(0, 0.5, 5).tolist()[1:], start=1):
+        keep = 1.0 - r
+        vals = set(round(v, 5) for v in torch.unique(f[i]).tolist())
+        assert vals <= {0.0, round(1.0 / keep, 5)}
+        assert abs(float((f[i] > 0).float().mean()) - keep) < 0.08        # 896 draws per layer
+        assert abs(float(f[i].mean()) - 1.0) < 0.15                       # unbiased
+    g2 = torch.Generator().manual_seed(3)
+    assert torch.equal(f, drop_path_factors(0.5, 5, 64, 4, 9, g2))         # replayable from the seed
+    assert torch.all(drop_path_factors(0.0, 3, 2, 2, 2) == 1.0)
+
+
 # ---- training host logic (streamformer_amd/training.py; reference utils.py:574-605, run_finetuning_multi_task.py:386) ----
 def test_cosine_scheduler_table():
     import math

@@ -171,7 +171,7 @@ def _to_dev(ti, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in ti.items()}
 
 
-def _compare_grads(tr, orc, floor=1e-3):
+def _compare_grads(tr, orc, floor=1e-3, scalar_rel=SCALAR_REL):
     og = orc.grads()
     names = set(tr.parameter_names(trainable_only=True))
     assert names == set(og), sorted(names ^ set(og))[:6]
@@ -186,7 +186,7 @@ def _compare_grads(tr, orc, floor=1e-3):
     scalars = {n: r for n, r in report.items() if og[n].numel() == 1}
     report = {n: r for n, r in report.items() if og[n].numel() > 1}
     for n, r in scalars.items():
-        assert r[0] < SCALAR_REL, (n, r)
+        assert r[0] < scalar_rel, (n, r)
     worst = max(report.items(), key=lambda kv: kv[1][0])
     wc = min(report.items(), key=lambda kv: kv[1][1])
     ws = max(scalars.items(), key=lambda kv: kv[1][0]) if scalars else ("-", (0.0, 1.0))
@@ -633,6 +633,48 @@ def test_checkpoint_resume_and_reference_optimizer_layout(golden_dir, tmp_path):
     lb = tr2.micro_step(task, x.to(dev), _to_dev(ti, dev))
     assert float(la) == float(lb)
     assert torch.equal(tr.params, tr2.params) and torch.equal(tr.exp_avg, tr2.exp_avg) and torch.equal(tr.exp_avg_sq, tr2.exp_avg_sq)
+
+
+@pytest.mark.parametrize("task_idx", [0, 1])
+def test_drop_path_gradients_match_the_oracle_on_the_same_draw(task_idx):
+    """VERDICT r2 missing #4: stochastic depth in the training step (modeling:460-486, 846-856: layer i drops each residual
+    branch per sample with rate linspace(0, drop_path_rate, L)[i]; sample = dim-0 entry of the tensor the branch returns).
+    The trainer draws the keep / drop factors per forward from a seeded generator; the oracle's autograd replays the same
+    draw.  Also: the draw changes per forward, an evaluation forward (drop_path off) ignores it, dropout still raises."""
+    from oracle import train_oracle as TO
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    cfg = small_cfg(add_lora_spatial=True, drop_path_rate=0.4, num_hidden_layers=3)
+    sd = make_state_dict(cfg, seed=8, lora=True)
+    dev = _dev()
+    tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device=dev, drop_path_seed=5)
+    orc = TO.OracleTrainer(sd, cfg, ["retrieval", "localization"], freeze_spatial=True)
+    task, x, ti, _ = TO.schedule(cfg, B=4)[task_idx]
+    _, pooler = tr.forward(x.to(dev))
+    dp = tr.last_drop_path
+    assert dp is not None and tuple(dp.shape) == (3, 4 * 9 + 4 * 4 + 4)
+    assert float(dp[0].min()) == 1.0 and float(dp[0].max()) == 1.0                 # layer 0: rate 0
+    assert {round(v, 4) for v in torch.unique(dp[2]).tolist()} <= {0.0, round(1.0 / 0.6, 4)} and float(dp[2].min()) == 0.0      # layer 2: rate 0.4
+    loss, gp, gs = tr.loss_and_grad(task, pooler, _to_dev(ti, dev))
+    tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+    tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+    tr.backward(gp)
+    torch.cuda.synchronize()
+    want_loss = orc.loss(task, x, ti, drop_path=dp)
+    want_loss.backward()
+    assert abs(float(loss) - float(want_loss)) < 2e-2 * abs(float(want_loss))
+    _compare_grads(tr, orc, scalar_rel=0.2)       # gate gradients: the same cancelling sum over 40 % fewer live rows (measured 12 %)
+    plain = float(orc.loss(task, x, ti).detach())
+    assert abs(plain - float(want_loss)) > 1e-4 * abs(plain)                      # the draw really changes the forward
+    _, p2 = tr.forward(x.to(dev))
+    assert not torch.equal(tr.last_drop_path, dp)                                  # a new draw per forward
+    tr.drop_path = False
+    _, p3 = tr.forward(x.to(dev))
+    want = orc.loss(task, x, ti)
+    l3, _, _ = tr.loss_and_grad(task, p3, _to_dev(ti, dev))
+    assert tr.last_drop_path is None and abs(float(l3) - float(want.detach())) < 2e-2 * abs(float(want.detach()))
+    with pytest.raises(NotImplementedError):
+        StreamformerTrainer(small_cfg(hidden_dropout_prob=0.1), make_state_dict(small_cfg(), seed=1), ["retrieval"], device=dev)
 
 
 def test_trainer_rejects_what_it_cannot_do():
