@@ -57,3 +57,52 @@ def test_tile_gemm_shapes(shape):
         env["SF_TILE_SHAPE"] = shape
     r = subprocess.run([sys.executable, "-c", PROBE], env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
     assert r.returncode == 0 and "OK worst" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+TRAIN_PROBE = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["SF_ROOT"])
+import streamformer_amd as sa
+from streamformer_amd.training import StreamformerTrainer
+cfg = sa.siglip_base(add_lora_spatial=True)
+sd = sa.make_state_dict(cfg, seed=3, lora=True)
+tr = StreamformerTrainer(cfg, sd, ["localization"], freeze_spatial=True, device="cuda:0")
+g = torch.Generator().manual_seed(11)
+x = torch.randn(1, 16, 3, 224, 224, generator=g).cuda()
+lab = torch.randn(7, cfg.hidden_size, generator=g); lab = (lab / lab.norm(dim=-1, keepdim=True)).cuda()
+labels = torch.randint(-1, 7, (1, 16), generator=g).cuda()
+_, pooler = tr.forward(x)
+loss, gp, gs = tr.loss_and_grad("localization", pooler, {"kind": "localization", "label_emb": lab, "labels": labels})
+tr.backward(gp)
+torch.cuda.synchronize()
+names = ["encoder.layer.0.temporal_attention.attention.qkv.weight", "encoder.layer.5.intermediate.dense.weight",
+         "encoder.layer.11.output.dense.weight", "encoder.layer.3.attention.attention.qkv_lora_b.weight", "embeddings.position_embeddings"]
+out = {"loss": float(loss), "pooler": pooler.double().norm().item()}
+torch.save({n: tr.grad(n).cpu() for n in names}, os.environ["SF_OUT"])
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_training_step_of_one_clip_is_the_same_on_the_tile_kernels(tmp_path):
+    """One SigLIP-base clip (M = 3136) through the training step: its forward / input-gradient GEMMs land on the tile kernels;
+    the same step with the family switched off (panel / 256^2 kernels) must give the same loss and gradients up to summation
+    order."""
+    import json
+    import torch
+    res = {}
+    for tag, off in (("tile", False), ("plain", True)):
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        env["SF_ROOT"] = ROOT
+        env["SF_OUT"] = str(tmp_path / f"{tag}.pt")
+        if off:
+            env["SF_DISABLE_GEMM_TILE"] = "1"
+        r = subprocess.run([sys.executable, "-c", TRAIN_PROBE], env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0]
+        res[tag] = (json.loads(line[7:]), torch.load(env["SF_OUT"]))
+    a, b = res["tile"], res["plain"]
+    assert abs(a[0]["loss"] - b[0]["loss"]) <= 2e-3 * abs(b[0]["loss"])
+    for n in a[1]:
+        rel = float((a[1][n].double() - b[1][n].double()).norm() / (b[1][n].double().norm() + 1e-30))
+        assert rel < 2e-2, (n, rel)
