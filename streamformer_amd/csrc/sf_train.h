@@ -25,6 +25,27 @@ struct SfWgradArgs {
 size_t sf_wgrad_partial_floats(int M, int N1, int N2);
 hipError_t sf_launch_wgrad(const SfWgradArgs& a, hipStream_t s);
 
+// Several weight gradients over the SAME token rows in one launch (the Linears of one encoder layer): their 256 x 256
+// tiles fill the chip together, so the token range is split 2-ways instead of 7...28-ways per projection — 5x fewer
+// launches and ~10x fewer fp32 partial bytes per layer.  Every job needs N1 % 256 == 0 and N2 % 256 == 0.
+#define SF_WG_MAX_JOBS 8
+struct SfWgradJob {
+  const bf16_t* dy; const bf16_t* x;   // [M, ldy] / [M, ldx]
+  float* out; float* dbias;            // [N1, ldo] fp32; optional bias gradient (+= alpha * column sums of dY)
+  int ldy, ldx, N1, N2, ldo, accumulate;
+  float alpha;
+  int tile0, tiles2;                   // filled by the launcher: first tile of the job, tiles along N2
+  unsigned part_off, bias_off;         // filled by the launcher: float offsets inside one split's partial / bias block
+};
+struct SfWgradGroup {
+  SfWgradJob job[SF_WG_MAX_JOBS];
+  int njobs, M;
+  float* partial;                      // >= sf_wgrad_group_partial_floats(M, sum of tiles, sum of N1) floats
+};
+bool sf_wgrad_groupable(int M, int N1, int N2);
+size_t sf_wgrad_group_partial_floats(int M, int ntiles, int sum_n1);
+hipError_t sf_launch_wgrad_group(SfWgradGroup& g, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // attention backward (softmax(QK^T * scale [+ causal mask]) V), bf16 storage, fp32 math
 // ------------------------------------------------------------------------------------------------

@@ -392,6 +392,7 @@ struct TWs {
   bf16_t* d_ln_bf;
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
   bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
+  bf16_t *g_bf1, *g_bf2, *d_wide_s, *d_wide_t;       // a layer's weight-gradient operands stay intact until its grouped launch
   float *gh, *d_hn, *d_pc, *dq_frames, *dq_total;
   bf16_t *gh_bf, *d_hm;
   size_t bytes;
@@ -427,6 +428,8 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   w.g_bf = c.take<bf16_t>(M * D);
   w.d_wide = c.take<bf16_t>(M * max_sz(I, 3 * D));
   w.d_ctx = c.take<bf16_t>(M * D); w.d_tout = c.take<bf16_t>(M * D);
+  w.g_bf1 = c.take<bf16_t>(M * D); w.g_bf2 = c.take<bf16_t>(M * D);
+  w.d_wide_s = c.take<bf16_t>(M * 3 * D); w.d_wide_t = c.take<bf16_t>(M * 3 * D);
   w.lora_u = c.take<bf16_t>(M * kRank); w.lora_v = c.take<bf16_t>(M * kRank);
   size_t wp = 0;
   const int Mi = (int)M, Fi = (int)F, Di = t->D, Ii = t->I;
@@ -436,6 +439,13 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Di, Ii)); wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Ii, Di));
   wp = max_sz(wp, sf_wgrad_partial_floats(Fi, Di, Di));
   wp = max_sz(wp, sf_wgrad_partial_floats(Mi, 3 * Di, kRank)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, kRank, Di));
+  {     // one layer's Linears in one grouped launch (backward_layer)
+    int tiles = 0, n1 = 0;
+    const int dims[7][2] = {{Di, Ii}, {Ii, Di}, {Di, Di}, {3 * Di, Di}, {Di, Di}, {Di, Di}, {3 * Di, Di}};
+    for (const auto& d : dims)
+      if (sf_wgrad_groupable(Mi, d[0], d[1])) { tiles += (d[0] / 256) * (d[1] / 256); n1 += d[0]; }
+    for (int n = 1; n <= tiles; ++n) wp = max_sz(wp, sf_wgrad_group_partial_floats(Mi, n, n1));
+  }
   w.wg_partial = c.take<float>(wp);
   w.dw_scratch = c.take<float>((size_t)3 * D * D);
   w.cs = c.take<float>(max_sz(I, 3 * D));
@@ -694,6 +704,22 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   return SF_OK;
 }
 
+// one encoder layer's weight gradients, batched: a Linear whose [N, K] is made of 256^2 tiles (and is trained densely, no
+// LoRA factors) is queued here with its operands and launched together with the others at the end of the layer
+struct LayerWgrads {
+  SfWgradGroup g;
+  bool on;
+};
+static hipError_t lin_wgrad_queued(const BwdCtx& c, LayerWgrads& q, const TLin& l, const bf16_t* dy, const bf16_t* x, int M) {
+  float* gw = GG(c.t, c.grads, l.pw, l.pw_off);
+  if (!q.on || l.pla >= 0 || !gw || !sf_wgrad_groupable(M, l.N, l.K) || q.g.njobs >= SF_WG_MAX_JOBS) return lin_wgrad(c, l, dy, x, M);
+  SfWgradJob& J = q.g.job[q.g.njobs++];
+  memset(&J, 0, sizeof(J));
+  J.dy = dy; J.x = x; J.ldy = l.N; J.ldx = l.K; J.N1 = l.N; J.N2 = l.K; J.ldo = l.K; J.alpha = 1.f; J.accumulate = 1;
+  J.out = gw; J.dbias = GG(c.t, c.grads, l.pb, l.pb_off);
+  return hipSuccess;
+}
+
 static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   const sf_trainer* t = c.t;
   const TWs& ws = *c.ws;
@@ -707,42 +733,55 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
 
   // drop_path: the gradient entering a dropped branch carries the branch's factor (0 or 1 / keep per sample group)
   const float* dp = t->f_dp ? t->f_dp + (size_t)li * ((size_t)B * N + (size_t)B * T + (size_t)B) : nullptr;
-  // g (fp32) and g_bf (its bf16 copy) are both written by the LayerNorm backward that produced them
+  static const bool ungrouped = getenv("SF_WGRAD_UNGROUPED") != nullptr;
+  LayerWgrads q;
+  memset(&q.g, 0, sizeof(q.g));
+  q.g.M = M; q.g.partial = ws.wg_partial;
+  q.on = !dp && !ungrouped;         // the drop_path copies reuse d_ctx / d_tout inside the layer: immediate launches there
+  // g (fp32) and its bf16 copy are both written by the LayerNorm backward that produced them; the bf16 copy rotates through
+  // g_bf -> g_bf1 -> g_bf2 -> g_bf inside the layer and the three attention / MLP gradients have their own wide buffers, so
+  // that every queued weight gradient still finds its operands at the end of the layer
   // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
   const bf16_t* gy = ws.g_bf;
   if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf, ws.d_ctx, dp + (size_t)B * N + (size_t)B * T, M, D, 2, T, N, s)); gy = ws.d_ctx; }
   HIP_TRY(lin_dgrad_dgelu(l.down, gy, M, s, ws.d_wide, sv.pre));            // d pre = (g W_down) * gelu'(pre)  [M,I]
-  HIP_TRY(lin_wgrad(c, l.down, gy, sv.act, M));
+  HIP_TRY(lin_wgrad_queued(c, q, l.down, gy, sv.act, M));
   HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
-  HIP_TRY(lin_wgrad(c, l.up, ws.d_wide, sv.ln_a, M));
-  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln_bf, 1, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
+  HIP_TRY(lin_wgrad_queued(c, q, l.up, ws.d_wide, sv.ln_a, M));
+  HIP_TRY(sf_launch_ln_bwd(sv.h2, ws.d_ln_bf, 1, PP(t, P0, l.ln_a_g), ws.g, ws.g, ws.g_bf1, GG(t, c.grads, l.ln_a_g), GG(t, c.grads, l.ln_a_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- spatial: h2 = h1 + out(attn(qkv(LN_b(h1)))) ---------------------------------------------------------
-  gy = ws.g_bf;
-  if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf, ws.d_tout, dp + (size_t)B * N, M, D, 1, T, N, s)); gy = ws.d_tout; }
+  gy = ws.g_bf1;
+  if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf1, ws.d_tout, dp + (size_t)B * N, M, D, 1, T, N, s)); gy = ws.d_tout; }
   HIP_TRY(lin_dgrad(l.s_out, gy, M, s, nullptr, ws.d_ctx));
-  HIP_TRY(lin_wgrad(c, l.s_out, gy, sv.ctx_s, M));
+  HIP_TRY(lin_wgrad_queued(c, q, l.s_out, gy, sv.ctx_s, M));
   {
     SfAttnBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.qkv = sv.sqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_s; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide;
+    a.qkv = sv.sqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_s; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide_s;
     a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = N; a.nseq = F; a.seq_rows = 1; a.causal = 0;
     a.lse2 = sv.lse_s;
     HIP_TRY(sf_launch_spatial_attention_bwd(a, s));
   }
-  HIP_TRY(lin_wgrad(c, l.s_qkv, ws.d_wide, sv.ln_b, M));
-  HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
-  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln_bf, 1, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
+  HIP_TRY(lin_wgrad_queued(c, q, l.s_qkv, ws.d_wide_s, sv.ln_b, M));
+  HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide_s, M, s, nullptr, ws.d_ln_bf));
+  HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln_bf, 1, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf2, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- temporal: h1 = h + tanh(gate) * dense(out(attn(qkv(LN_t(h))))) ----------------------------------------
-  HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
-  {
-    // unscaled G = g^T t_out and column sums -> dW, db, dgate (see sf_launch_gate_grad)
+  HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf2, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
+  // unscaled G = g^T t_out and column sums -> dW, db, dgate (see sf_launch_gate_grad, after the grouped launch)
+  HIP_TRY(hipMemsetAsync(ws.cs, 0, (size_t)D * sizeof(float), s));
+  const bool dense_queued = q.on && sf_wgrad_groupable(M, D, D) && q.g.njobs < SF_WG_MAX_JOBS;
+  if (dense_queued) {
+    SfWgradJob& J = q.g.job[q.g.njobs++];
+    memset(&J, 0, sizeof(J));
+    J.dy = ws.g_bf2; J.x = sv.t_out; J.ldy = D; J.ldx = D; J.N1 = D; J.N2 = D; J.ldo = D; J.alpha = 1.f; J.accumulate = 0;
+    J.out = ws.dw_scratch; J.dbias = ws.cs;
+  } else {
     SfWgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.dy = ws.g_bf; a.ldy = D; a.x = sv.t_out; a.ldx = D; a.M = M; a.N1 = D; a.N2 = D; a.ldo = D; a.alpha = 1.f;
+    a.dy = ws.g_bf2; a.ldy = D; a.x = sv.t_out; a.ldx = D; a.M = M; a.N1 = D; a.N2 = D; a.ldo = D; a.alpha = 1.f;
     a.partial = ws.wg_partial; a.out = ws.dw_scratch; a.accumulate = 0;
-    HIP_TRY(hipMemsetAsync(ws.cs, 0, (size_t)D * sizeof(float), s));
     a.dbias = ws.cs; a.dbias_scratch = ws.cs_partial;
     HIP_TRY(sf_launch_wgrad(a, s));
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
@@ -750,17 +789,21 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   }
   if (dp) HIP_TRY(sf_launch_rowscale_bf16(ws.d_tout, ws.d_tout, dp, M, D, 0, T, N, s));     // through the drop_path in front of temporal_dense
   HIP_TRY(lin_dgrad(l.t_out, ws.d_tout, M, s, nullptr, ws.d_ctx));
-  HIP_TRY(lin_wgrad(c, l.t_out, ws.d_tout, sv.ctx_t, M));
+  HIP_TRY(lin_wgrad_queued(c, q, l.t_out, ws.d_tout, sv.ctx_t, M));
   {
     SfAttnBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.qkv = sv.tqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_t; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide;
+    a.qkv = sv.tqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_t; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide_t;
     a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = T; a.nseq = B * N; a.seq_rows = N;
     a.causal = t->cfg.enable_causal_temporal;
     HIP_TRY(sf_launch_temporal_attention_bwd(a, s));
   }
-  HIP_TRY(lin_wgrad(c, l.t_qkv, ws.d_wide, sv.ln_t, M));
-  HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
+  HIP_TRY(lin_wgrad_queued(c, q, l.t_qkv, ws.d_wide_t, sv.ln_t, M));
+  HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide_t, M, s, nullptr, ws.d_ln_bf));
+  if (q.g.njobs > 0) HIP_TRY(sf_launch_wgrad_group(q.g, s));
+  if (dense_queued)
+    HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
+                                GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln_bf, 1, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
                            ws.ln_partial, M, D, eps, s));
   return SF_OK;

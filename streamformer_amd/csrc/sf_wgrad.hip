@@ -14,6 +14,7 @@
 // The M range is split across workgroups (fp32 partial tiles) and reduced in a fixed order.
 #include "sf_train.h"
 #include <cstdlib>
+#include <cstring>
 
 #define WG_T 128          // tile edge (both N1 and N2)
 #define WG_KM 64          // token rows per K-step
@@ -147,20 +148,31 @@ SF_DEVICE bf16x8_t wb_frag(const char* tile, int ks, int cb, int lane) {
   return f;
 }
 
-__global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradArgs p, int tiles2, int ntiles, int kt_per, int kt_total,
-                                                                 float* bias_partial) {
+__global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradGroup G, int ntiles, int nsplit, int per_xcd, int kt_per,
+                                                                 int kt_total, unsigned part_stride, unsigned bias_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
-  const int t1 = tile / tiles2, t2 = tile % tiles2;
+  // work item = (split, job, t1, t2), t2 fastest; an XCD (blockIdx % 8) takes a run of consecutive items, so the tiles that
+  // share its L2 read the same token rows of the same dY / X column panels
+  const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per_xcd || item >= ntiles * nsplit) return;
+  const int tile = item % ntiles, split = item / ntiles;
+  int ji = 0;
+#pragma unroll
+  for (int j = 1; j < SF_WG_MAX_JOBS; ++j)
+    if (j < G.njobs && tile >= G.job[j].tile0) ji = j;
+  const SfWgradJob& J = G.job[ji];
+  const int lt = tile - J.tile0;
+  const int t1 = lt / J.tiles2, t2 = lt % J.tiles2;
   const int n1_0 = t1 * WB_T, n2_0 = t2 * WB_T;
   const int kt0 = split * kt_per;
   const int kt1 = min(kt_total, kt0 + kt_per);
-  const bool do_bias = bias_partial != nullptr && t2 == 0;
+  const bool do_bias = J.dbias != nullptr && t2 == 0;
+  const int ldy = J.ldy, ldx = J.ldx;
 
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)p.M * (unsigned)p.ldy * 2u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.M * (unsigned)p.ldx * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)J.dy, 0, (unsigned)G.M * (unsigned)ldy * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)J.x, 0, (unsigned)G.M * (unsigned)ldx * 2u, 0x00020000);
   // 4 rounds x 16 rows per operand; LDS position p of row r holds source chunk p ^ ((r & 7) << 1)
   unsigned offa[4], offb[4];
 #pragma unroll
@@ -168,17 +180,17 @@ __global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradArgs p, 
     const int c = r * WB_THREADS + tid;
     const int row = c >> 5, pos = c & 31;
     const int src = pos ^ ((row & 7) << 1);
-    offa[r] = ((unsigned)row * (unsigned)p.ldy + (unsigned)(n1_0 + src * 8)) * 2u;
-    offb[r] = ((unsigned)row * (unsigned)p.ldx + (unsigned)(n2_0 + src * 8)) * 2u;
+    offa[r] = ((unsigned)row * (unsigned)ldy + (unsigned)(n1_0 + src * 8)) * 2u;
+    offb[r] = ((unsigned)row * (unsigned)ldx + (unsigned)(n2_0 + src * 8)) * 2u;
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * 2 * WB_TILE_BYTES + wave * 1024;
-    const unsigned soa = (unsigned)kt * WG_KM * (unsigned)p.ldy * 2u;
-    const unsigned sob = (unsigned)kt * WG_KM * (unsigned)p.ldx * 2u;
+    const unsigned soa = (unsigned)kt * WG_KM * (unsigned)ldy * 2u;
+    const unsigned sob = (unsigned)kt * WG_KM * (unsigned)ldx * 2u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(base + r * 8192), 16, offa[r], soa, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + WB_TILE_BYTES + r * 8192), 16, offb[r], sob, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(base + r * 8192), 16, (int)offa[r], soa, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + WB_TILE_BYTES + r * 8192), 16, (int)offb[r], sob, 0, 0);
     }
   };
 
@@ -221,40 +233,106 @@ __global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradArgs p, 
     }
   }
 
-  float* part = p.partial + (size_t)split * p.N1 * p.N2;
   const int l15 = lane & 15, g = lane >> 4;
+  if (nsplit == 1) {            // the workgroup saw every token row: write the gradient itself
+    const float alpha = J.alpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n1 = n1_0 + wr * 128 + i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n2 = n2_0 + wc * 64 + j * 16 + g * 4;
+        f32x4_t* dst = reinterpret_cast<f32x4_t*>(J.out + (size_t)n1 * J.ldo + n2);
+        f32x4_t o = acc[i][j] * alpha;
+        if (J.accumulate) o += *dst;
+        *dst = o;
+      }
+    }
+    if (do_bias && g == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) J.dbias[n1_0 + wr * 128 + (wc * 2 + q) * 16 + l15] += alpha * accb[q][0];
+    }
+    return;
+  }
+  float* part = G.partial + (size_t)split * part_stride + J.part_off;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int n1 = n1_0 + wr * 128 + i * 16 + l15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n2 = n2_0 + wc * 64 + j * 16 + g * 4;
-      *reinterpret_cast<f32x4_t*>(part + (size_t)n1 * p.N2 + n2) = acc[i][j];
+      *reinterpret_cast<f32x4_t*>(part + (size_t)n1 * J.N2 + n2) = acc[i][j];
     }
   }
   if (do_bias && g == 0) {
+    float* bp = G.partial + (size_t)nsplit * part_stride + (size_t)split * bias_stride + J.bias_off;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) bias_partial[(size_t)split * p.N1 + n1_0 + wr * 128 + (wc * 2 + q) * 16 + l15] = accb[q][0];
+    for (int q = 0; q < 2; ++q) bp[n1_0 + wr * 128 + (wc * 2 + q) * 16 + l15] = accb[q][0];
   }
 }
 
-// out (+)= alpha * sum_s partial[s]; the trailing workgroups of the same launch reduce the bias partials
-// (dbias[n1] += alpha * sum_s bias_partial[s][n1]) when the tile kernel produced them
-__global__ __launch_bounds__(256) void sf_wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t n12, int N2,
-                                                              float alpha, float* out, int ldo, int accumulate, int main_blocks,
-                                                              const float* __restrict__ bias_partial, int N1, float* dbias) {
+// out (+)= alpha * sum_s partial[s] for every job of the group, in split order (deterministic); one block = 1024 consecutive
+// floats of one job (N1 * N2 is a multiple of 65 536).  Trailing blocks reduce the bias partials, 256 entries each.
+__global__ __launch_bounds__(256) void sf_wgrad_group_reduce_kernel(SfWgradGroup G, int nsplit, unsigned part_stride, unsigned bias_stride,
+                                                                    int main_blocks) {
   if ((int)blockIdx.x >= main_blocks) {
-    const int n = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
-    if (n >= N1) return;
+    const unsigned n = ((unsigned)blockIdx.x - (unsigned)main_blocks) * 256u + threadIdx.x;      // position in the bias block
+    if (n >= bias_stride) return;
+    int ji = 0;
+#pragma unroll
+    for (int j = 1; j < SF_WG_MAX_JOBS; ++j)
+      if (j < G.njobs && n >= G.job[j].bias_off) ji = j;
+    const SfWgradJob& J = G.job[ji];
+    if (!J.dbias) return;
+    const float* bp = G.partial + (size_t)nsplit * part_stride + n;
     float t = 0.f;
-    for (int s = 0; s < nsplit; ++s) t += bias_partial[(size_t)s * N1 + n];
-    dbias[n] += alpha * t;
+    for (int s = 0; s < nsplit; ++s) t += bp[(size_t)s * bias_stride];
+    J.dbias[n - J.bias_off] += J.alpha * t;
     return;
   }
-  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i4 * 4 >= n12) return;
+  const unsigned e = ((unsigned)blockIdx.x * 256u + threadIdx.x) * 4u;       // float position in one split's block
+  int ji = 0;
+#pragma unroll
+  for (int j = 1; j < SF_WG_MAX_JOBS; ++j)
+    if (j < G.njobs && e >= G.job[j].part_off) ji = j;
+  const SfWgradJob& J = G.job[ji];
+  const float* pp = G.partial + e;
   f32x4_t t = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < nsplit; ++s) t += *reinterpret_cast<const f32x4_t*>(partial + (size_t)s * n12 + i4 * 4);
+  for (int s = 0; s < nsplit; ++s) t += *reinterpret_cast<const f32x4_t*>(pp + (size_t)s * part_stride);
+  const unsigned le = e - J.part_off;
+  const unsigned n1 = le / (unsigned)J.N2, n2 = le % (unsigned)J.N2;
+  f32x4_t* dst = reinterpret_cast<f32x4_t*>(J.out + (size_t)n1 * J.ldo + n2);
+  f32x4_t o = t * J.alpha;
+  if (J.accumulate) o += *dst;
+  *dst = o;
+}
+
+// out (+)= alpha * sum_s partial[s] (128^2 path).  The outputs of this path are small (LoRA factors, head projections) and the
+// split count large (up to 98), so a block covers 64 float4 positions x 4 split lanes: lane q adds splits q, q+4, ... and the
+// four lane sums are combined in a fixed order through LDS — 4x the workgroups and a quarter of the dependent loads.
+__global__ __launch_bounds__(256) void sf_wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t n12, int N2,
+                                                              float alpha, float* out, int ldo, int accumulate) {
+  __shared__ f32x4_t red[4][64];
+  const int pos = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t i4 = (size_t)blockIdx.x * 64 + pos;
+  const bool in = i4 * 4 < n12;
+  f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    const float* pp = partial + i4 * 4;
+    int sidx = q;
+    for (; sidx + 12 < nsplit; sidx += 16) {       // four independent loads in flight
+      const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(pp + (size_t)sidx * n12);
+      const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(pp + (size_t)(sidx + 4) * n12);
+      const f32x4_t a2 = *reinterpret_cast<const f32x4_t*>(pp + (size_t)(sidx + 8) * n12);
+      const f32x4_t a3 = *reinterpret_cast<const f32x4_t*>(pp + (size_t)(sidx + 12) * n12);
+      t += a0; t += a1; t += a2; t += a3;
+    }
+    for (; sidx < nsplit; sidx += 4) t += *reinterpret_cast<const f32x4_t*>(pp + (size_t)sidx * n12);
+  }
+  red[q][pos] = t;
+  __syncthreads();
+  if (q != 0 || !in) return;
+  t = ((red[0][pos] + red[1][pos]) + red[2][pos]) + red[3][pos];
   const size_t n1 = (i4 * 4) / N2, n2 = (i4 * 4) % N2;
   f32x4_t* dst = reinterpret_cast<f32x4_t*>(out + n1 * ldo + n2);
   f32x4_t o = t * alpha;
@@ -262,7 +340,6 @@ __global__ __launch_bounds__(256) void sf_wgrad_reduce_kernel(const float* __res
   *dst = o;
 }
 
-struct WgPlan { int big, tiles1, tiles2, ntiles, kt_total, kt_per, nsplit; };
 static int wg_cus() {
   static int cus = 0;
   if (!cus) {
@@ -273,16 +350,76 @@ static int wg_cus() {
   }
   return cus;
 }
-static WgPlan wg_plan(int M, int N1, int N2) {
+
+// ---- grouped 256^2 launches ----------------------------------------------------------------------------------------------
+// split count of a group of `ntiles` tiles over kt K-steps: rounds x (K-steps per workgroup + the tile write) + the reduce
+// pass, in K-step units (a K-step is ~2.4 us, a 256 KB partial write ~6 of them, reducing one split of one tile ~0.03)
+static int wgg_nsplit(int ntiles, int kt) {
+  if (const char* f = getenv("SF_WGRAD_NSPLIT")) { const int s = atoi(f); return s < 1 ? 1 : s; }     // lab: tools/wgrad_lab.py
+  const int cus = wg_cus();
+  int best = 1;
+  double best_cost = 1e30;
+  const int smax = kt / 4 < 1 ? 1 : (kt / 4 > 64 ? 64 : kt / 4);
+  for (int s = 1; s <= smax; ++s) {
+    const int per = (kt + s - 1) / s;
+    if ((kt + per - 1) / per != s) continue;          // same split count after rounding
+    const int rounds = (ntiles * s + cus - 1) / cus;
+    const double cost = (double)rounds * (per + 6.0) + (s > 1 ? 0.03 * s * ntiles : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+bool sf_wgrad_groupable(int M, int N1, int N2) {
+  return N1 > 0 && N2 > 0 && (N1 % WB_T == 0) && (N2 % WB_T == 0) && (M + WG_KM - 1) / WG_KM >= 32 && !getenv("SF_WGRAD_SMALL_TILES");
+}
+size_t sf_wgrad_group_partial_floats(int M, int ntiles, int sum_n1) {
+  const int kt = (M + WG_KM - 1) / WG_KM;
+  return (size_t)wgg_nsplit(ntiles, kt) * ((size_t)ntiles * WB_T * WB_T + (size_t)sum_n1);
+}
+
+hipError_t sf_launch_wgrad_group(SfWgradGroup& g, hipStream_t s) {
+  if (g.njobs <= 0 || g.njobs > SF_WG_MAX_JOBS || g.M <= 0 || !g.partial) return hipErrorInvalidValue;
+  int ntiles = 0;
+  size_t part = 0, bias = 0;
+  for (int j = 0; j < g.njobs; ++j) {
+    SfWgradJob& J = g.job[j];
+    if (!sf_wgrad_groupable(g.M, J.N1, J.N2) || !J.dy || !J.x || !J.out) return hipErrorInvalidValue;
+    if ((J.ldy % 8) || (J.ldx % 8) || (J.ldo % 4)) return hipErrorInvalidValue;
+    if ((size_t)g.M * J.ldy * 2 >= ((size_t)1 << 32) || (size_t)g.M * J.ldx * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+    J.tile0 = ntiles; J.tiles2 = J.N2 / WB_T;
+    J.part_off = (unsigned)part; J.bias_off = (unsigned)bias;
+    ntiles += (J.N1 / WB_T) * J.tiles2;
+    part += (size_t)J.N1 * J.N2; bias += (size_t)J.N1;
+  }
+  if (part >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+  const int kt_total = (g.M + WG_KM - 1) / WG_KM;
+  int nsplit = wgg_nsplit(ntiles, kt_total);
+  const int kt_per = (kt_total + nsplit - 1) / nsplit;
+  nsplit = (kt_total + kt_per - 1) / kt_per;
+  const int items = ntiles * nsplit;
+  const int per_xcd = (items + 7) / 8;
+  static SfPerDeviceOnce attr_set;
+  if (attr_set.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_wgrad256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_TILE_BYTES);
+  hipLaunchKernelGGL(sf_wgrad256_kernel, dim3(per_xcd * 8), dim3(WB_THREADS), 4 * WB_TILE_BYTES, s, g, ntiles, nsplit, per_xcd, kt_per, kt_total,
+                     (unsigned)part, (unsigned)bias);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || nsplit == 1) return e;
+  const int main_blocks = (int)(part / 1024);
+  const int bias_blocks = (int)((bias + 255) / 256);
+  hipLaunchKernelGGL(sf_wgrad_group_reduce_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, g, nsplit, (unsigned)part, (unsigned)bias,
+                     main_blocks);
+  return hipGetLastError();
+}
+
+struct WgPlan { int tiles1, tiles2, ntiles, kt_total, kt_per, nsplit; };
+static WgPlan wg_plan(int M, int N1, int N2) {       // 128^2 tiles: ~2 rounds of 2 workgroups per CU
   WgPlan pl;
   pl.kt_total = (M + WG_KM - 1) / WG_KM;
-  pl.big = (N1 % WB_T == 0) && (N2 % WB_T == 0) && pl.kt_total >= 32 && !getenv("SF_WGRAD_SMALL_TILES");
-  const int T = pl.big ? WB_T : WG_T;
-  pl.tiles1 = (N1 + T - 1) / T;
-  pl.tiles2 = (N2 + T - 1) / T;
+  pl.tiles1 = (N1 + WG_T - 1) / WG_T;
+  pl.tiles2 = (N2 + WG_T - 1) / WG_T;
   pl.ntiles = pl.tiles1 * pl.tiles2;
-  // 128^2: ~2 rounds of 2 workgroups per CU; 256^2: one workgroup per CU, one round
-  int s = pl.big ? wg_cus() / pl.ntiles : (1024 + pl.ntiles - 1) / pl.ntiles;
+  int s = (1024 + pl.ntiles - 1) / pl.ntiles;
   if (s > pl.kt_total / 4) s = pl.kt_total / 4;        // at least 4 K-steps per workgroup
   if (s < 1) s = 1;
   pl.kt_per = (pl.kt_total + s - 1) / s;
@@ -291,43 +428,40 @@ static WgPlan wg_plan(int M, int N1, int N2) {
 }
 
 size_t sf_wgrad_partial_floats(int M, int N1, int N2) {
+  if (sf_wgrad_groupable(M, N1, N2)) return sf_wgrad_group_partial_floats(M, (N1 / WB_T) * (N2 / WB_T), N1);
   const WgPlan pl = wg_plan(M, N1, N2);
-  return (size_t)pl.nsplit * N1 * N2 + (size_t)pl.nsplit * N1;     // + bias partials
+  return (size_t)pl.nsplit * N1 * N2;
 }
 
 hipError_t sf_launch_wgrad(const SfWgradArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N1 <= 0 || a.N2 <= 0) return hipErrorInvalidValue;
   if ((a.ldy % 8) || (a.ldx % 8) || (a.N2 % 4) || (a.ldo % 4)) return hipErrorInvalidValue;
   if ((size_t)a.M * a.ldy * 2 >= ((size_t)1 << 32) || (size_t)a.M * a.ldx * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+  if (a.out && sf_wgrad_groupable(a.M, a.N1, a.N2)) {      // a group of one
+    SfWgradGroup g;
+    memset(&g, 0, sizeof(g));
+    g.njobs = 1; g.M = a.M; g.partial = a.partial;
+    SfWgradJob& J = g.job[0];
+    J.dy = a.dy; J.x = a.x; J.out = a.out; J.dbias = a.dbias; J.ldy = a.ldy; J.ldx = a.ldx; J.N1 = a.N1; J.N2 = a.N2; J.ldo = a.ldo;
+    J.accumulate = a.accumulate; J.alpha = a.alpha;
+    return sf_launch_wgrad_group(g, s);
+  }
   const WgPlan pl = wg_plan(a.M, a.N1, a.N2);
   const size_t n12 = (size_t)a.N1 * a.N2;
-  float* bias_partial = a.partial + (size_t)pl.nsplit * n12;
   static SfPerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (attr_set.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_wgrad256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WB_TILE_BYTES);
-  }
-  bool bias_done = false;
-  if (pl.big) {
-    hipLaunchKernelGGL(sf_wgrad256_kernel, dim3(pl.ntiles * pl.nsplit), dim3(WB_THREADS), 4 * WB_TILE_BYTES, s, a, pl.tiles2, pl.ntiles,
-                       pl.kt_per, pl.kt_total, a.dbias ? bias_partial : nullptr);
-    bias_done = a.dbias != nullptr;
-  } else {
-    hipLaunchKernelGGL(sf_wgrad_kernel, dim3(pl.ntiles * pl.nsplit), dim3(WG_THREADS), 4 * WG_TILE_BYTES, s, a, pl.tiles2, pl.ntiles,
-                       pl.kt_per, pl.kt_total);
-  }
+  hipLaunchKernelGGL(sf_wgrad_kernel, dim3(pl.ntiles * pl.nsplit), dim3(WG_THREADS), 4 * WG_TILE_BYTES, s, a, pl.tiles2, pl.ntiles,
+                     pl.kt_per, pl.kt_total);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  {
-    const int main_blocks = a.out ? (int)((n12 / 4 + 255) / 256) : 0;
-    const int bias_blocks = bias_done ? (a.N1 + 255) / 256 : 0;
-    if (main_blocks + bias_blocks > 0)
-      hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3((unsigned)(main_blocks + bias_blocks)), dim3(256), 0, s, a.partial, pl.nsplit, n12, a.N2,
-                         a.alpha, a.out, a.ldo, a.accumulate, main_blocks, bias_partial, a.N1, a.dbias);
+  if (a.out) {
+    hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3((unsigned)((n12 / 4 + 63) / 64)), dim3(256), 0, s, a.partial, pl.nsplit, n12, a.N2,
+                       a.alpha, a.out, a.ldo, a.accumulate);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (a.dbias && !bias_done)      // small-tile path: separate column-sum kernel (scratch after the tile partials)
+  if (a.dbias)      // small-tile path: separate column-sum kernel
     e = sf_launch_colsum_bf16(a.dy, a.M, a.N1, a.ldy, a.alpha, a.dbias, 1, a.dbias_scratch, s);
   return e;
 }
