@@ -19,6 +19,7 @@
 // Spatial: one 8-wave workgroup per (frame, head), L <= 224.  Temporal: one WAVE per (batch, patch,
 // head) sequence with wave-private images, L <= 32.
 #include "sf_train.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
@@ -318,12 +319,106 @@ SF_DEVICE void stage_do_delta(char* img, float* delta, const bf16_t* d_o, const 
   }
 }
 
+// ---- 16-row owners (spatial kernel): the same products with one 16-key tile (phase B) or one 16-query tile (phase C) per
+// wave, so that 13 of 16 waves (L = 196) work instead of 7 of 8 and every SIMD has four waves to hide the
+// LDS -> MFMA -> exp2 -> MFMA chain behind.  The contraction over tokens still runs 32 rows per MFMA.
+SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb, f32x4_t (&dk)[4], f32x4_t (&dv)[4], int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16x8_t kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = row_frag(w.k, jt * 16 + l15, ks * 4 + g);
+    vf[ks] = row_frag(w.v, jt * 16 + l15, ks * 4 + g);
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dk[b] = dv[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int kj = jt * 16 + l15;
+  const int ib0 = w.causal ? (jt >> 1) : 0;
+  for (int ib = ib0; ib < nb; ++ib) {
+    f32x4_t p[2], ds[2];                   // [query tile]
+#pragma unroll
+    for (int it2 = 0; it2 < 2; ++it2) {
+      const int q0 = ib * 32 + it2 * 16;
+      f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        sc = ab_mfma(row_frag(w.q, q0 + l15, ks * 4 + g), kf[ks], sc);
+        dp = ab_mfma(row_frag(w.d_o, q0 + l15, ks * 4 + g), vf[ks], dp);
+      }
+      const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(w.lse2 + q0 + 4 * g);
+      const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(w.delta + q0 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + 4 * g + r;
+        const bool ok = kj < w.L && !(w.causal && kj > qi);
+        const float pv = ok ? __builtin_amdgcn_exp2f(sc[r] * w.sl2 - lse[r]) : 0.f;
+        p[it2][r] = pv;
+        ds[it2][r] = pv * (dp[r] - dl[r]) * w.scale;
+      }
+    }
+    const bf16x8_t pa = pack_a(p[0], p[1]), dsa = pack_a(ds[0], ds[1]);
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      dv[et] = ab_mfma(pa, tr_frag<true>(w.d_o, ib * 32, et, lane), dv[et]);
+      dk[et] = ab_mfma(dsa, tr_frag<true>(w.q, ib * 32, et, lane), dk[et]);
+    }
+  }
+}
+
+SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb, f32x4_t (&dq)[4], int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16x8_t qf[2], gf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = row_frag(w.q, it * 16 + l15, ks * 4 + g);
+    gf[ks] = row_frag(w.d_o, it * 16 + l15, ks * 4 + g);
+  }
+  const int qi = it * 16 + l15;
+  const float lse = w.lse2[qi], dl = w.delta[qi];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dq[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int jb1 = w.causal ? (it >> 1) + 1 : nb;
+  for (int jb = 0; jb < jb1; ++jb) {
+    f32x4_t ds[2];                          // [key tile]
+#pragma unroll
+    for (int jt2 = 0; jt2 < 2; ++jt2) {
+      const int k0 = jb * 32 + jt2 * 16;
+      f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        sc = ab_mfma(row_frag(w.k, k0 + l15, ks * 4 + g), qf[ks], sc);
+        dp = ab_mfma(row_frag(w.v, k0 + l15, ks * 4 + g), gf[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = k0 + 4 * g + r;
+        const bool ok = kj < w.L && !(w.causal && kj > qi);
+        const float pv = ok ? __builtin_amdgcn_exp2f(sc[r] * w.sl2 - lse) : 0.f;
+        ds[jt2][r] = pv * (dp[r] - dl) * w.scale;
+      }
+    }
+    const bf16x8_t dsa = pack_a(ds[0], ds[1]);
+#pragma unroll
+    for (int et = 0; et < 4; ++et) dq[et] = ab_mfma(dsa, tr_frag<true>(w.k, jb * 32, et, lane), dq[et]);
+  }
+}
+
+SF_DEVICE void tile16_to_patch(char* patch, const f32x4_t (&t)[4], int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int et = 0; et < 4; ++et)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store_patch(patch, 4 * g + r, et * 16 + l15, t[et][r]);
+}
+
 // ------------------------------------------------------------------------------------------------
-// spatial: one workgroup (8 waves) per (frame, head)
+// spatial: one workgroup (16 waves) per (frame, head)
 // ------------------------------------------------------------------------------------------------
-#define SB_THREADS 512
+#define SB_THREADS 1024
+#define SB_WAVES 16
 #define SB_ROWS 224
 #define SB_IMG (SB_ROWS * 128)
+#define SB_PATCH 2048
 
 __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,7 +433,7 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   char* ig = smem + 3 * SB_IMG;
   float* lse2 = reinterpret_cast<float*>(smem + 4 * SB_IMG);
   float* delta = lse2 + SB_ROWS;
-  char* patch = smem + 4 * SB_IMG + 2 * SB_ROWS * 4 + wave * 4096;
+  char* patch = smem + 4 * SB_IMG + 2 * SB_ROWS * 4 + wave * SB_PATCH;
 
   const long row_base = (long)f * L;
   const bf16_t* qkv = a.qkv + h * 64;
@@ -355,36 +450,41 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   if (a.lse2) {       // statistics saved by the forward kernel: padding queries get +big so that p = 0
     for (int i = tid; i < rows_pad; i += SB_THREADS) lse2[i] = i < L ? a.lse2[((size_t)f * a.heads + h) * L + i] : -NEG_BIG;
   } else {
-    for (int it = wave; it < 2 * nb; it += 8) phase_a_tile<true>(w, it, nt, lane);
+    for (int it = wave; it < 2 * nb; it += SB_WAVES) phase_a_tile<true>(w, it, nt, lane);
   }
   __syncthreads();
 
   bf16_t* dqkv = a.d_qkv + h * 64;
-  for (int jb = wave; jb < nb; jb += 8) {
-    f32x4_t dk[2][4], dv[2][4];
-    phase_b_block<true>(w, jb, nb, dk, dv, lane);
-    tiles_to_patch<true>(patch, dk, lane);
-    patch_to_global(patch, dqkv + a.D, a.ld_qkv, row_base, 1, jb * 32, L, 32, lane);
-    tiles_to_patch<true>(patch, dv, lane);
-    patch_to_global(patch, dqkv + 2 * a.D, a.ld_qkv, row_base, 1, jb * 32, L, 32, lane);
+  for (int jt = wave; jt < nt && !(a.lab & 1); jt += SB_WAVES) {
+    f32x4_t dk[4], dv[4];
+    phase_b_tile16(w, jt, nb, dk, dv, lane);
+    if ((a.lab & 4) && dk[0][0] + dv[0][0] != 12345.f) continue;
+    tile16_to_patch(patch, dk, lane);
+    patch_to_global(patch, dqkv + a.D, a.ld_qkv, row_base, 1, jt * 16, L, 16, lane);
+    tile16_to_patch(patch, dv, lane);
+    patch_to_global(patch, dqkv + 2 * a.D, a.ld_qkv, row_base, 1, jt * 16, L, 16, lane);
   }
-  for (int ib = wave; ib < nb; ib += 8) {
-    f32x4_t dq[2][4];
-    phase_c_block<true>(w, ib, nb, dq, lane);
-    tiles_to_patch<true>(patch, dq, lane);
-    patch_to_global(patch, dqkv, a.ld_qkv, row_base, 1, ib * 32, L, 32, lane);
+  for (int it = wave; it < nt && !(a.lab & 2); it += SB_WAVES) {
+    f32x4_t dq[4];
+    phase_c_tile16(w, it, nb, dq, lane);
+    if ((a.lab & 4) && dq[0][0] != 12345.f) continue;
+    tile16_to_patch(patch, dq, lane);
+    patch_to_global(patch, dqkv, a.ld_qkv, row_base, 1, it * 16, L, 16, lane);
   }
 }
 
 hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s) {
   if (a.L <= 0 || a.L > SB_ROWS || a.nseq <= 0 || a.D != a.heads * 64) return hipErrorInvalidValue;
   if ((a.ld_qkv % 8) || (a.ld_o % 8)) return hipErrorInvalidValue;
-  const size_t lds = 4 * SB_IMG + 2 * SB_ROWS * 4 + 8 * 4096;
+  const size_t lds = 4 * SB_IMG + 2 * SB_ROWS * 4 + SB_WAVES * SB_PATCH;
   static SfPerDeviceOnce attr_set;
   if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, a);
+  static const int lab = getenv("SF_ATTN_BWD_LAB") ? atoi(getenv("SF_ATTN_BWD_LAB")) : 0;
+  SfAttnBwdArgs b = a;
+  b.lab = lab;
+  hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, b);
   return hipGetLastError();
 }
 

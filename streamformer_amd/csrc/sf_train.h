@@ -62,6 +62,7 @@ struct SfAttnBwdArgs {
   int causal;
   const float* lse2;               // spatial, optional: [nseq, heads, L] log-sum-exp (base 2) saved by the forward kernel;
                                    // without it the backward recomputes the row statistics (phase A)
+  int lab;                         // timing lab (SF_ATTN_BWD_LAB): 1 no phase B, 2 no phase C, 4 no output stores
 };
 hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);    // L <= 224
 hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);   // L <= 32
