@@ -64,9 +64,10 @@ import os, sys, json, torch
 sys.path.insert(0, os.environ["SF_ROOT"])
 import streamformer_amd as sa
 from streamformer_amd.training import StreamformerTrainer
-cfg = sa.siglip_base(add_lora_spatial=True)
-sd = sa.make_state_dict(cfg, seed=3, lora=True)
-tr = StreamformerTrainer(cfg, sd, ["localization"], freeze_spatial=True, device="cuda:0")
+lora = os.environ.get("SF_PROBE_LORA", "1") == "1"
+cfg = sa.siglip_base(add_lora_spatial=lora)
+sd = sa.make_state_dict(cfg, seed=3, lora=lora)
+tr = StreamformerTrainer(cfg, sd, ["localization"], freeze_spatial=lora, device="cuda:0")
 g = torch.Generator().manual_seed(11)
 x = torch.randn(1, 16, 3, 224, 224, generator=g).cuda()
 lab = torch.randn(7, cfg.hidden_size, generator=g); lab = (lab / lab.norm(dim=-1, keepdim=True)).cuda()
@@ -76,7 +77,12 @@ loss, gp, gs = tr.loss_and_grad("localization", pooler, {"kind": "localization",
 tr.backward(gp)
 torch.cuda.synchronize()
 names = ["encoder.layer.0.temporal_attention.attention.qkv.weight", "encoder.layer.5.intermediate.dense.weight",
-         "encoder.layer.11.output.dense.weight", "encoder.layer.3.attention.attention.qkv_lora_b.weight", "embeddings.position_embeddings"]
+         "encoder.layer.11.output.dense.weight", "encoder.layer.11.output.dense.bias", "encoder.layer.7.temporal_dense.weight",
+         "encoder.layer.7.temporal_dense.bias", "encoder.layer.7.temporal_attention_gating", "encoder.layer.2.temporal_attention.output.dense.weight",
+         "encoder.layer.2.temporal_attention.attention.qkv.bias", "embeddings.position_embeddings"]
+names += (["encoder.layer.3.attention.attention.qkv_lora_b.weight"] if lora else
+          ["encoder.layer.3.attention.attention.qkv.weight", "encoder.layer.3.attention.output.dense.weight",
+           "encoder.layer.3.attention.output.dense.bias"])
 out = {"loss": float(loss), "pooler": pooler.double().norm().item()}
 torch.save({n: tr.grad(n).cpu() for n in names}, os.environ["SF_OUT"])
 print("RESULT " + json.dumps(out))
@@ -106,3 +112,31 @@ def test_training_step_of_one_clip_is_the_same_on_the_tile_kernels(tmp_path):
     for n in a[1]:
         rel = float((a[1][n].double() - b[1][n].double()).norm() / (b[1][n].double().norm() + 1e-30))
         assert rel < 2e-2, (n, rel)
+
+
+@pytest.mark.parametrize("lora", [True, False])
+def test_grouped_weight_gradients_equal_the_per_projection_launches(tmp_path, lora):
+    """backward_layer batches the weight gradients of a layer's Linears into one launch (sf_launch_wgrad_group: shared tile
+    numbering, partial and bias offsets per job).  SF_WGRAD_UNGROUPED=1 launches every projection by itself; both must give
+    the same gradients up to the order of the token-split sums — with LoRA on the frozen spatial block (5 jobs per layer)
+    and with every Linear trained (7 jobs)."""
+    import json
+    import torch
+    res = {}
+    for tag, off in (("grouped", False), ("single", True)):
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        env["SF_ROOT"] = ROOT
+        env["SF_OUT"] = str(tmp_path / f"{tag}.pt")
+        env["SF_PROBE_LORA"] = "1" if lora else "0"
+        if off:
+            env["SF_WGRAD_UNGROUPED"] = "1"
+        r = subprocess.run([sys.executable, "-c", TRAIN_PROBE], env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0]
+        res[tag] = (json.loads(line[7:]), torch.load(env["SF_OUT"]))
+    a, b = res["grouped"], res["single"]
+    assert a[0]["loss"] == b[0]["loss"]            # the forward is the same code
+    for n in a[1]:
+        rel = float((a[1][n].double() - b[1][n].double()).norm() / (b[1][n].double().norm() + 1e-30))
+        assert rel < 1e-5, (n, rel)
