@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS) void sf_gemm_kernel(SfGemmArgs p) {
       } else {
         if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_fast(v[j], p.act);
+          for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_bf16(v[j], p.act);
         }
         unsigned int h[4], l[4];
 #pragma unroll

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
               v += bias4[nq][nt];
               if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act_fast(v[j], 0);   // erf-GELU only (launcher checks)
+                for (int j = 0; j < 4; ++j) v[j] = gelu_bf16(v[j]);   // erf-GELU only (launcher checks)
               }
               const u32x2_t hv = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
               *reinterpret_cast<u32x2_t*>(smem + r * 512 + ((((nl >> 3)) ^ (r & 31)) << 4) + (nl & 4) * 2) = hv;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
           if (EPI == G256_EPI_BF16_AUX && p.aux_mode == 1) {               // training forward: the GELU of the (bf16) pre-activation
             u32x4_t a;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = pack_bf2(gelu_fast(bf2f(v[j] & 0xffffu)), gelu_fast(bf2f(v[j] >> 16)));
+            for (int j = 0; j < 4; ++j) a[j] = pack_bf2(gelu_bf16(bf2f(v[j] & 0xffffu)), gelu_bf16(bf2f(v[j] >> 16)));
             *reinterpret_cast<u32x4_t*>(p.aux + o) = a;
           } else if (EPI == G256_EPI_BF16_AUX && p.aux_mode == 2) {        // training backward: d pre = d act * gelu'(pre)
             const u32x4_t a = *reinterpret_cast<const u32x4_t*>(p.aux + o);

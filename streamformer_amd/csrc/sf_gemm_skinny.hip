@@ -201,7 +201,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
     } else {
       if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_fast(v[j], p.act);
+        for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_bf16(v[j], p.act);
       }
       unsigned int h[4], l[4];
 #pragma unroll
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   } else {
     if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_fast(v[j], p.act);
+      for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_bf16(v[j], p.act);
     }
     unsigned int h[4], l[4];
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_mid_kernel(SfGemmArgs p) {
       } else {
         if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = apply_act_fast(v[q], p.act);
+          for (int q = 0; q < 4; ++q) v[q] = apply_act_bf16(v[q], p.act);
         }
         *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
       }

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
           v += bias4[j];
           if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act_fast(v[e], p.act);
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_bf16(v[e], p.act);
           }
           const int col = (wn * NT + j) * 16 + g * 4;
           if (F32OUT) *reinterpret_cast<f32x4_t*>(srow + col * 4) = v;
