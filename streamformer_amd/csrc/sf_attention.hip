@@ -1161,16 +1161,22 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
     for (int c = 0; c < QL; ++c) kv[kp][c] = *reinterpret_cast<const u32x4_t*>(kb + off + c * 16);
   }
   const int tsub = lane >> 3, ch = lane & 7;       // P V layout: key = 8 i + tsub, d = 8 ch .. 8 ch + 7
+  // fp32 rows with four key passes (the pooling head of the accurate mode: 196 keys): K alone is 256 VGPRs per lane, so the
+  // V chunks are requested after the scores have consumed the K rows (two latencies per task instead of 100 spilled VGPRs)
+  constexpr bool V_LATE = F32 && KP >= 4;
+  auto load_v = [&]() {
 #pragma unroll
-  for (int kp = 0; kp < KP; ++kp)
+    for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int key = kp * 64 + i * 8 + tsub;
-      key = key < Tk ? key : Tk - 1;
-      const size_t off = ((((size_t)b * p.Tcap + key) * p.N + n) * p.row_pitch_kv + h * HD + ch * 8) * ESZ;
-      vv[kp][i][0] = *reinterpret_cast<const u32x4_t*>(vb + off);
-      if (F32) vv[kp][i][F32 ? 1 : 0] = *reinterpret_cast<const u32x4_t*>(vb + off + 16);
-    }
+      for (int i = 0; i < 8; ++i) {
+        int key = kp * 64 + i * 8 + tsub;
+        key = key < Tk ? key : Tk - 1;
+        const size_t off = ((((size_t)b * p.Tcap + key) * p.N + n) * p.row_pitch_kv + h * HD + ch * 8) * ESZ;
+        vv[kp][i][0] = *reinterpret_cast<const u32x4_t*>(vb + off);
+        if (F32) vv[kp][i][F32 ? 1 : 0] = *reinterpret_cast<const u32x4_t*>(vb + off + 16);
+      }
+  };
+  if (!V_LATE) load_v();
   __builtin_amdgcn_sched_barrier(0);     // keep every load of the task ahead of the arithmetic (one latency per task)
 
   // ---- scores -----------------------------------------------------------------------------------------------------
@@ -1196,6 +1202,11 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
     const bool ok = key < Tk && (!p.causal || key <= qpos);
     sc[kp] = ok ? (a0 + a1) : -INFINITY;
     mx = fmaxf(mx, sc[kp]);
+  }
+  if (V_LATE) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_v();
+    __builtin_amdgcn_sched_barrier(0);
   }
   mx = wave_max_dpp(mx);
   const float c2 = p.scale * 1.44269504088896340736f;

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(WG_THREADS) void sf_wgrad_kernel(SfWgradArgs p, int
 // ------------------------------------------------------------------------------------------------
 #define WB_T 256
 #define WB_THREADS 512
+#define WB_KM 32                                  // token rows per stage
+#define WB_STAGE_BYTES (2 * WB_KM * WB_T * 2)     // dY tile | X tile: 32 KB
 #define WB_TILE_BYTES (WG_KM * WB_T * 2)   // 32 KB
 
 SF_DEVICE bf16x8_t wb_frag(const char* tile, int ks, int cb, int lane) {
@@ -148,9 +150,16 @@ SF_DEVICE bf16x8_t wb_frag(const char* tile, int ks, int cb, int lane) {
   return f;
 }
 
+SF_DEVICE bf16x8_t wb_join(s16x4_t lo, s16x4_t hi) {
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
 __global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradGroup G, int ntiles, int nsplit, int per_xcd, int kt_per,
                                                                  int kt_total, unsigned part_stride, unsigned bias_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 stages x (dY tile | X tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   // work item = (split, job, t1, t2), t2 fastest; an XCD (blockIdx % 8) takes a run of consecutive items, so the tiles that
@@ -173,24 +182,25 @@ __global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradGroup G,
 
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)J.dy, 0, (unsigned)G.M * (unsigned)ldy * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)J.x, 0, (unsigned)G.M * (unsigned)ldx * 2u, 0x00020000);
-  // 4 rounds x 16 rows per operand; LDS position p of row r holds source chunk p ^ ((r & 7) << 1)
-  unsigned offa[4], offb[4];
+  // A stage = 32 token rows of both operands ([32][256] bf16 each, 2 x 16 KB); four stages in a ring, three in flight.
+  // 2 rounds x 16 rows per operand; LDS position p of row r holds source chunk p ^ ((r & 7) << 1)
+  unsigned offa[2], offb[2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 2; ++r) {
     const int c = r * WB_THREADS + tid;
     const int row = c >> 5, pos = c & 31;
     const int src = pos ^ ((row & 7) << 1);
     offa[r] = ((unsigned)row * (unsigned)ldy + (unsigned)(n1_0 + src * 8)) * 2u;
     offb[r] = ((unsigned)row * (unsigned)ldx + (unsigned)(n2_0 + src * 8)) * 2u;
   }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * 2 * WB_TILE_BYTES + wave * 1024;
-    const unsigned soa = (unsigned)kt * WG_KM * (unsigned)ldy * 2u;
-    const unsigned sob = (unsigned)kt * WG_KM * (unsigned)ldx * 2u;
+  auto stage = [&](int slot, int ht) {
+    char* base = smem + slot * WB_STAGE_BYTES + wave * 1024;
+    const unsigned soa = (unsigned)ht * WB_KM * (unsigned)ldy * 2u;
+    const unsigned sob = (unsigned)ht * WB_KM * (unsigned)ldx * 2u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 2; ++r) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(base + r * 8192), 16, (int)offa[r], soa, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + WB_TILE_BYTES + r * 8192), 16, (int)offb[r], sob, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(base + WB_STAGE_BYTES / 2 + r * 8192), 16, (int)offb[r], sob, 0, 0);
     }
   };
 
@@ -205,32 +215,89 @@ __global__ __launch_bounds__(WB_THREADS) void sf_wgrad256_kernel(SfWgradGroup G,
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (short)0x3f80;
 
-  if (kt0 < kt1) {
-    stage(0, kt0);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (kt - kt0) & 1;
-      if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-      const char* ta = smem + cur * 2 * WB_TILE_BYTES;
-      const char* tb = ta + WB_TILE_BYTES;
+  // One barrier per 32-row step.  Step h: wait for stage h alone (the two younger stages stay in flight: counted vmcnt, a
+  // lane has 4 DMA loads per stage), barrier, refill the slot that step h-1 read (every wave is past it now) with stage
+  // h+3, then 12 transposed fragment reads + 32 MFMAs.  Round 2's two-stage loop waited for ALL loads at every 64-row step.
+  const int h0 = kt0 * 2, h1 = kt1 * 2;
+  // fragment addresses (wb_frag's arithmetic, k-step 0): row = 4 g + (t16 >> 2), 32-byte column block cb ^ (row & 7)
+  const int t16f = lane & 15, gf = lane >> 4;
+  const int frow = 4 * gf + (t16f >> 2);
+  const int rsw = frow & 7;
+  const unsigned lane_off = (unsigned)(frow * (WB_T * 2) + (((t16f & 3) >> 1) << 4) + ((t16f & 1) << 3));
+  const unsigned frag_a = lane_off + (unsigned)(wr * 8 << 5);       // A block wr*8 + i -> (wr*8 + (i ^ rsw)) << 5
+  const int rsw_b = rsw & 3;                                           // B block wc*4 + j: the XOR splits into (j ^ (rsw & 3)) and bit 2
+  const unsigned frag_b = lane_off + (unsigned)(((wc * 4) ^ (rsw & 4)) << 5);
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  auto step = [&](int ht) {          // after the wait + barrier of step ht
+    const int slot = (ht - h0) & 3;
+      // the 24 transposed reads of the step go out as inline asm: hipcc 7.2 puts an s_waitcnt vmcnt(0) in front of every
+      // ds_read_b64_tr_b16 it can see while a buffer_load ... lds is outstanding (it cannot tell the slots apart), which
+      // would drain the two stages in flight at every step.  The fragments pass through the lgkmcnt wait as operands so
+      // that no MFMA is scheduled above it.
+      const unsigned sa = lds0 + (unsigned)(slot * WB_STAGE_BYTES), sb = sa + WB_STAGE_BYTES / 2;
+      s16x4_t fbl[4], fbh[4], fal[8], fah[8];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t fb[4];
+      for (int j = 0; j < 4; ++j) {
+        const unsigned ad = sb + frag_b + (unsigned)((j ^ rsw_b) << 5);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fbl[j]) : "v"(ad));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(fbh[j]) : "v"(ad));
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = wb_frag(tb, ks, wc * 4 + j, lane);
+      for (int i = 0; i < 8; ++i) {
+        const unsigned ad = sa + frag_a + (unsigned)((i ^ rsw) << 5);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fal[i]) : "v"(ad));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(fah[i]) : "v"(ad));
+      }
+      if (ht + 3 < h1) stage((slot + 3) & 3, ht + 3);
+      asm volatile("s_waitcnt lgkmcnt(8)"
+                   : "+v"(fbl[0]), "+v"(fbh[0]), "+v"(fbl[1]), "+v"(fbh[1]), "+v"(fbl[2]), "+v"(fbh[2]), "+v"(fbl[3]), "+v"(fbh[3]),
+                     "+v"(fal[0]), "+v"(fah[0]), "+v"(fal[1]), "+v"(fah[1]), "+v"(fal[2]), "+v"(fah[2]), "+v"(fal[3]), "+v"(fah[3]));
+      bf16x8_t fb[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bf16x8_t fa = wb_frag(ta, ks, wr * 8 + i, lane);
+      for (int j = 0; j < 4; ++j) fb[j] = wb_join(fbl[j], fbh[j]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = wg_mfma(fb[j], fa, acc[i][j]);
-        }
-        if (do_bias) {          // column sums of dY: this wave's two of the eight 16-column blocks
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8_t fa = wb_join(fal[i], fah[i]);
 #pragma unroll
-          for (int q = 0; q < 2; ++q) accb[q] = wg_mfma(ones, wb_frag(ta, ks, wr * 8 + wc * 2 + q, lane), accb[q]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = wg_mfma(fb[j], fa, acc[i][j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fal[4]), "+v"(fah[4]), "+v"(fal[5]), "+v"(fah[5]), "+v"(fal[6]), "+v"(fah[6]), "+v"(fal[7]), "+v"(fah[7]));
+#pragma unroll
+      for (int i = 4; i < 8; ++i) {
+        const bf16x8_t fa = wb_join(fal[i], fah[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = wg_mfma(fb[j], fa, acc[i][j]);
+      }
+      if (do_bias) {          // column sums of dY: this wave's two of the eight 16-column blocks (read again: a register index
+                              // that depends on the wave would turn into a select chain over the eight fragments)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned ad = sa + frag_a + (unsigned)(((wc * 2 + q) ^ rsw) << 5);
+          s16x4_t bl, bh;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bl) : "v"(ad));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(bh) : "v"(ad));
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bl), "+v"(bh));
+          accb[q] = wg_mfma(ones, wb_join(bl, bh), accb[q]);
         }
       }
-      __syncthreads();
+  };
+  if (h0 < h1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (h0 + i < h1) stage(i, h0 + i);
+    int ht = h0;
+    for (; ht < h1 - 2; ++ht) {       // two younger stages stay in flight
+      asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      step(ht);
     }
+    if (ht < h1 - 1) {                // one younger stage
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      step(ht);
+      ++ht;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    step(ht);
   }
 
   const int l15 = lane & 15, g = lane >> 4;
