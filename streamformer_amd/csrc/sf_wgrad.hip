@@ -422,7 +422,8 @@ static int wg_cus() {
 // split count of a group of `ntiles` tiles over kt K-steps: rounds x (K-steps per workgroup + the tile write) + the reduce
 // pass, in K-step units (a K-step is ~2.4 us, a 256 KB partial write ~6 of them, reducing one split of one tile ~0.03)
 static int wgg_nsplit(int ntiles, int kt) {
-  if (const char* f = getenv("SF_WGRAD_NSPLIT")) { const int s = atoi(f); return s < 1 ? 1 : s; }     // lab: tools/wgrad_lab.py
+  static const int forced = getenv("SF_WGRAD_NSPLIT") ? atoi(getenv("SF_WGRAD_NSPLIT")) : 0;     // lab: tools/wgrad_lab.py
+  if (forced > 0) return forced;
   const int cus = wg_cus();
   int best = 1;
   double best_cost = 1e30;
@@ -437,7 +438,8 @@ static int wgg_nsplit(int ntiles, int kt) {
   return best;
 }
 bool sf_wgrad_groupable(int M, int N1, int N2) {
-  return N1 > 0 && N2 > 0 && (N1 % WB_T == 0) && (N2 % WB_T == 0) && (M + WG_KM - 1) / WG_KM >= 32 && !getenv("SF_WGRAD_SMALL_TILES");
+  static const bool small_only = getenv("SF_WGRAD_SMALL_TILES") != nullptr;
+  return N1 > 0 && N2 > 0 && (N1 % WB_T == 0) && (N2 % WB_T == 0) && (M + WG_KM - 1) / WG_KM >= 32 && !small_only;
 }
 size_t sf_wgrad_group_partial_floats(int M, int ntiles, int sum_n1) {
   const int kt = (M + WG_KM - 1) / WG_KM;

@@ -34,6 +34,9 @@ which = os.environ.get("WGRAD_LAB", "all")
 if which in ("all", "step"):
     for n1, n2 in ((768, 768), (2304, 768), (3072, 768), (768, 3072)):
         print("step shape", n1, n2, "host us (malloc+sync incl.) %.0f rel err %.2e" % run(n1, n2, 5), flush=True)
-if which in ("all", "grouped"):
-    os.environ["SF_WGRAD_NSPLIT"] = "1"
+if which == "all":          # the split override is read once per process: the no-split case runs in its own
+    import subprocess
+    subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, WGRAD_LAB="grouped", SF_WGRAD_NSPLIT="1"), check=True)
+if which == "grouped":
+    assert os.environ.get("SF_WGRAD_NSPLIT") == "1", "run with SF_WGRAD_NSPLIT=1"
     print("234 tiles, no split", "host us %.0f rel err %.2e" % run(4608, 3328, 5), flush=True)
