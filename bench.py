@@ -484,7 +484,7 @@ def main():
             gemms[name] = {"ms": round(ms.value, 4), "tflops": round(fl.value / ms.value / 1e9, 1)}
         # The kernel with the largest share of the forward (in-forward rocprof profile, profiles/r02_forward_kernel_stats.txt)
         # is sf_gemm_panel_kernel: per layer two K = 768 launches (temporal / spatial attention output projection) and one
-        # K = 3072 launch (MLP down-projection), each with the fp32 residual read-modify-write, the bf16 copy and the
+        # K = 3072 launch (MLP down-projection), each with the residual read-modify-write (hi + lo bf16 planes since round 3) and the
         # LayerNorm statistics of the next GEMM in its epilogue.  Its launches are MFMA-work-weighted here exactly as the
         # forward runs them: achieved = algorithmic FLOPs of (2 x out_proj + 1 x mlp_down) / their summed launch times.
         L = cfg.num_hidden_layers
@@ -503,14 +503,15 @@ def main():
             if pmc.get("panel_source_sha16") == hsrc:
                 traffic = tr
                 traffic_note = ("IMPORTED, not measured by this run: bytes/launch, mean over the panel launches of a forward = 2*FETCH_SIZE + WRITE_SIZE "
-                                f"({traffic_from}, separate --pmc passes; FETCH includes Infinity-Cache hits); algorithmic bytes/launch: 231e6 at K = 768 "
-                                "(A 38.5 + W 1.2 + fp32 residual in/out 154 + bf16 copy 38.5 MB), 346e6 at K = 3072")
+                                f"({traffic_from}, separate --pmc passes; FETCH includes Infinity-Cache hits); algorithmic bytes/launch: 194e6 at K = 768 "
+                                "(A 38.5 + W 1.2 + residual as hi + lo bf16 planes in / out 154 MB; the hi plane is the next GEMM's operand), "
+                                "313e6 at K = 3072")
             else:
                 traffic_note = f"{traffic_from} was taken on an older sf_gemm_panel.hip: traffic withheld until the PMC passes are re-run"
         except Exception as e:
             traffic_note = f"PMC file unreadable: {e!r}"
         out["roofline"] = {"kernel": "sf_gemm_panel_kernel<13> (N = 768 residual projections: 2 x attention out-proj K=768 + MLP down-proj K=3072 per layer, "
-                                     "epilogue = fp32 residual RMW + bf16 copy + LayerNorm row sums; M=%d)" % M,
+                                     "epilogue = residual read-modify-write on hi + lo bf16 planes + LayerNorm row sums; M=%d)" % M,
                            "bound": "mfma", "achieved": round(panel_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(panel_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_imported_from": traffic_from,
                            "traffic_note": traffic_note, "avg_launch_ms": round(panel_ms / 3, 4),
@@ -519,8 +520,8 @@ def main():
                            "share_of_step_time_live": round((L * panel_ms + gemms["out_proj"]["ms"]) / (1e3 * dt / args.steps), 4),
                            "share_from_profile": "39 % of kernel time (profiles/r02_forward_kernel_stats.txt; r03 re-profile in profiles/)",
                            "launches": {"out_proj_K768": gemms["out_proj"], "mlp_down_K3072": gemms["mlp_down"]},
-                           "hbm_view_K768": {"algorithmic_GB": 0.2312, "GBps": round(0.2312 / gemms["out_proj"]["ms"] * 1e3, 1),
-                                             "frac_of_hbm_peak": round(0.2312 / gemms["out_proj"]["ms"] * 1e3 / PEAK_HBM_GBS, 4)},
+                           "hbm_view_K768": {"algorithmic_GB": 0.1939, "GBps": round(0.1939 / gemms["out_proj"]["ms"] * 1e3, 1),
+                                             "frac_of_hbm_peak": round(0.1939 / gemms["out_proj"]["ms"] * 1e3 / PEAK_HBM_GBS, 4)},
                            "other_gemms": {"mlp_up": gemms["mlp_up"], "qkv": gemms["qkv"]},
                            "clock_note": "peak is the nominal 2.4 GHz figure the contract asks for; in-kernel cycle stamps put the shader clock of "
                                          "these MFMA loops at 1.88 GHz on random data (power budget; the same binary runs 12 % faster on all-zero "

@@ -160,6 +160,10 @@ struct SfGemmArgs {
   float alpha;                              // SF_EPI_RESID_F32
   const float* resid;                       // [M,N] fp32 ([resid_mod,N] when resid_mod > 0: row m reads resid[m % resid_mod],
   int resid_mod;                            //  the position + time embedding table of the patch-embedding GEMM; panel kernel)
+  // panel kernel, bf16 mode at BASELINE-sized M: the residual stream as TWO bf16 planes (hi = bf16(x), lo = bf16(x - hi)) instead of
+  // fp32 — the hi plane IS the A operand of the LayerNorm-folded Linear that follows, so the separate bf16 copy disappears
+  // (192 -> 154 MB per launch).  resid_hi / resid_lo: the incoming residual (instead of `resid`); out_hi / out_lo: the new one.
+  const bf16_t* resid_hi; const bf16_t* resid_lo;
   const float* pos; const float* time_rows; // SF_EPI_EMBED_F32: [Np,N], [Tn,N]
   int Np, Tn;
   float* out_f32;                           // [*,ldc]
@@ -212,7 +216,8 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over D: x fp32 [rows,D] -> any of {y_f32, y_hi, y_lo} (nullptr = skip)
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
-                               bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s);
+                               bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s, const bf16_t* xp_hi = nullptr,
+                               const bf16_t* xp_lo = nullptr);
 // pixels [F,C,H,W] -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw).
 // pixel_kind 0 fp32, 1 bf16, 2 uint8 raw frames normalised on the fly: y = x * scale[c] + shift[c]
 struct SfPixelNorm { float scale[4]; float shift[4]; };

@@ -479,6 +479,7 @@ struct Workspace {
   bf16_t *pc_hi, *pc_lo, *hn_hi, *hn_lo, *hm_hi, *hm_lo;
   float *lhs_stage, *pool_stage;   // streaming only: graph-owned outputs, copied to the caller's tensors after the replay
   bf16_t* res_bf;                  // small-M LayerNorm fold: bf16 copy of the residual stream (A operand of the folded Linears)
+  bf16_t* res_lo;                  // BASELINE-sized M, bf16 mode: lo plane of the residual stream (hi plane = xn_hi), see SfGemmArgs::resid_hi
   size_t bytes;
 };
 
@@ -516,6 +517,7 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.hm_hi = c.take<bf16_t>(F * I);
   w.hm_lo = acc ? c.take<bf16_t>(F * I) : nullptr;
   w.res_bf = (!acc && M <= (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
+  w.res_lo = (!acc && M > (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
   w.lhs_stage = !need_tqkv ? c.take<float>(M * D) : nullptr;       // streaming carve (the cache holds the temporal qkv)
   w.pool_stage = !need_tqkv ? c.take<float>(F * D) : nullptr;
   w.bytes = (c.off + 255) & ~(size_t)255;
@@ -530,7 +532,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
                              const float* resid = nullptr, float alpha = 1.f, int ldc = 0, int grp_rows = 0,
                              int grp_stride = 0, int grp_off = 0, const float* ln_stats = nullptr,
                              float* ln_stats_out = nullptr, bool ln_inkernel = false, const int* grp_off_dev = nullptr,
-                             int grp_off_scale = 0) {
+                             int grp_off_scale = 0, const bf16_t* resid_hi = nullptr, const bf16_t* resid_lo = nullptr) {
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
   const bool split = e->compute == SF_COMPUTE_BF16X3;
@@ -539,7 +541,8 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   g.bias = lin.bias;
   g.M = M; g.N = lin.N; g.K = lin.K;
   g.epi = epi; g.act = e->cfg.hidden_act; g.alpha = alpha; g.resid = resid;
-  g.out_f32 = out_f32; g.out_hi = out_hi; g.out_lo = split ? out_lo : nullptr;
+  g.out_f32 = out_f32; g.out_hi = out_hi; g.out_lo = (split || resid_hi) ? out_lo : nullptr;
+  g.resid_hi = resid_hi; g.resid_lo = resid_lo;
   g.ldc = ldc ? ldc : lin.N;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride; g.grp_off = grp_off;
   g.grp_off_dev = grp_off_dev; g.grp_off_scale = grp_off_scale;
@@ -643,6 +646,12 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const float scale = 1.0f / sqrtf(64.0f);
 
   bool embed_emitted_stats = false;
+  // pm: the residual stream of a whole bf16 forward at BASELINE-sized M travels as hi + lo bf16 planes (hi = xn_hi, the A operand
+  // of the folded Linears; lo = res_lo) instead of fp32: every residual producer moves 154 MB instead of 192 (no separate bf16
+  // copy).  Only for complete forwards without hidden_states (the fp32 tensor is the interface of the stage-wise entry points).
+  static const bool planes_off = getenv("SF_DISABLE_RESID_PLANES") != nullptr;
+  bool pm = !planes_off && !acc && !streaming && ws.res_lo && !hidden_states && (stages & 7) == 7 && ln_fold_ok(e, M) && ws.embed_tab &&
+            ws.patch_buf && e->Kp % 32 == 0 && e->Kp >= 128 && D == 768 && !getenv("SF_EMBED_VIA_GEMM128");
   if (stages & 1) {
   SfRowIndex idx;
   int rc = time_rows(e, t_row, T, streaming, &idx);
@@ -670,6 +679,11 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     SfGemmArgs gp = g;
     gp.epi = SF_EPI_RESID_F32; gp.alpha = 1.f; gp.resid = ws.embed_tab; gp.resid_mod = T * N;
     gp.out_hi = ws.xn_hi; gp.ln_stats_out = ws.ln_stats;
+    if (pm) {
+      SfGemmArgs gq = gp;
+      gq.out_f32 = nullptr; gq.out_lo = ws.res_lo;
+      if (embed_panel && sf_gemm_panel_supported(gq, false)) gp = gq; else pm = false;
+    }
     if (embed_panel && sf_gemm_panel_supported(gp, false)) {
       HIP_TRY(sf_launch_pos_time_table(pos_dev ? pos_dev : e->pos, ws.te_rows, ws.embed_tab, T, N, D, s));
       HIP_TRY(sf_launch_gemm_panel(gp, s));
@@ -720,12 +734,12 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       HIP_TRY(sf_launch_temporal_attention(a, acc, s));
     }
     if (e->fused_temporal) {
-      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, l.gate_tanh,
-                         0, 0, 0, 0, nullptr, fold_st));
+      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, l.gate_tanh,
+                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
     } else {
       HIP_TRY(run_linear(e, l.t_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_BF16, s, nullptr, ws.tmp_hi, ws.tmp_lo));
-      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, l.gate_tanh,
-                         0, 0, 0, 0, nullptr, fold_st));
+      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, l.gate_tanh,
+                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
     }
     // ---- spatial attention (modeling:962-996) ------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
@@ -745,21 +759,22 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.probs = attentions ? attentions + (size_t)(li - la) * F * heads * N * N : nullptr;
       HIP_TRY(sf_launch_spatial_attention(a, acc, s));
     }
-    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
-                       0, 0, 0, 0, nullptr, fold_st));
+    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, 1.f,
+                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
     // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
     HIP_TRY(run_linear(e, anyfold ? l.up_f : l.up, ln_in, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
                        0, 0, 0, 0, fold_st, nullptr, sfold));
-    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, ws.resid, fold_hi, nullptr, ws.resid, 1.f,
-                       0, 0, 0, 0, nullptr, fold_st));
+    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, 1.f,
+                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
   }
   if (hidden_states && (stages & 2) && lb == e->L)
     HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
   if (!(stages & 12)) return SF_OK;
   // ---- post LayerNorm + pooling head (modeling:1330-1340, 1141-1154) -------------------------------
-  if (stages & 4)
-    HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
+  if (stages & 4)       // pm: the rows arrive as the two planes of the residual stream
+    HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s,
+                                pm ? ws.xn_hi : nullptr, pm ? ws.res_lo : nullptr));
   else      // stage 8: the head alone on tokens the caller has already normalised (model.head(x))
     HIP_TRY(sf_launch_split(ws.resid, ws.xn_hi, acc ? ws.xn_lo : nullptr, (size_t)M * D, s));
   if (pooler) {
@@ -1235,9 +1250,19 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   if (acc && epi == SF_EPI_RESID_F32) oh = nullptr;     // the accurate mode keeps no bf16 copy of the residual (no LayerNorm fold)
-  HIP_TRY(run_linear(e, *lin, ah, al, M, epi, s, of, oh, ol, of, 0.f));   // warm
+  // bf16 mode at BASELINE-sized M: the residual projections as the forward launches them — hi + lo planes in and out, LayerNorm
+  // row sums of the next Linear (run_forward's `pm`); fp32 residual + bf16 copy otherwise
+  static const bool planes_off = getenv("SF_DISABLE_RESID_PLANES") != nullptr;
+  const bool pm = !planes_off && !acc && epi == SF_EPI_RESID_F32 && ln_fold_ok(e, M);
+  float* st = pm ? c.take<float>((size_t)M * 4) : nullptr;
+  if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
+  auto go = [&]() {
+    return pm ? run_linear(e, *lin, ah, al, M, epi, s, nullptr, oh, ol, nullptr, 0.f, 0, 0, 0, 0, nullptr, st, false, nullptr, 0, oh, ol)
+              : run_linear(e, *lin, ah, al, M, epi, s, of, oh, ol, of, 0.f);
+  };
+  HIP_TRY(go());   // warm
   HIP_TRY(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIP_TRY(run_linear(e, *lin, ah, al, M, epi, s, of, oh, ol, of, 0.f));
+  for (int i = 0; i < iters; ++i) HIP_TRY(go());
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -179,6 +179,17 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
       const int m = m0 + grp * 64 + wave + 8 * j;
+      if (p.resid_hi) {            // residual stream as hi + lo bf16 planes: lane e < 48 takes columns 8 e .. 8 e + 7 (16 bytes of each plane)
+        u32x4_t h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+        if (j < rows_w && m < m_end && elane < 48) {
+          const size_t ro = (size_t)m * (size_t)p.ldc + n0 + elane * 8;
+          h = *reinterpret_cast<const u32x4_t*>(p.resid_hi + ro);
+          l = *reinterpret_cast<const u32x4_t*>(p.resid_lo + ro);
+        }
+        res[j][0] = __builtin_bit_cast(f32x4_t, h);
+        res[j][1] = __builtin_bit_cast(f32x4_t, l);
+        continue;
+      }
       const bool ok = j < rows_w && m < m_end && p.resid != nullptr;     // no residual: plain F32 / BF16 output
       const int mr = p.resid_mod > 0 ? m % p.resid_mod : m;          // embedding table: one row per (frame slot, patch)
       const float* rp = p.resid + (size_t)mr * (size_t)p.ldc + n0;
@@ -205,6 +216,30 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
       const int m = m0 + grp * 64 + r;
       if (j < rows_w && m < m_end) {                 // wave-uniform
         float s1 = 0.f, s2 = 0.f;
+        if (p.resid_hi) {          // plane form: 8 columns per lane, 16-byte accesses on both planes
+          if (elane < 48) {
+            const u32x4_t h = __builtin_bit_cast(u32x4_t, res[j][0]), l = __builtin_bit_cast(u32x4_t, res[j][1]);
+            u32x4_t ho, lo;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int c = 2 * elane + hf;
+              const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + r * 1536 + (((c & ~31) | ((c ^ r) & 31)) << 4));
+              f32x4_t x;
+              x[0] = bf2f(h[2 * hf] & 0xffffu) + bf2f(l[2 * hf] & 0xffffu) + p.alpha * v[0];
+              x[1] = bf2f(h[2 * hf] >> 16) + bf2f(l[2 * hf] >> 16) + p.alpha * v[1];
+              x[2] = bf2f(h[2 * hf + 1] & 0xffffu) + bf2f(l[2 * hf + 1] & 0xffffu) + p.alpha * v[2];
+              x[3] = bf2f(h[2 * hf + 1] >> 16) + bf2f(l[2 * hf + 1] >> 16) + p.alpha * v[3];
+              ho[2 * hf] = pack_bf2(x[0], x[1]); ho[2 * hf + 1] = pack_bf2(x[2], x[3]);
+              lo[2 * hf] = pack_bf2(x[0] - bf2f(ho[2 * hf] & 0xffffu), x[1] - bf2f(ho[2 * hf] >> 16));
+              lo[2 * hf + 1] = pack_bf2(x[2] - bf2f(ho[2 * hf + 1] & 0xffffu), x[3] - bf2f(ho[2 * hf + 1] >> 16));
+              s1 += (x[0] + x[1]) + (x[2] + x[3]);
+              s2 += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+            }
+            const size_t o = (size_t)m * (size_t)p.ldc + n0 + elane * 8;
+            *reinterpret_cast<u32x4_t*>(p.out_hi + o) = ho;
+            *reinterpret_cast<u32x4_t*>(p.out_lo + o) = lo;
+          }
+        } else
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
           const int c = hp * 64 + elane;
@@ -214,7 +249,11 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
             const size_t o = (size_t)m * (size_t)p.ldc + n0 + c * 4;
             if (p.out_f32) *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = x;
             if (p.out_hi) {
-              *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+              const u32x2_t hv = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+              *reinterpret_cast<u32x2_t*>(p.out_hi + o) = hv;
+              if (p.out_lo)
+                *reinterpret_cast<u32x2_t*>(p.out_lo + o) = (u32x2_t){pack_bf2(x[0] - bf2f(hv[0] & 0xffffu), x[1] - bf2f(hv[0] >> 16)),
+                                                                    pack_bf2(x[2] - bf2f(hv[1] & 0xffffu), x[3] - bf2f(hv[1] >> 16))};
               s1 += (x[0] + x[1]) + (x[2] + x[3]);
               s2 += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
             }
@@ -266,7 +305,9 @@ static PanelPlan panel_plan(int M) {
 }
 
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split) {
-  if (split || a.N != 768 || a.grp_rows > 0 || a.out_lo) return false;
+  if (split || a.N != 768 || a.grp_rows > 0) return false;
+  if (a.out_lo && (a.epi != SF_EPI_RESID_F32 || !a.out_hi)) return false;        // lo plane only next to the hi plane of a residual producer
+  if (a.resid_hi && (!a.resid_lo || !a.out_lo || a.epi != SF_EPI_RESID_F32 || a.resid_mod > 0)) return false;
   if (a.epi != SF_EPI_RESID_F32 && a.epi != SF_EPI_F32 && a.epi != SF_EPI_BF16) return false;
   if (a.ln_stats) return false;                     // LN-folded consumers run on the 256^2 kernel
   if (a.K % 32 || a.K < 128) return false;

@@ -14,19 +14,29 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
                                                            float* __restrict__ y_f32,
                                                            bf16_t* __restrict__ y_hi,
                                                            bf16_t* __restrict__ y_lo, int rows, int D,
-                                                           float eps) {
+                                                           float eps, const bf16_t* xp_hi, const bf16_t* xp_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv = D >> 2;                       // float4 per row
   const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D);
+  // xp_hi / xp_lo: the row arrives as hi + lo bf16 planes (residual stream of the BASELINE-sized bf16 forward) instead of x;
+  // y_hi may be xp_hi itself: the row is in registers before the first store
+  const u32x2_t* xh = reinterpret_cast<const u32x2_t*>(xp_hi + (size_t)row * D);
+  const u32x2_t* xl = reinterpret_cast<const u32x2_t*>(xp_lo + (size_t)row * D);
   f32x4_t v[MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
     if (c < nv) {
-      v[i] = xr[c];
+      if (xp_hi) {
+        const u32x2_t h = xh[c], l = xl[c];
+        v[i] = (f32x4_t){bf2f(h[0] & 0xffffu) + bf2f(l[0] & 0xffffu), bf2f(h[0] >> 16) + bf2f(l[0] >> 16),
+                         bf2f(h[1] & 0xffffu) + bf2f(l[1] & 0xffffu), bf2f(h[1] >> 16) + bf2f(l[1] >> 16)};
+      } else {
+        v[i] = xr[c];
+      }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
       v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -69,15 +79,16 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
 }
 
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
-                               bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s) {
+                               bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s, const bf16_t* xp_hi,
+                               const bf16_t* xp_lo) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > 64 * 4 * 16) return hipErrorInvalidValue;
   const dim3 grid((rows + 3) / 4), block(256);
   const int nv = (D / 4 + 63) / 64;
-  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
-  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
-  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
-  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps);
+  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
+  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
+  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
+  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
   return hipGetLastError();
 }
 
