@@ -180,6 +180,9 @@ struct SfGemmArgs {
   // (A = bf16(x), W' = W * gamma) finishes y = rstd * (acc - mean * ln_s[n]) + bias' in its epilogue.
   float* ln_stats_out;
   const float* ln_stats; const float* ln_s; float ln_eps;
+  // ln_stats_wide = 1 (fp32-accurate mode): rows of 8 floats, one {sum x, sum x^2} pair per 256-column tile of the bf16x3 256^2
+  // kernel that produced the residual row (3 pairs + 2 pad) — ln_stats and ln_stats_out alike
+  int ln_stats_wide;
   // small-M variant of the fold (sf_gemm_skinny.hip): ln_inkernel = 1 -> the consumer derives mean / rstd of its rows from the
   // A fragments it streams anyway (A = bf16(x), ln_s as above); no statistics buffer exists
   int ln_inkernel;
@@ -238,7 +241,7 @@ hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hip
 hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s,
                            const SfStreamParams* sp = nullptr);        // sp != nullptr: a_dst = sp->lhs, b_dst = sp->pooler (device reads)
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
-hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s);
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo = nullptr);
 // out[t*N + n, :] = pos[n, :] + time_rows[t, :]   (the additive table of the embeddings, modeling:413-457)
 hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, float* out, int T, int N, int D, hipStream_t s);
 // gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)

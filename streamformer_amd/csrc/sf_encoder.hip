@@ -62,7 +62,7 @@ struct DevLN { float* g = nullptr; float* b = nullptr; };
 struct DevLayer {
   DevLN ln_t, ln_b, ln_a;
   DevLinear t_qkv, t_out, t_dense, t_fused, s_qkv, s_out, up, down;
-  DevLinear t_qkv_f, s_qkv_f, up_f;   // bf16 mode: the preceding LayerNorm folded in (W' = W*gamma, b' = b + W beta)
+  DevLinear t_qkv_f, s_qkv_f, up_f;   // the preceding LayerNorm folded in (W' = W*gamma, b' = b + W beta; hi + lo planes in the accurate mode)
   float gate_tanh = 0.f;
 };
 
@@ -313,13 +313,15 @@ static int upload_folded_linear(sf_encoder* e, const std::vector<float>& w, cons
                                 const std::vector<float>& gamma, const std::vector<float>& beta, int N, int K,
                                 DevLinear* out) {
   std::vector<float> wf(w.size()), bf(N), sn(N);
+  const bool split = e->compute == SF_COMPUTE_BF16X3;      // the MFMAs then see hi + lo planes of W'
   for (int n = 0; n < N; ++n) {
     double bb = bias ? (double)(*bias)[n] : 0.0, ss = 0.0;
     for (int k = 0; k < K; ++k) {
       const float wv = w[(size_t)n * K + k];
       const float wg = (float)((double)wv * (double)gamma[k]);
       wf[(size_t)n * K + k] = wg;
-      ss += (double)h_bf2f(h_f2bf(wg));
+      const float hi = h_bf2f(h_f2bf(wg));
+      ss += (double)hi + (split ? (double)h_bf2f(h_f2bf(wg - hi)) : 0.0);
       bb += (double)wv * (double)beta[k];
     }
     bf[n] = (float)bb;
@@ -375,9 +377,8 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     TRY(upload_ln(e, p + "layernorm_before", &l.ln_b));
     TRY(upload_ln(e, p + "layernorm_after", &l.ln_a));
     TRY(upload_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"), 3 * D, D, &l.t_qkv));
-    if (compute == SF_COMPUTE_BF16)
-      TRY(upload_folded_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"),
-                               H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_f));
+    TRY(upload_folded_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"),
+                             H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_f));
     if (e->fused_temporal) {
       // temporal_dense(output.dense(x)) = (W2 W1) x + (W2 b1 + b2)      (modeling:947-954)
       const std::vector<float>& w1 = H(p + "temporal_attention.output.dense.weight");
@@ -410,12 +411,10 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
       merge_lora_into(wo, H(p + "attention.output.dense_lora_a.weight"), H(p + "attention.output.dense_lora_b.weight"), D, D, kLoraRank);
     }
     TRY(upload_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), 3 * D, D, &l.s_qkv));
-    if (compute == SF_COMPUTE_BF16) {
-      TRY(upload_folded_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), H(p + "layernorm_before.weight"),
-                               H(p + "layernorm_before.bias"), 3 * D, D, &l.s_qkv_f));
-      TRY(upload_folded_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"),
-                               H(p + "layernorm_after.weight"), H(p + "layernorm_after.bias"), I, D, &l.up_f));
-    }
+    TRY(upload_folded_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), H(p + "layernorm_before.weight"),
+                             H(p + "layernorm_before.bias"), 3 * D, D, &l.s_qkv_f));
+    TRY(upload_folded_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"),
+                             H(p + "layernorm_after.weight"), H(p + "layernorm_after.bias"), I, D, &l.up_f));
     TRY(upload_linear(e, wo, Hopt(p + "attention.output.dense.bias"), D, D, &l.s_out));
     TRY(upload_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"), I, D, &l.up));
     TRY(upload_linear(e, H(p + "output.dense.weight"), Hopt(p + "output.dense.bias"), D, I, &l.down));
@@ -492,7 +491,7 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   const size_t wide = D > (size_t)e->Kp ? D : (size_t)e->Kp;
   w.resid = c.take<float>(M * D);
   w.te_rows = c.take<float>((size_t)T * D);
-  w.ln_stats = c.take<float>(M * 4);
+  w.ln_stats = c.take<float>(M * (acc ? 8 : 4));      // accurate mode: one pair per 256-column tile of the producer
   w.embed_tab = (!acc && M >= 2048) ? c.take<float>((size_t)T * N * D) : nullptr;
   w.patch_buf = (!acc && M >= 2048) ? c.take<bf16_t>(M * (size_t)e->Kp) : nullptr;
   w.xn_hi = c.take<bf16_t>(M * wide);
@@ -549,6 +548,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   if (grp_rows > 0 && grp_stride == grp_rows && grp_off == 0 && !grp_off_dev) g.grp_rows = 0;   // identity remap (full clip)
   g.ln_stats = ln_stats; g.ln_s = ln_stats ? lin.ln_s : nullptr; g.ln_eps = e->cfg.layer_norm_eps;
   g.ln_stats_out = ln_stats_out;
+  g.ln_stats_wide = split ? 1 : 0;
   if (ln_inkernel) { g.ln_inkernel = 1; g.ln_s = lin.ln_s; }
   if (epi == SF_EPI_RESID_F32) g.out_hi = out_hi;     // LN-fold producer: bf16 copy of the new residual rows
   return sf_launch_gemm(g, split, s);
@@ -573,6 +573,29 @@ static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (!sf_gemm256_supported(g, false)) return false;
   g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
   return sf_gemm256_supported(g, false);
+}
+
+// fp32-accurate mode: the fold on the bf16x3 256^2 kernel, with the residual stream itself carried as the hi + lo bf16 planes
+// that are the folded Linears' operands (xn_hi / xn_lo): a residual producer reads and writes the planes and emits one
+// {sum x, sum x^2} pair per 256-column tile; no fp32 residual, no LayerNorm launch.  The planes hold x to 2^-18 relative, the
+// precision every bf16x3 operand has anyway.  SF_DISABLE_ACC_FOLD restores fp32 residual + standalone LayerNorm (A/B).
+static bool ln_fold_acc_ok(const sf_encoder* e, int M) {
+  if (e->compute != SF_COMPUTE_BF16X3 || e->D != 768) return false;
+  static const bool off = getenv("SF_DISABLE_ACC_FOLD") != nullptr;
+  if (off) return false;
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_lo = (const bf16_t*)1; g.w_lo = (const bf16_t*)1; g.ln_stats_wide = 1;
+  g.M = M; g.N = e->D; g.K = e->D; g.epi = SF_EPI_RESID_F32;
+  g.out_hi = (bf16_t*)1; g.out_lo = (bf16_t*)1; g.ln_stats_out = (float*)1; g.resid_hi = (const bf16_t*)1; g.resid_lo = (const bf16_t*)1;
+  if (!sf_gemm256_supported(g, true)) return false;
+  g.K = e->I;
+  if (!sf_gemm256_supported(g, true)) return false;
+  g.ln_stats_out = nullptr; g.out_hi = nullptr; g.resid_hi = g.resid_lo = nullptr; g.ln_stats = (const float*)1; g.ln_s = (const float*)1;
+  g.epi = SF_EPI_BF16; g.K = e->D; g.N = 3 * e->D;
+  if (!sf_gemm256_supported(g, true)) return false;
+  g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
+  return sf_gemm256_supported(g, true);
 }
 
 // Small-M variant (the per-frame streaming step): the skinny GEMM derives the row statistics itself from the A fragments
@@ -702,11 +725,17 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const bool fold = ln_fold_ok(e, M) && !streaming;
   // sfold: the same algebra at small M (streamed frames), statistics computed inside the consumer GEMM
   const bool sfold = !fold && ws.res_bf && ln_fold_small_ok(e, M);
-  bf16_t* fold_hi = fold ? ws.xn_hi : (sfold ? ws.res_bf : nullptr);
-  float* fold_st = fold ? ws.ln_stats : nullptr;
+  // xm: the accurate mode's counterpart of fold + pm (ln_fold_acc_ok): whole clips on the plane-fed attention kernels
+  const bool xm = acc && !streaming && !hidden_states && (stages & 7) == 7 && !layer_tqkv && cap == T && t_past == 0 &&
+                  sf_temporal_planes_ok(T, T) && sf_spatial_planes_ok(N, attentions != nullptr) && ln_fold_acc_ok(e, M);
+  bf16_t* fold_hi = (fold || xm) ? ws.xn_hi : (sfold ? ws.res_bf : nullptr);
+  float* fold_st = (fold || xm) ? ws.ln_stats : nullptr;
   const bf16_t* ln_in = sfold ? ws.res_bf : ws.xn_hi;       // A operand of the three LayerNorm'd Linears
-  const bool anyfold = fold || sfold;
+  const bool anyfold = fold || sfold || xm;
+  const bool rplanes = pm || xm;                             // residual stream as two bf16 planes: hi = xn_hi, lo = plo
+  bf16_t* plo = pm ? ws.res_lo : (xm ? ws.xn_lo : nullptr);
   if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
+  if (xm) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, ws.xn_lo));      // embeddings -> planes + wide statistics
   if (sfold && (stages & 2) && !(stages & 1) && !(ready & 2)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
   for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];
@@ -734,12 +763,12 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       HIP_TRY(sf_launch_temporal_attention(a, acc, s));
     }
     if (e->fused_temporal) {
-      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, l.gate_tanh,
-                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
+      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, l.gate_tanh,
+                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo));
     } else {
       HIP_TRY(run_linear(e, l.t_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_BF16, s, nullptr, ws.tmp_hi, ws.tmp_lo));
-      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, l.gate_tanh,
-                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
+      HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, l.gate_tanh,
+                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo));
     }
     // ---- spatial attention (modeling:962-996) ------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_b.g, l.ln_b.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
@@ -759,14 +788,14 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.probs = attentions ? attentions + (size_t)(li - la) * F * heads * N * N : nullptr;
       HIP_TRY(sf_launch_spatial_attention(a, acc, s));
     }
-    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, 1.f,
-                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
+    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,
+                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo));
     // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
     HIP_TRY(run_linear(e, anyfold ? l.up_f : l.up, ln_in, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
                        0, 0, 0, 0, fold_st, nullptr, sfold));
-    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, pm ? nullptr : ws.resid, fold_hi, pm ? ws.res_lo : nullptr, pm ? nullptr : ws.resid, 1.f,
-                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, pm ? fold_hi : nullptr, pm ? ws.res_lo : nullptr));
+    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,
+                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo));
   }
   if (hidden_states && (stages & 2) && lb == e->L)
     HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
@@ -774,7 +803,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // ---- post LayerNorm + pooling head (modeling:1330-1340, 1141-1154) -------------------------------
   if (stages & 4)       // pm: the rows arrive as the two planes of the residual stream
     HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s,
-                                pm ? ws.xn_hi : nullptr, pm ? ws.res_lo : nullptr));
+                                rplanes ? ws.xn_hi : nullptr, plo));
   else      // stage 8: the head alone on tokens the caller has already normalised (model.head(x))
     HIP_TRY(sf_launch_split(ws.resid, ws.xn_hi, acc ? ws.xn_lo : nullptr, (size_t)M * D, s));
   if (pooler) {

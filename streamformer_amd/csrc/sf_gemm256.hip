@@ -387,12 +387,23 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #pragma unroll
         for (int mt = 0; mt < (mq ? MT1 : 4); ++mt) {
           const int r = wm * 64 + mt * 16 + l15;
+          float ln_mu = 0.f, ln_r = 1.f;
+          if (ln_fold) {      // fp32-accurate mode: A = the hi + lo planes of the raw residual rows, wide statistics from their producer
+            const int mrow = min(m0 + wm * HR + mq * 64 + mt * 16 + l15, p.M - 1);
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 8);
+            const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 8 + 4);
+            const float invd = 1.0f / (float)K;
+            ln_mu = ((s0[0] + s0[2]) + s1[0]) * invd;
+            ln_r = rsqrtf(((s0[1] + s0[3]) + s1[1]) * invd - ln_mu * ln_mu + p.ln_eps);
+          }
 #pragma unroll
           for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               const int nl = wn * 64 + nq * 32 + nt * 16 + g * 4;
-              f32x4_t v = acc[mq][nq][mt][nt] + bias4[nq][nt];
+              f32x4_t v = acc[mq][nq][mt][nt];
+              if (ln_fold) v = ln_r * (v - ln_mu * lns4[nq][nt]);
+              v += bias4[nq][nt];
               if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = p.act == 0 ? apply_act_fast(v[j], 0) : apply_act(v[j], p.act);   // erf to 1.5e-7 abs (ocml erff costs ~100 us per launch here)
@@ -424,6 +435,48 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
               if (p.out_lo) *reinterpret_cast<u32x4_t*>(p.out_lo + o) = l;
             }
           }
+        } else if (SPLIT && EPI == SF_EPI_RESID_F32 && p.resid_hi) {
+          // fp32-accurate mode, residual stream as hi + lo bf16 planes (they ARE the operand planes of the folded Linear that
+          // follows): a lane takes 8 columns — 16 bytes of each plane in, 16 out — and the 32 lanes of a row reduce this
+          // 256-column tile's {sum x, sum x^2} for the wide statistics
+#pragma unroll 2
+          for (int it = 0; it < 8; ++it) {
+            const int idx = it * G_THREADS + tid;
+            const int r = idx >> 5, c2 = idx & 31;
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + (((2 * c2) ^ (r & 63)) << 4));
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + r * 1024 + (((2 * c2 + 1) ^ (r & 63)) << 4));
+            const int m = m0 + (r >> 6) * HR + mq * 64 + (r & 63);
+            const bool ok = m < p.M && (r & 63) < (mq ? MT1 : 4) * 16;        // uniform over the 32 lanes of a row
+            float s1 = 0.f, s2 = 0.f;
+            const size_t o = (size_t)(ok ? m : 0) * (size_t)p.ldc + n0 + c2 * 8;
+            if (ok) {
+              const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(p.resid_hi + o), li = *reinterpret_cast<const u32x4_t*>(p.resid_lo + o);
+              float x[8];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const f32x4_t& vv = j < 2 ? v0 : v1;
+                x[2 * j] = bf2f(hi[j] & 0xffffu) + bf2f(li[j] & 0xffffu) + p.alpha * vv[(2 * j) & 3];
+                x[2 * j + 1] = bf2f(hi[j] >> 16) + bf2f(li[j] >> 16) + p.alpha * vv[(2 * j + 1) & 3];
+              }
+              u32x4_t h, l;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                h[j] = pack_bf2(x[2 * j], x[2 * j + 1]);
+                l[j] = pack_bf2(x[2 * j] - bf2f(h[j] & 0xffffu), x[2 * j + 1] - bf2f(h[j] >> 16));
+                s1 += x[2 * j] + x[2 * j + 1];
+                s2 += x[2 * j] * x[2 * j] + x[2 * j + 1] * x[2 * j + 1];
+              }
+              *reinterpret_cast<u32x4_t*>(p.out_hi + o) = h;
+              *reinterpret_cast<u32x4_t*>(p.out_lo + o) = l;
+            }
+#pragma unroll
+            for (int sh = 1; sh <= 16; sh <<= 1) {
+              s1 += __shfl_xor(s1, sh, 64);
+              s2 += __shfl_xor(s2, sh, 64);
+            }
+            if (ok && c2 == 0)
+              *reinterpret_cast<u32x2_t*>(p.ln_stats_out + (size_t)m * 8 + (size_t)(n0 >> 8) * 2) = (u32x2_t){__float_as_uint(s1), __float_as_uint(s2)};
+          }
         } else {
 #pragma unroll 4
           for (int it = 0; it < 16; ++it) {
@@ -447,9 +500,17 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 }
 
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
-  if (split && (!a.a_lo || !a.w_lo || a.ln_stats || a.aux_mode || getenv("SF_DISABLE_G256_SPLIT"))) return false;
+  if (split && (!a.a_lo || !a.w_lo || a.aux_mode || getenv("SF_DISABLE_G256_SPLIT"))) return false;
+  if (split && a.ln_stats && (!a.ln_stats_wide || !a.ln_s || a.K != 768 || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
+  if (!split && a.resid_hi) return false;
   if (a.epi == SF_EPI_EMBED_F32) return false;
-  if (a.epi == SF_EPI_RESID_F32 && a.out_hi) return false;     // no bf16 copy of the new residual here (panel kernel)
+  if (a.epi == SF_EPI_RESID_F32 && a.out_hi) {
+    // bf16 mode: no bf16 copy of the new residual here (panel kernel).  fp32-accurate mode: the residual as hi + lo planes, in
+    // and out, with the wide LayerNorm statistics of the Linear that follows
+    if (!split || !a.out_lo || !a.resid_hi || !a.resid_lo || !a.ln_stats_out || !a.ln_stats_wide || a.N != 768 || a.grp_rows > 0) return false;
+  } else if (a.resid_hi) {
+    return false;
+  }
   if (!split && a.epi == SF_EPI_ACT_BF16 && a.act != 0 && a.act != 99) return false;   // other activations: 128^2 kernel
   if (a.K % 128 || a.K < 128) return false;
   int min_n = 1024;                             // N = 768: 294 tiles on 256 CUs -> the panel / 128^2 kernels win
@@ -494,6 +555,9 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
 #define SF_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, false, BM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SF_ATTR(SF_EPI_F32) SF_ATTR(SF_EPI_BF16) SF_ATTR(SF_EPI_ACT_BF16) SF_ATTR(SF_EPI_RESID_F32)
 #undef SF_ATTR
+#define SF_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm256_kernel<E, true, BM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SF_ATTR(SF_EPI_BF16) SF_ATTR(SF_EPI_ACT_BF16)
+#undef SF_ATTR
   }
   const dim3 grid(g256_grid()), block(G_THREADS);
   // stagger as wall_clock64() ticks (sf_wall_clock_ticks), only when the launch runs
@@ -521,7 +585,14 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   }
 #define SF_LAUNCH256(E, L, SP) hipLaunchKernelGGL((sf_gemm256_kernel<E, L, BM, SP>), grid, block, lds, s, a, tiles, stagger, sgroups)
   if (a.a_lo && a.w_lo) {      // fp32-accurate mode: hi + lo planes of both operands, three products per fragment pair
-    if (a.ln_stats || a.aux_mode) return hipErrorInvalidValue;
+    if (a.aux_mode) return hipErrorInvalidValue;
+    if (a.ln_stats) {          // LayerNorm folded into this Linear (wide statistics of the accurate mode)
+      if (!a.ln_stats_wide || !a.ln_s) return hipErrorInvalidValue;
+      if (a.epi == SF_EPI_BF16) SF_LAUNCH256(SF_EPI_BF16, true, true);
+      else if (a.epi == SF_EPI_ACT_BF16) SF_LAUNCH256(SF_EPI_ACT_BF16, true, true);
+      else return hipErrorInvalidValue;
+      return hipGetLastError();
+    }
     switch (a.epi) {
 #define SF_CASE(E) case E: SF_LAUNCH256(E, false, true); break;
       SF_CASE(SF_EPI_F32) SF_CASE(SF_EPI_BF16) SF_CASE(SF_EPI_ACT_BF16) SF_CASE(SF_EPI_RESID_F32)

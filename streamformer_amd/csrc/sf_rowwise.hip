@@ -190,7 +190,7 @@ hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hip
 // ------------------------------------------------------------------------------------------------
 // LN-fold entry: bf16 copy of the rows + {sum x, sum x^2} (used once per forward, on the embeddings)
 __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
-                                                               float* __restrict__ stats, int rows, int D) {
+                                                               bf16_t* __restrict__ xlo, float* __restrict__ stats, int rows, int D) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -200,17 +200,24 @@ __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __re
     const f32x4_t v = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D)[c];
     s1 += (v[0] + v[1]) + (v[2] + v[3]);
     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-    *reinterpret_cast<u32x2_t*>(xb + (size_t)row * D + (size_t)c * 4) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    const u32x2_t h = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<u32x2_t*>(xb + (size_t)row * D + (size_t)c * 4) = h;
+    if (xlo)
+      *reinterpret_cast<u32x2_t*>(xlo + (size_t)row * D + (size_t)c * 4) =
+          (u32x2_t){pack_bf2(v[0] - bf2f(h[0] & 0xffffu), v[1] - bf2f(h[0] >> 16)), pack_bf2(v[2] - bf2f(h[1] & 0xffffu), v[3] - bf2f(h[1] >> 16))};
   }
   s1 = wave_sum_dpp(s1);
   s2 = wave_sum_dpp(s2);
-  if (lane == 0) *reinterpret_cast<f32x4_t*>(stats + (size_t)row * 4) = (f32x4_t){s1, s2, 0.f, 0.f};
+  if (lane == 0) {          // xlo: the wide rows of the accurate mode ([8]: this pair + two empty ones)
+    *reinterpret_cast<f32x4_t*>(stats + (size_t)row * (xlo ? 8 : 4)) = (f32x4_t){s1, s2, 0.f, 0.f};
+    if (xlo) *reinterpret_cast<f32x4_t*>(stats + (size_t)row * 8 + 4) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 }
 
-hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s) {
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo) {
   if (rows <= 0) return hipSuccess;
   if (D % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, stats, rows, D);
+  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, xlo, stats, rows, D);
   return hipGetLastError();
 }
 
