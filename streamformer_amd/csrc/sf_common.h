@@ -164,6 +164,9 @@ struct SfGemmArgs {
   // fp32 — the hi plane IS the A operand of the LayerNorm-folded Linear that follows, so the separate bf16 copy disappears
   // (192 -> 154 MB per launch).  resid_hi / resid_lo: the incoming residual (instead of `resid`); out_hi / out_lo: the new one.
   const bf16_t* resid_hi; const bf16_t* resid_lo;
+  // fp32-accurate mode: a third plane lo2 = bf16(x - hi - lo) that only the residual producers (and the last LayerNorm) read and
+  // write — hi + lo + lo2 hold x to 2^-27, so the stream loses nothing to the 36 re-splits of a forward
+  const bf16_t* resid_lo2; bf16_t* out_lo2;
   const float* pos; const float* time_rows; // SF_EPI_EMBED_F32: [Np,N], [Tn,N]
   int Np, Tn;
   float* out_f32;                           // [*,ldc]
@@ -220,7 +223,7 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 // LayerNorm over D: x fp32 [rows,D] -> any of {y_f32, y_hi, y_lo} (nullptr = skip)
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
                                bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s, const bf16_t* xp_hi = nullptr,
-                               const bf16_t* xp_lo = nullptr);
+                               const bf16_t* xp_lo = nullptr, const bf16_t* xp_lo2 = nullptr);
 // pixels [F,C,H,W] -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw).
 // pixel_kind 0 fp32, 1 bf16, 2 uint8 raw frames normalised on the fly: y = x * scale[c] + shift[c]
 struct SfPixelNorm { float scale[4]; float shift[4]; };
@@ -241,7 +244,8 @@ hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hip
 hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const float* b_src, float* b_dst, size_t nb, hipStream_t s,
                            const SfStreamParams* sp = nullptr);        // sp != nullptr: a_dst = sp->lhs, b_dst = sp->pooler (device reads)
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
-hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo = nullptr);
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo = nullptr,
+                                   bf16_t* xlo2 = nullptr);
 // out[t*N + n, :] = pos[n, :] + time_rows[t, :]   (the additive table of the embeddings, modeling:413-457)
 hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, float* out, int T, int N, int D, hipStream_t s);
 // gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)

@@ -451,23 +451,28 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
             const size_t o = (size_t)(ok ? m : 0) * (size_t)p.ldc + n0 + c2 * 8;
             if (ok) {
               const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(p.resid_hi + o), li = *reinterpret_cast<const u32x4_t*>(p.resid_lo + o);
+              u32x4_t l2i = {0u, 0u, 0u, 0u};
+              if (p.resid_lo2) l2i = *reinterpret_cast<const u32x4_t*>(p.resid_lo2 + o);
               float x[8];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const f32x4_t& vv = j < 2 ? v0 : v1;
-                x[2 * j] = bf2f(hi[j] & 0xffffu) + bf2f(li[j] & 0xffffu) + p.alpha * vv[(2 * j) & 3];
-                x[2 * j + 1] = bf2f(hi[j] >> 16) + bf2f(li[j] >> 16) + p.alpha * vv[(2 * j + 1) & 3];
+                x[2 * j] = (bf2f(hi[j] & 0xffffu) + bf2f(li[j] & 0xffffu)) + bf2f(l2i[j] & 0xffffu) + p.alpha * vv[(2 * j) & 3];
+                x[2 * j + 1] = (bf2f(hi[j] >> 16) + bf2f(li[j] >> 16)) + bf2f(l2i[j] >> 16) + p.alpha * vv[(2 * j + 1) & 3];
               }
-              u32x4_t h, l;
+              u32x4_t h, l, l2;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 h[j] = pack_bf2(x[2 * j], x[2 * j + 1]);
-                l[j] = pack_bf2(x[2 * j] - bf2f(h[j] & 0xffffu), x[2 * j + 1] - bf2f(h[j] >> 16));
+                const float r0 = x[2 * j] - bf2f(h[j] & 0xffffu), r1 = x[2 * j + 1] - bf2f(h[j] >> 16);
+                l[j] = pack_bf2(r0, r1);
+                l2[j] = pack_bf2(r0 - bf2f(l[j] & 0xffffu), r1 - bf2f(l[j] >> 16));
                 s1 += x[2 * j] + x[2 * j + 1];
                 s2 += x[2 * j] * x[2 * j] + x[2 * j + 1] * x[2 * j + 1];
               }
               *reinterpret_cast<u32x4_t*>(p.out_hi + o) = h;
               *reinterpret_cast<u32x4_t*>(p.out_lo + o) = l;
+              if (p.out_lo2) *reinterpret_cast<u32x4_t*>(p.out_lo2 + o) = l2;
             }
 #pragma unroll
             for (int sh = 1; sh <= 16; sh <<= 1) {

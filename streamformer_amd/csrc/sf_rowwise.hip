@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
                                                            float* __restrict__ y_f32,
                                                            bf16_t* __restrict__ y_hi,
                                                            bf16_t* __restrict__ y_lo, int rows, int D,
-                                                           float eps, const bf16_t* xp_hi, const bf16_t* xp_lo) {
+                                                           float eps, const bf16_t* xp_hi, const bf16_t* xp_lo, const bf16_t* xp_lo2) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
   // y_hi may be xp_hi itself: the row is in registers before the first store
   const u32x2_t* xh = reinterpret_cast<const u32x2_t*>(xp_hi + (size_t)row * D);
   const u32x2_t* xl = reinterpret_cast<const u32x2_t*>(xp_lo + (size_t)row * D);
+  const u32x2_t* xl2 = reinterpret_cast<const u32x2_t*>(xp_lo2 + (size_t)row * D);
   f32x4_t v[MAXV];
   float s = 0.f;
 #pragma unroll
@@ -34,6 +35,10 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
         const u32x2_t h = xh[c], l = xl[c];
         v[i] = (f32x4_t){bf2f(h[0] & 0xffffu) + bf2f(l[0] & 0xffffu), bf2f(h[0] >> 16) + bf2f(l[0] >> 16),
                          bf2f(h[1] & 0xffffu) + bf2f(l[1] & 0xffffu), bf2f(h[1] >> 16) + bf2f(l[1] >> 16)};
+        if (xp_lo2) {
+          const u32x2_t l2 = xl2[c];
+          v[i] += (f32x4_t){bf2f(l2[0] & 0xffffu), bf2f(l2[0] >> 16), bf2f(l2[1] & 0xffffu), bf2f(l2[1] >> 16)};
+        }
       } else {
         v[i] = xr[c];
       }
@@ -80,15 +85,15 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
 
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
                                bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s, const bf16_t* xp_hi,
-                               const bf16_t* xp_lo) {
+                               const bf16_t* xp_lo, const bf16_t* xp_lo2) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > 64 * 4 * 16) return hipErrorInvalidValue;
   const dim3 grid((rows + 3) / 4), block(256);
   const int nv = (D / 4 + 63) / 64;
-  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
-  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
-  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
-  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo);
+  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
+  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
+  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
+  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
   return hipGetLastError();
 }
 
@@ -190,7 +195,7 @@ hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hip
 // ------------------------------------------------------------------------------------------------
 // LN-fold entry: bf16 copy of the rows + {sum x, sum x^2} (used once per forward, on the embeddings)
 __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
-                                                               bf16_t* __restrict__ xlo, float* __restrict__ stats, int rows, int D) {
+                                                               bf16_t* __restrict__ xlo, bf16_t* __restrict__ xlo2, float* __restrict__ stats, int rows, int D) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -202,9 +207,14 @@ __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __re
     s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     const u32x2_t h = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     *reinterpret_cast<u32x2_t*>(xb + (size_t)row * D + (size_t)c * 4) = h;
-    if (xlo)
-      *reinterpret_cast<u32x2_t*>(xlo + (size_t)row * D + (size_t)c * 4) =
-          (u32x2_t){pack_bf2(v[0] - bf2f(h[0] & 0xffffu), v[1] - bf2f(h[0] >> 16)), pack_bf2(v[2] - bf2f(h[1] & 0xffffu), v[3] - bf2f(h[1] >> 16))};
+    if (xlo) {
+      const float r0 = v[0] - bf2f(h[0] & 0xffffu), r1 = v[1] - bf2f(h[0] >> 16), r2 = v[2] - bf2f(h[1] & 0xffffu), r3 = v[3] - bf2f(h[1] >> 16);
+      const u32x2_t l = {pack_bf2(r0, r1), pack_bf2(r2, r3)};
+      *reinterpret_cast<u32x2_t*>(xlo + (size_t)row * D + (size_t)c * 4) = l;
+      if (xlo2)
+        *reinterpret_cast<u32x2_t*>(xlo2 + (size_t)row * D + (size_t)c * 4) =
+            (u32x2_t){pack_bf2(r0 - bf2f(l[0] & 0xffffu), r1 - bf2f(l[0] >> 16)), pack_bf2(r2 - bf2f(l[1] & 0xffffu), r3 - bf2f(l[1] >> 16))};
+    }
   }
   s1 = wave_sum_dpp(s1);
   s2 = wave_sum_dpp(s2);
@@ -214,10 +224,10 @@ __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __re
   }
 }
 
-hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo) {
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo, bf16_t* xlo2) {
   if (rows <= 0) return hipSuccess;
   if (D % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, xlo, stats, rows, D);
+  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, xlo, xlo2, stats, rows, D);
   return hipGetLastError();
 }
 
