@@ -1,5 +1,6 @@
+"""8-clip bf16 forward: time + checksum; run with and without SF_DISABLE_RESID_PLANES=1 (profiles/r03_resid_planes_ab.txt)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, streamformer_amd as sa
 cfg = sa.siglip_base()
 m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
