@@ -300,7 +300,12 @@ static PanelPlan panel_plan(int M) {
   for (int i = 0; i < 4; ++i)
     if (rows <= 16 * kMt[i]) { pl.mt = kMt[i]; break; }
   if (!pl.mt) return pl;
-  pl.panels = panels; pl.rows = rows; pl.ok = rows * 4 >= pl.mt * 16 * 3;   // >= 75 % of the MFMA rows are real
+  // >= 75 % of the MFMA rows real; from five clips on 55 % is enough — the folded schedule (and the plane-form residual that comes
+  // with it) beats LayerNorm launches + the 256^2 / 128^2 residual kernels there (tools/bsweep.py: 5 clips 6.44 -> 6.09 ms, 6 clips
+  // 6.95 -> 6.64; three clips at 66 % lose 6 %).  SF_PANEL_MIN_FILL_PCT forces one threshold (lab).
+  static const int forced = getenv("SF_PANEL_MIN_FILL_PCT") ? atoi(getenv("SF_PANEL_MIN_FILL_PCT")) : 0;
+  const int min_fill = forced ? forced : (M >= 14000 ? 55 : 75);
+  pl.panels = panels; pl.rows = rows; pl.ok = rows * 100 >= pl.mt * 16 * min_fill;
   return pl;
 }
 

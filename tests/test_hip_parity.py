@@ -907,3 +907,20 @@ def test_plane_form_residual_stream_equals_the_fp32_one(sa, mode):
     lt, pt = (ACC_TOL, ACC_TOL) if mode == "fp32" else (BF16_LHS, BF16_POOL)
     assert maxabs(planes.last_hidden_state[2], want["last_hidden_state"][0]) <= lt
     assert maxabs(planes.pooler_output[2], want["pooler_output"][0]) <= pt
+
+
+def test_five_clips_run_the_folded_schedule(sa):
+    """Five and six clips fill 59 % / 71 % of the panel kernel's MFMA rows; from five clips on the folded schedule (panel producers,
+    plane-form residual, 256^2 consumers) is taken anyway (sf_gemm_panel.hip: panel_plan).  Against the oracle, clip by clip
+    independence included."""
+    cfg = siglip_base()
+    sd = make_state_dict(cfg, seed=0)
+    m = build(sa, cfg, sd, "bf16")
+    xc = torch.randn(5, 16, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    out = m(xc.cuda())
+    want = O.forward(sd, cfg, xc[4:5])
+    assert maxabs(out.last_hidden_state[4], want["last_hidden_state"][0]) <= BF16_LHS
+    assert maxabs(out.pooler_output[4], want["pooler_output"][0]) <= BF16_POOL
+    x2 = xc.clone(); x2[:4] = -x2[:4]
+    out2 = m(x2.cuda())
+    assert torch.equal(out2.last_hidden_state[4], out.last_hidden_state[4])
