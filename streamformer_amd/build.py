@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamformer_hip.so")
-SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip",
+SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_pp.hip", "sf_gemm_pipe.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -35,9 +35,13 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
+    """lab=True: the measurement variant libstreamformer_hip_lab.so (-DSF_LAB: result-discarding timing switches compiled in),
+    loaded by tools/ through SF_LIB=lab; never by the package's default path, bench.py or the tests."""
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_lab" if lab else "build")
+    lib_path = os.path.join(HERE, "libstreamformer_hip_lab.so") if lab else LIB
+    flags = FLAGS + (["-DSF_LAB"] if lab else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "sf_train.h"), os.path.join(CSRC, "sf_internal.h"),
                os.path.join(os.path.dirname(HERE), "include", "streamformer_hip.h")]
@@ -46,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
         if force or _stale(obj, [srcp] + headers):
-            cmd = [hipcc, *FLAGS, "-c", srcp, "-o", obj]
+            cmd = [hipcc, *flags, "-c", srcp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -54,11 +58,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if force or _stale(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    if lab:
+        return lib_path
     # the C++ host example of the C ABI (no Python / torch in that process); tests/test_c_host.py runs it on a GPU
     ex_src = os.path.join(os.path.dirname(HERE), "examples", "host_forward.cpp")
     ex_bin = os.path.join(os.path.dirname(HERE), "examples", "host_forward")
@@ -72,5 +78,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, lab="--lab" in sys.argv))

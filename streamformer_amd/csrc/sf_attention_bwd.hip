@@ -481,7 +481,7 @@ hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s
   if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  static const int lab = getenv("SF_ATTN_BWD_LAB") ? atoi(getenv("SF_ATTN_BWD_LAB")) : 0;
+  static const int lab = SF_LAB_SWITCH("SF_ATTN_BWD_LAB");      // timing lab: phases off, results invalid (lab builds only)
   SfAttnBwdArgs b = a;
   b.lab = lab;
   hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, b);

@@ -12,6 +12,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define SF_DEVICE __device__ __forceinline__
 
+// Lab switches that DISCARD results (stores off, phases off) exist only in builds made with -DSF_LAB
+// (`python streamformer_amd/build.py --lab` -> libstreamformer_hip_lab.so, used by tools/ alone).  In the product library the
+// macro is the constant 0 and the variable name is not even compiled in (tests/test_abi.py checks the .so for such names).
+#ifdef SF_LAB
+#define SF_LAB_SWITCH(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define SF_LAB_SWITCH(name) 0
+#endif
+
 // round-to-nearest-even fp32 -> bf16: the casts lower to gfx950's v_cvt_pk_bf16_f32 (one VALU op per
 // pair instead of the 4-op integer sequence)
 SF_DEVICE unsigned int f2bf(float f) {
@@ -183,8 +192,9 @@ struct SfGemmArgs {
   // (A = bf16(x), W' = W * gamma) finishes y = rstd * (acc - mean * ln_s[n]) + bias' in its epilogue.
   float* ln_stats_out;
   const float* ln_stats; const float* ln_s; float ln_eps;
-  // ln_stats_wide = 1 (fp32-accurate mode): rows of 8 floats, one {sum x, sum x^2} pair per 256-column tile of the bf16x3 256^2
-  // kernel that produced the residual row (3 pairs + 2 pad) — ln_stats and ln_stats_out alike
+  // ln_stats_wide = 1: rows of 8 floats — ln_stats and ln_stats_out alike.  fp32-accurate mode: one {sum x, sum x^2} pair per
+  // 256-column tile of the bf16x3 256^2 kernel that produced the residual row (3 pairs + 2 pad).  bf16 mode (round 4): four pairs,
+  // one per 192-column quarter (sf_gemm_pp.hip); the 384-column panel kernel fills pairs 0 and 2 and zeroes 1 and 3.
   int ln_stats_wide;
   // small-M variant of the fold (sf_gemm_skinny.hip): ln_inkernel = 1 -> the consumer derives mean / rstd of its rows from the
   // A fragments it streams anyway (A = bf16(x), ln_s as above); no statistics buffer exists
@@ -216,6 +226,11 @@ int sf_tile_max_rows();
 int sf_infold_max_rows();                                                        // largest M of the in-kernel-statistics LayerNorm fold (skinny + tile kernels)
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip
 hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
+bool sf_gemm_pp_supported(const SfGemmArgs& a, bool split);                      // sf_gemm_pp.hip: two workgroups per CU, epilogue beside main loop
+hipError_t sf_launch_gemm_pp(const SfGemmArgs& a, hipStream_t s);
+bool sf_gemm_pipe_supported(const SfGemmArgs& a, bool split);                    // sf_gemm_pipe.hip: persistent, role-split waves, epilogue of tile k under tile k + 1
+hipError_t sf_launch_gemm_pipe(const SfGemmArgs& a, hipStream_t s);
+int sf_gemm_pipe_failed();                                                       // 1 after a bounded spin of that kernel gave up (never expected)
 
 // ------------------------------------------------------------------------------------------------
 // row-wise / elementwise kernels
@@ -245,7 +260,7 @@ hipError_t sf_launch_copy2(const float* a_src, float* a_dst, size_t na, const fl
                            const SfStreamParams* sp = nullptr);        // sp != nullptr: a_dst = sp->lhs, b_dst = sp->pooler (device reads)
 // fp32 rows -> bf16 copy + LayerNorm partial statistics {sum x, sum x^2, 0, 0} per row (stats [rows][4])
 hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo = nullptr,
-                                   bf16_t* xlo2 = nullptr);
+                                   bf16_t* xlo2 = nullptr, int wide = 0);      // wide (or xlo): stats rows of 8 floats
 // out[t*N + n, :] = pos[n, :] + time_rows[t, :]   (the additive table of the embeddings, modeling:413-457)
 hipError_t sf_launch_pos_time_table(const float* pos, const float* time_rows, float* out, int T, int N, int D, hipStream_t s);
 // gather rows: out[t,:] = table[idx[t],:]   (idx passed by value, T <= 256)

@@ -492,7 +492,7 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   const size_t wide = D > (size_t)e->Kp ? D : (size_t)e->Kp;
   w.resid = c.take<float>(M * D);
   w.te_rows = c.take<float>((size_t)T * D);
-  w.ln_stats = c.take<float>(M * (acc ? 8 : 4));      // accurate mode: one pair per 256-column tile of the producer
+  w.ln_stats = c.take<float>(M * 8);                  // rows of 8 floats in both modes (SfGemmArgs::ln_stats_wide)
   w.embed_tab = (!acc && M >= 2048) ? c.take<float>((size_t)T * N * D) : nullptr;
   w.patch_buf = (!acc && M >= 2048) ? c.take<bf16_t>(M * (size_t)e->Kp) : nullptr;
   w.xn_hi = c.take<bf16_t>(M * wide);
@@ -551,7 +551,7 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
   if (grp_rows > 0 && grp_stride == grp_rows && grp_off == 0 && !grp_off_dev) g.grp_rows = 0;   // identity remap (full clip)
   g.ln_stats = ln_stats; g.ln_s = ln_stats ? lin.ln_s : nullptr; g.ln_eps = e->cfg.layer_norm_eps;
   g.ln_stats_out = ln_stats_out;
-  g.ln_stats_wide = split ? 1 : 0;
+  g.ln_stats_wide = 1;
   if (ln_inkernel) { g.ln_inkernel = 1; g.ln_s = lin.ln_s; }
   if (epi == SF_EPI_RESID_F32) g.out_hi = out_hi;     // LN-fold producer: bf16 copy of the new residual rows
   return sf_launch_gemm(g, split, s);
@@ -704,7 +704,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     g.out_f32 = ws.resid; g.ldc = D;
     SfGemmArgs gp = g;
     gp.epi = SF_EPI_RESID_F32; gp.alpha = 1.f; gp.resid = ws.embed_tab; gp.resid_mod = T * N;
-    gp.out_hi = ws.xn_hi; gp.ln_stats_out = ws.ln_stats;
+    gp.out_hi = ws.xn_hi; gp.ln_stats_out = ws.ln_stats; gp.ln_stats_wide = 1;
     if (pm) {
       SfGemmArgs gq = gp;
       gq.out_f32 = nullptr; gq.out_lo = ws.res_lo;
@@ -739,7 +739,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const bool anyfold = fold || sfold || xm;
   const bool rplanes = pm || xm;                             // residual stream as two bf16 planes: hi = xn_hi, lo = plo
   bf16_t* plo = pm ? ws.res_lo : (xm ? ws.xn_lo : nullptr);
-  if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s));
+  if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, nullptr, nullptr, 1));
   if (!xm) plo2 = nullptr;
   if (xm) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, ws.xn_lo, plo2));      // embeddings -> planes + wide statistics
   if (sfold && (stages & 2) && !(stages & 1) && !(ready & 2)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
@@ -1289,7 +1289,7 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   // row sums of the next Linear (run_forward's `pm`); fp32 residual + bf16 copy otherwise
   static const bool planes_off = getenv("SF_DISABLE_RESID_PLANES") != nullptr;
   const bool pm = !planes_off && !acc && epi == SF_EPI_RESID_F32 && ln_fold_ok(e, M);
-  float* st = pm ? c.take<float>((size_t)M * 4) : nullptr;
+  float* st = pm ? c.take<float>((size_t)M * 8) : nullptr;
   if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
   auto go = [&]() {
     return pm ? run_linear(e, *lin, ah, al, M, epi, s, nullptr, oh, ol, nullptr, 0.f, 0, 0, 0, 0, nullptr, st, false, nullptr, 0, oh, ol)

@@ -244,6 +244,8 @@ hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
   }
   if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);
   if (sf_gemm_tile_supported(a, split)) return sf_launch_gemm_tile(a, s);
+  if (sf_gemm_pipe_supported(a, split)) return sf_launch_gemm_pipe(a, s);
+  if (sf_gemm_pp_supported(a, split)) return sf_launch_gemm_pp(a, s);
   if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
   if (a.resid_hi) return hipErrorInvalidValue;      // plane-form residual: panel kernel only

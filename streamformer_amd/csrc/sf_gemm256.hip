@@ -331,7 +331,12 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
           float ln_mu = 0.f, ln_r = 1.f;
           if (ln_fold) {
             const int mrow = min(m0 + r, p.M - 1);
-            const f32x4_t st = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 4);
+            f32x4_t st = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * (p.ln_stats_wide ? 8 : 4));
+            if (p.ln_stats_wide) {      // four pairs per row (one per 192-column quarter of the producer), fixed order
+              const f32x4_t s2 = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 8 + 4);
+              st[0] += st[2]; st[1] += st[3];
+              st[2] = s2[0] + s2[2]; st[3] = s2[1] + s2[3];
+            }
             const float invd = 1.0f / (float)K;
             ln_mu = (st[0] + st[2]) * invd;
             ln_r = rsqrtf((st[1] + st[3]) * invd - ln_mu * ln_mu + p.ln_eps);
@@ -546,7 +551,7 @@ static int g256_grid() {
 template <int BM, bool SPLIT_ONLY = false>
 static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   SfGemmArgs a = a_in;
-  if (getenv("SF_G256_LAB_NOSTORE")) a.act = 99;      // lab: main loops only (results are discarded)
+  if (SF_LAB_SWITCH("SF_G256_LAB_NOSTORE")) a.act = 99;      // lab builds only: main loops without stores (results are discarded)
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / 256);
   const size_t lds = 8 * PIECE_BYTES;
   static SfPerDeviceOnce attr_set;

@@ -263,8 +263,12 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
           s1 = wave_sum_dpp(s1);
           s2 = wave_sum_dpp(s2);
           if (elane == 0) {
-            p.ln_stats_out[(size_t)m * 4 + nh * 2 + 0] = s1;
-            p.ln_stats_out[(size_t)m * 4 + nh * 2 + 1] = s2;
+            if (p.ln_stats_wide) {      // rows of 8 floats = four pairs (sf_gemm_pp.hip writes one per 192-column quarter): this half's pair + an empty one
+              *reinterpret_cast<f32x4_t*>(p.ln_stats_out + (size_t)m * 8 + nh * 4) = (f32x4_t){s1, s2, 0.f, 0.f};
+            } else {
+              p.ln_stats_out[(size_t)m * 4 + nh * 2 + 0] = s1;
+              p.ln_stats_out[(size_t)m * 4 + nh * 2 + 1] = s2;
+            }
           }
         }
       }

@@ -378,7 +378,7 @@ static hipError_t tl_go(const SfGemmArgs& a, hipStream_t s) {
   const int tiles_n = a.N / C::BN, tiles_m = (a.M + C::BM - 1) / C::BM;
   const int ntiles = tiles_n * tiles_m;
   const int per_xcd = (ntiles + 7) / 8;
-  static const int lab_env = getenv("SF_TILE_LAB") ? atoi(getenv("SF_TILE_LAB")) : 0;
+  static const int lab_env = SF_LAB_SWITCH("SF_TILE_LAB");      // lab builds only
   hipLaunchKernelGGL((sf_gemm_tile_kernel<MT, NT, WM, WN, BK, STAGES, EPI, LNF>), dim3(per_xcd * 8), dim3(TL_THREADS), C::LDS_BYTES, s,
                      a, tiles_n, ntiles, per_xcd, lab_env);
   return hipGetLastError();

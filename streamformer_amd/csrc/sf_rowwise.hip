@@ -195,7 +195,7 @@ hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hip
 // ------------------------------------------------------------------------------------------------
 // LN-fold entry: bf16 copy of the rows + {sum x, sum x^2} (used once per forward, on the embeddings)
 __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
-                                                               bf16_t* __restrict__ xlo, bf16_t* __restrict__ xlo2, float* __restrict__ stats, int rows, int D) {
+                                                               bf16_t* __restrict__ xlo, bf16_t* __restrict__ xlo2, float* __restrict__ stats, int rows, int D, int wide) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -218,16 +218,16 @@ __global__ __launch_bounds__(256) void sf_rowstats_cast_kernel(const float* __re
   }
   s1 = wave_sum_dpp(s1);
   s2 = wave_sum_dpp(s2);
-  if (lane == 0) {          // xlo: the wide rows of the accurate mode ([8]: this pair + two empty ones)
-    *reinterpret_cast<f32x4_t*>(stats + (size_t)row * (xlo ? 8 : 4)) = (f32x4_t){s1, s2, 0.f, 0.f};
-    if (xlo) *reinterpret_cast<f32x4_t*>(stats + (size_t)row * 8 + 4) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if (lane == 0) {          // wide rows ([8]: this pair + empty ones): the accurate mode, and the bf16 mode's four-pair layout
+    *reinterpret_cast<f32x4_t*>(stats + (size_t)row * (wide ? 8 : 4)) = (f32x4_t){s1, s2, 0.f, 0.f};
+    if (wide) *reinterpret_cast<f32x4_t*>(stats + (size_t)row * 8 + 4) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
 }
 
-hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo, bf16_t* xlo2) {
+hipError_t sf_launch_rowstats_cast(const float* x, bf16_t* xb, float* stats, int rows, int D, hipStream_t s, bf16_t* xlo, bf16_t* xlo2, int wide) {
   if (rows <= 0) return hipSuccess;
   if (D % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, xlo, xlo2, stats, rows, D);
+  hipLaunchKernelGGL(sf_rowstats_cast_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xb, xlo, xlo2, stats, rows, D, (wide || xlo) ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -35,3 +35,12 @@ def test_create_validates_config_without_gpu():
     bad = nat.SfConfig(224, 16, 3, 16, 768, 12, 8, 3072, 0, 1, 1, 0, 1e-6)   # head_dim 96
     assert nat.lib.sf_create(ctypes.byref(bad), 0, ctypes.byref(h)) == nat.SF_ERR_INVALID
     assert b"head_dim" in nat.lib.sf_last_error()
+
+
+def test_product_library_holds_no_result_discarding_lab_switches():
+    """timing switches that skip stores / phases are compiled in only with -DSF_LAB (build.py --lab); the product
+    .so must not even contain their names."""
+    import streamformer_amd._native as nat
+    blob = open(os.path.join(os.path.dirname(nat.LIB_PATH), "libstreamformer_hip.so"), "rb").read()
+    names = set(re.findall(rb"SF_[A-Z0-9_]*LAB[A-Z0-9_]*", blob))
+    assert not names, f"lab switches compiled into the product library: {sorted(names)}"
