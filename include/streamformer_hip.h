@@ -152,6 +152,12 @@ int sf_stream_workspace_bytes(sf_encoder* enc, const sf_cache* cache, int T_new,
 int sf_forward_stream(sf_encoder* enc, sf_cache* cache, const void* pixels_dev, int pixel_dtype,
                       int T_new, float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
                       const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
+/* The same call with output_attentions (timesformer_encoder.py:494, 557, 633, 659, 720-754): attentions_dev receives the
+ * spatial attention probabilities of the NEW frames, [L, B * T_new, heads, N, N] fp32 (N <= 224), as sf_forward_attentions
+ * returns them for whole clips.  Runs the launches eagerly (no graph replay).                                            */
+int sf_forward_stream_attentions(sf_encoder* enc, sf_cache* cache, const void* pixels_dev, int pixel_dtype, int T_new,
+                                 float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev, float* attentions_dev,
+                                 const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 
 /* ---- single operators (each is one kernel of the path; used by the parity tests) ----------- */
 /* nn.LayerNorm(D, eps) rows (modeling:860-865,878-880,1251): x fp32 [rows,D] -> y fp32 [rows,D] */
@@ -240,6 +246,13 @@ int sf_trainer_workspace_bytes(const sf_trainer* tr, int B, int T, size_t* out);
  * The backward of a forward applies the factors that forward used.  NULL = none (eval, or drop_path_rate 0).  The array is
  * caller-owned and must stay valid until the matching backward has run.                                                        */
 int sf_trainer_set_drop_path(sf_trainer* tr, const float* scales_dev, int B, int T);
+/* Non-finite guard of the optimizer step (tools/finetune_tools.py:533-541 stops the run on a non-finite loss; the GradScaler of
+ * utils.py:515-551 skips a step whose gradients hold inf / NaN).  flag_dev = DEVICE int32[2], caller-owned and zero-initialised:
+ * every sf_trainer_adamw_step that follows checks sum g^2 of the gradient (and *loss_dev, a device float, when not NULL) ON THE
+ * DEVICE; if either is inf / NaN the update is skipped as a whole (parameters and moments untouched, gradients still cleared
+ * when zero_grads) and flag_dev = {1 (sticky), number of skipped steps}.  No host synchronisation: the caller reads the flag at
+ * its next host touch.  flag_dev = NULL switches the guard off.                                                              */
+int sf_trainer_set_nonfinite_guard(sf_trainer* tr, int32_t* flag_dev, const float* loss_dev);
 /* forward with every activation the backward needs kept in the workspace                         */
 int sf_trainer_forward(sf_trainer* tr, const void* pixels_dev, int pixel_dtype, int B, int T,
                        float* last_hidden_dev, float* pooler_dev, void* workspace_dev,

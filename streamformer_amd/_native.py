@@ -61,6 +61,7 @@ SIGNATURES = {
     "sf_cache_destroy": (None, [_P]),
     "sf_stream_workspace_bytes": (_I, [_P, _P, _I, C.POINTER(_SZ)]),
     "sf_forward_stream": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sf_forward_stream_attentions": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sf_op_linear": (_I, [_P, _P, _P, _P, _F, _I, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "sf_op_linear_workspace_bytes": (_SZ, [_I, _I, _I]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "sf_trainer_backward": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
     "sf_trainer_adamw_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P, _F, _I, _P]),
     "sf_trainer_set_drop_path": (_I, [_P, _P, _I, _I]),
+    "sf_trainer_set_nonfinite_guard": (_I, [_P, _P, _P]),
     "sf_trainer_set_extra_steps": (_I, [_P, C.POINTER(C.c_int32), _I]),
     "sf_trainer_grad_sumsq": (_I, [_P, _P, _P, _P]),
     "sf_op_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P]),

@@ -36,8 +36,9 @@ class TrainEngine:
         self.module_token = None
         named = module._named
         lora = module._lora
-        # frozen LoRA base (the shipped recipe, modeling:1471-1484): the library then skips those weight-gradient GEMMs
-        freeze = lora and not any(p.requires_grad for k, p in named.items() if _is_spatial_base(k))
+        # frozen spatial base weights (frozen_spatial(), modeling:1471-1484, with or without LoRA): the library then skips those
+        # weight-gradient GEMMs instead of computing gradients that backward() would throw away
+        freeze = self._frozen_spatial(module)
         sd = {k: p.detach() for k, p in named.items()}
         self.tr = StreamformerTrainer(module.config, sd, [], freeze_spatial=freeze, device=module.device, with_optimizer=False)
         self.freeze = freeze
@@ -47,11 +48,13 @@ class TrainEngine:
         self.signature = self._signature(module)
 
     @staticmethod
+    def _frozen_spatial(module) -> bool:
+        base = [p for k, p in module._named.items() if _is_spatial_base(k)]
+        return bool(base) and not any(p.requires_grad for p in base)
+
+    @staticmethod
     def _signature(module):
-        named = module._named
-        lora = module._lora
-        freeze = lora and not any(p.requires_grad for k, p in named.items() if _is_spatial_base(k))
-        return (module.device, lora, freeze, len(named))
+        return (module.device, module._lora, TrainEngine._frozen_spatial(module), len(module._named))
 
     def upload(self, module) -> None:
         """Module parameters -> flat buffer + bf16 operand refresh, only when something changed."""
@@ -73,6 +76,19 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, module, pixel_values, *params):
         eng: TrainEngine = module._train_engine()
         eng.upload(module)
+        if pixel_values.dtype == torch.uint8:
+            # the training forward normalises raw uint8 frames with the default mean = std = 0.5, rescale 1 / 255; a module whose
+            # image processor differs would see different inputs in train() and eval(): apply the module's own
+            # normalisation on the way in instead
+            ip = getattr(module, "image_processor", None)
+            mean = tuple(float(m) for m in getattr(ip, "image_mean", (0.5, 0.5, 0.5))) if ip is not None else (0.5, 0.5, 0.5)
+            std = tuple(float(m) for m in getattr(ip, "image_std", (0.5, 0.5, 0.5))) if ip is not None else (0.5, 0.5, 0.5)
+            rescale = float(getattr(ip, "rescale_factor", 1.0 / 255.0)) if ip is not None else 1.0 / 255.0
+            if any(abs(m - 0.5) > 1e-12 for m in mean) or any(abs(m - 0.5) > 1e-12 for m in std) or abs(rescale - 1.0 / 255.0) > 1e-12:
+                c = pixel_values.shape[2]
+                mt = torch.tensor(mean[:c], dtype=torch.float32, device=pixel_values.device).view(1, 1, c, 1, 1)
+                st = torch.tensor(std[:c], dtype=torch.float32, device=pixel_values.device).view(1, 1, c, 1, 1)
+                pixel_values = (pixel_values.to(torch.float32) * rescale - mt) / st
         lhs, pool = eng.tr.forward(pixel_values)
         eng.forward_id += 1
         ctx.eng, ctx.fid = eng, eng.forward_id

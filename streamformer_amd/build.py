@@ -16,8 +16,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamformer_hip.so")
-SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_pp.hip", "sf_gemm_pipe.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip",
+SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
+# lab library only (build.py --lab): the two epilogue-overlap experiments of round 4, measured slower than the panel kernel
+LAB_SOURCES = ["sf_gemm_pp.hip", "sf_gemm_pipe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -42,6 +44,7 @@ def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
     objdir = os.path.join(CSRC, "build_lab" if lab else "build")
     lib_path = os.path.join(HERE, "libstreamformer_hip_lab.so") if lab else LIB
     flags = FLAGS + (["-DSF_LAB"] if lab else [])
+    sources = SOURCES + (LAB_SOURCES if lab else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "sf_train.h"), os.path.join(CSRC, "sf_internal.h"),
                os.path.join(os.path.dirname(HERE), "include", "streamformer_hip.h")]
@@ -56,8 +59,8 @@ def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
             subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(compile_one, sources))
     if force or _stale(lib_path, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
         if verbose:

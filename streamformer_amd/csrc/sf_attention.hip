@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) split_bf(o[j] * inv, hb[j], lb[j]);
     *reinterpret_cast<u32x4_t*>(p.ctx_hi + o_off) = (u32x4_t){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
-    if (F32) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = (u32x4_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+    if (F32 || p.ctx_lo) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = (u32x4_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
   }
 }
 

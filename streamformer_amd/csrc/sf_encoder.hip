@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#define SF_ABI_VERSION 3
+#define SF_ABI_VERSION 4
 static const int kLoraRank = 32;  // modeling:1280-1281
 
 // ------------------------------------------------------------------------------------------------
@@ -290,9 +290,9 @@ static int dev_upload(sf_encoder* e, const std::vector<T>& h, T** out) {
 }
 
 static int upload_linear(sf_encoder* e, const std::vector<float>& w, const std::vector<float>* bias, int N,
-                         int K, DevLinear* out) {
+                         int K, DevLinear* out, bool force_split = false) {
   std::vector<uint16_t> hi(w.size()), lo;
-  const bool split = e->compute == SF_COMPUTE_BF16X3;
+  const bool split = force_split || e->compute == SF_COMPUTE_BF16X3;     // force_split: the pooling head's small Linears keep the lo plane in bf16 mode too
   if (split) lo.resize(w.size());
   for (size_t i = 0; i < w.size(); ++i) {
     hi[i] = h_f2bf(w[i]);
@@ -442,9 +442,9 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     std::vector<float> bkv(b.begin() + D, b.end());
     TRY(upload_linear(e, wkv, &bkv, 2 * D, D, &e->head_kv));
   }
-  TRY(upload_linear(e, H("head.attention.out_proj.weight"), Hopt("head.attention.out_proj.bias"), D, D, &e->head_out));
-  TRY(upload_linear(e, H("head.mlp.fc1.weight"), Hopt("head.mlp.fc1.bias"), I, D, &e->head_fc1));
-  TRY(upload_linear(e, H("head.mlp.fc2.weight"), Hopt("head.mlp.fc2.bias"), D, I, &e->head_fc2));
+  TRY(upload_linear(e, H("head.attention.out_proj.weight"), Hopt("head.attention.out_proj.bias"), D, D, &e->head_out, true));
+  TRY(upload_linear(e, H("head.mlp.fc1.weight"), Hopt("head.mlp.fc1.bias"), I, D, &e->head_fc1, true));
+  TRY(upload_linear(e, H("head.mlp.fc2.weight"), Hopt("head.mlp.fc2.bias"), D, I, &e->head_fc2, true));
 #undef TRY
   e->finalized = true;
   e->generation = next_generation();   // caches created against an earlier packing are refused from here on
@@ -510,12 +510,12 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.qkv = c.take<char>(M * 3 * D * (acc ? 4 : 2));
   w.tqkv = need_tqkv ? (void*)c.take<char>(M * 3 * D * (acc ? 4 : 2)) : nullptr;
   w.attn_out = c.take<float>(F * D);
-  w.pc_hi = c.take<bf16_t>(F * D);
-  w.pc_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
+  w.pc_hi = c.take<bf16_t>(F * D);          // the pooling head's one-row-per-frame tensors keep hi + lo planes in both modes
+  w.pc_lo = c.take<bf16_t>(F * D);
   w.hn_hi = c.take<bf16_t>(F * D);
-  w.hn_lo = acc ? c.take<bf16_t>(F * D) : nullptr;
+  w.hn_lo = c.take<bf16_t>(F * D);
   w.hm_hi = c.take<bf16_t>(F * I);
-  w.hm_lo = acc ? c.take<bf16_t>(F * I) : nullptr;
+  w.hm_lo = c.take<bf16_t>(F * I);
   w.res_bf = (!acc && M <= (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
   w.res_lo = (!acc && M > (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
   w.res_lo2 = (acc && M >= 2048) ? c.take<bf16_t>(M * D) : nullptr;
@@ -534,10 +534,10 @@ static hipError_t run_linear(const sf_encoder* e, const DevLinear& lin, const bf
                              int grp_stride = 0, int grp_off = 0, const float* ln_stats = nullptr,
                              float* ln_stats_out = nullptr, bool ln_inkernel = false, const int* grp_off_dev = nullptr,
                              int grp_off_scale = 0, const bf16_t* resid_hi = nullptr, const bf16_t* resid_lo = nullptr,
-                             bf16_t* resid_lo2 = nullptr) {
+                             bf16_t* resid_lo2 = nullptr, bool force_split = false) {
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
-  const bool split = e->compute == SF_COMPUTE_BF16X3;
+  const bool split = force_split || e->compute == SF_COMPUTE_BF16X3;
   g.a_hi = a_hi; g.a_lo = split ? a_lo : nullptr;
   g.w_hi = lin.w_hi; g.w_lo = split ? lin.w_lo : nullptr;
   g.bias = lin.bias;
@@ -813,6 +813,8 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   else      // stage 8: the head alone on tokens the caller has already normalised (model.head(x))
     HIP_TRY(sf_launch_split(ws.resid, ws.xn_hi, acc ? ws.xn_lo : nullptr, (size_t)M * D, s));
   if (pooler) {
+    static const bool head_acc_off = getenv("SF_DISABLE_HEAD_ACC") != nullptr;       // A/B switch
+    bool hacc = !acc && !head_acc_off;
     HIP_TRY(run_linear(e, e->head_kv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
     static const bool pool_decode_off = getenv("SF_DISABLE_POOL_DECODE") != nullptr;
     if (N <= 256 && !pool_decode_off) {
@@ -824,15 +826,22 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.k = ws.qkv; a.v = (char*)ws.qkv + (size_t)D * esz;
       a.in_is_f32 = acc; a.row_pitch_q = 0; a.row_pitch_kv = 2 * D; a.heads = heads; a.scale = 1.0f;
       a.N = 1; a.B = F; a.Tq = 1; a.Tk = N; a.Tcap = N; a.t_past = N; a.causal = 0; a.Tq_cap = 0; a.q_t0 = 0;
-      a.ctx_hi = ws.pc_hi; a.ctx_lo = ws.pc_lo; a.D = D;
+      a.ctx_hi = ws.pc_hi; a.ctx_lo = (acc || hacc) ? ws.pc_lo : nullptr; a.D = D;
       HIP_TRY(sf_launch_temporal_attention(a, acc, s));
     } else {
+      hacc = false;            // sf_pool_attn_kernel writes the lo plane in the accurate mode only
       HIP_TRY(sf_launch_pool_attention(e->head_q, ws.qkv, acc, 2 * D, ws.pc_hi, ws.pc_lo, F, N, heads, D, s));
     }
-    HIP_TRY(run_linear(e, e->head_out, ws.pc_hi, ws.pc_lo, F, SF_EPI_F32, s, ws.attn_out, nullptr, nullptr));
-    HIP_TRY(sf_launch_layernorm(ws.attn_out, e->head_ln.g, e->head_ln.b, nullptr, ws.hn_hi, ws.hn_lo, F, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, e->head_fc1, ws.hn_hi, ws.hn_lo, F, SF_EPI_ACT_BF16, s, nullptr, ws.hm_hi, ws.hm_lo));
-    HIP_TRY(run_linear(e, e->head_fc2, ws.hm_hi, ws.hm_lo, F, SF_EPI_RESID_F32, s, pooler, nullptr, nullptr, ws.attn_out, 1.f));
+    // one row per frame from here on (F rows: 0.03 % of the forward's FLOPs): three bf16 products per operand pair in BOTH modes —
+    // pooler_output is the product both loss heads and the feature dumps consume, and the bf16 mode's own head added 1.5e-2 of
+    // max-abs error to it on top of what the encoder's tokens carry (tools/pool_err.py)
+    HIP_TRY(run_linear(e, e->head_out, ws.pc_hi, ws.pc_lo, F, SF_EPI_F32, s, ws.attn_out, nullptr, nullptr, nullptr, 1.f, 0, 0, 0, 0, nullptr, nullptr,
+                       false, nullptr, 0, nullptr, nullptr, nullptr, hacc));
+    HIP_TRY(sf_launch_layernorm(ws.attn_out, e->head_ln.g, e->head_ln.b, nullptr, ws.hn_hi, (acc || hacc) ? ws.hn_lo : nullptr, F, D, c.layer_norm_eps, s));
+    HIP_TRY(run_linear(e, e->head_fc1, ws.hn_hi, ws.hn_lo, F, SF_EPI_ACT_BF16, s, nullptr, ws.hm_hi, ws.hm_lo, nullptr, 1.f, 0, 0, 0, 0, nullptr, nullptr,
+                       false, nullptr, 0, nullptr, nullptr, nullptr, hacc));
+    HIP_TRY(run_linear(e, e->head_fc2, ws.hm_hi, ws.hm_lo, F, SF_EPI_RESID_F32, s, pooler, nullptr, nullptr, ws.attn_out, 1.f, 0, 0, 0, 0, nullptr, nullptr,
+                       false, nullptr, 0, nullptr, nullptr, nullptr, hacc));
   }
   return SF_OK;
 }
@@ -1005,9 +1014,9 @@ extern "C" int sf_stream_workspace_bytes(sf_encoder* e, const sf_cache* c, int T
   *out = carve(e, nullptr, c->B, T_new, c->N, false).bytes;
   return SF_OK;
 }
-extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels, int pixel_dtype, int T_new,
-                                 float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev, void* workspace,
-                                 size_t workspace_bytes, sf_stream stream) {
+static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, int pixel_dtype, int T_new,
+                               float* last_hidden, float* pooler, float* hidden_states, float* attentions, const float* pos_dev,
+                               void* workspace, size_t workspace_bytes, sf_stream stream) {
   if (!e || !c || c->enc != e) return set_err(SF_ERR_INVALID, "cache does not belong to this encoder");
   // a handle address can be reused after sf_destroy, and sf_finalize_weights may have changed the compute mode (cache element
   // size) or the device: the generation stamp tells a cache of an earlier packing from a current one
@@ -1045,10 +1054,12 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
   static const bool graphs_off = getenv("SF_DISABLE_STREAM_GRAPH") != nullptr;
-  const bool use_graph = !graphs_off && !hidden_states && cap == hipStreamCaptureStatusNone && T_new < 256 && c->len < 65536;
+  if (attentions && N > 224)
+    return set_err(SF_ERR_INVALID, "attention probabilities are materialised for <= 224 patches per frame (got %d)", N);
+  const bool use_graph = !graphs_off && !hidden_states && !attentions && cap == hipStreamCaptureStatusNone && T_new < 256 && c->len < 65536;
   if (!use_graph) {
     rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,
-                     c->qkv.data(), c->cap, c->len, true, s, nullptr, 7, 0, -1, 0, nullptr, pos);
+                     c->qkv.data(), c->cap, c->len, true, s, attentions, 7, 0, -1, 0, nullptr, pos);
     if (rc == SF_OK) c->len += T_new;
     return rc;
   }
@@ -1132,6 +1143,22 @@ extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels,
   }
   c->len += T_new;
   return SF_OK;
+}
+
+extern "C" int sf_forward_stream(sf_encoder* e, sf_cache* c, const void* pixels, int pixel_dtype, int T_new,
+                                 float* last_hidden, float* pooler, float* hidden_states, const float* pos_dev, void* workspace,
+                                 size_t workspace_bytes, sf_stream stream) {
+  return forward_stream_impl(e, c, pixels, pixel_dtype, T_new, last_hidden, pooler, hidden_states, nullptr, pos_dev, workspace, workspace_bytes,
+                             stream);
+}
+// output_attentions while streaming (timesformer_encoder.py:494, 557, 633, 659, 720-754): the spatial attention probabilities of
+// the NEW frames, [L, B * T_new, heads, N, N] fp32, as sf_forward_attentions returns them for whole clips
+extern "C" int sf_forward_stream_attentions(sf_encoder* e, sf_cache* c, const void* pixels, int pixel_dtype, int T_new,
+                                            float* last_hidden, float* pooler, float* hidden_states, float* attentions,
+                                            const float* pos_dev, void* workspace, size_t workspace_bytes, sf_stream stream) {
+  if (!attentions) return set_err(SF_ERR_INVALID, "null attentions buffer");
+  return forward_stream_impl(e, c, pixels, pixel_dtype, T_new, last_hidden, pooler, hidden_states, attentions, pos_dev, workspace,
+                             workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

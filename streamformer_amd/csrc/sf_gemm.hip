@@ -244,8 +244,10 @@ hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
   }
   if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);
   if (sf_gemm_tile_supported(a, split)) return sf_launch_gemm_tile(a, s);
+#ifdef SF_LAB      // round-4 epilogue-overlap experiments (profiles/r04_panel_overlap_lab.txt): lab library only, behind SF_PANEL_PIPE / SF_PANEL_PP
   if (sf_gemm_pipe_supported(a, split)) return sf_launch_gemm_pipe(a, s);
   if (sf_gemm_pp_supported(a, split)) return sf_launch_gemm_pp(a, s);
+#endif
   if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
   if (a.resid_hi) return hipErrorInvalidValue;      // plane-form residual: panel kernel only

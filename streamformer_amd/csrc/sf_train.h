@@ -145,6 +145,11 @@ struct SfAdamWArgs {
   // torch.optim.AdamW keeps `step` per parameter and skips parameters without a gradient
   int extra_seg0, n_extra;                     // n_extra = 0: no per-slot handling
   int extra_steps[64];
+  // non-finite guard (tools/finetune_tools.py:533-541 stops on a non-finite loss; utils.py:515-551 skips the step on inf grads):
+  // guard_flag != nullptr -> the kernel reads sum g^2 (guard_sumsq) and, when given, the loss scalar; if either is inf / NaN the
+  // whole update is skipped (p, m, v untouched; g still cleared when zero_grads) and guard_flag = {1 (sticky), skipped steps + 1}.
+  // Nothing synchronises with the host: the flag is read at the caller's next host touch.
+  int* guard_flag; const float* guard_sumsq; const float* guard_loss;
 };
 hipError_t sf_launch_adamw(const SfAdamWArgs& a, hipStream_t s);
 // out[0] = sum g^2 (deterministic two-stage); partial >= 1024 floats

@@ -73,6 +73,9 @@ struct sf_trainer {
   int n_extra = 0, extra_seg0 = 0;  // the scalar slots are the last n_extra trainable segments
   bool extra_steps_set = false;
   int extra_steps[64] = {};
+  int* guard_flag = nullptr;          // non-finite guard (sf_trainer_set_nonfinite_guard): device int32[2], caller-owned
+  const float* guard_loss = nullptr;  // optional device loss scalar checked next to the gradient's sum of squares
+  float* guard_sumsq = nullptr;       // library-owned scalar the guard's own sum-of-squares pass writes
 };
 
 static int add_param(sf_trainer* t, const std::string& name, std::initializer_list<int64_t> shape, bool trainable) {
@@ -295,6 +298,7 @@ extern "C" void sf_trainer_destroy(sf_trainer* t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   free_trainer_device(t);
+  if (t->guard_sumsq) (void)hipFree(t->guard_sumsq);
   delete t;
 }
 
@@ -865,7 +869,24 @@ extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, float* grads,
   a.n_extra = t->extra_steps_set ? t->n_extra : 0;
   for (int i = 0; i < 64; ++i) a.extra_steps[i] = t->extra_steps[i];
   if (grad_sumsq_dev && !(clip_norm > 0.f)) return sf_set_err(SF_ERR_INVALID, "clip_norm must be positive");
+  a.guard_flag = t->guard_flag; a.guard_sumsq = nullptr; a.guard_loss = t->guard_loss;
+  if (t->guard_flag) {
+    // the clip pass already holds sum g^2 of this gradient; otherwise one deterministic pass over the trainable prefix (~0.1 ms)
+    if (grad_sumsq_dev) a.guard_sumsq = grad_sumsq_dev;
+    else {
+      if (!t->guard_sumsq) HIP_TRY(hipMalloc((void**)&t->guard_sumsq, sizeof(float)));
+      HIP_TRY(sf_launch_sumsq(grads, t->n_train, t->guard_sumsq, t->red_partial, (hipStream_t)stream));
+      a.guard_sumsq = t->guard_sumsq;
+    }
+  }
   HIP_TRY(sf_launch_adamw(a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_set_nonfinite_guard(sf_trainer* t, int32_t* flag_dev, const float* loss_dev) {
+  if (!t) return sf_set_err(SF_ERR_INVALID, "null argument");
+  t->guard_flag = (int*)flag_dev;
+  t->guard_loss = flag_dev ? loss_dev : nullptr;
   return SF_OK;
 }
 

@@ -591,6 +591,17 @@ __global__ __launch_bounds__(256) void sf_adamw_kernel(SfAdamWArgs a) {
   const size_t nv = a.n >> 2;
   float gscale = a.grad_scale;
   if (a.clip_sumsq) gscale *= fminf(1.0f, a.clip_norm / (sqrtf(a.clip_sumsq[0]) * a.grad_scale + 1e-6f));
+  if (a.guard_flag) {        // every thread reads the same two scalars: a uniform, deterministic decision
+    bool bad = !(a.guard_sumsq[0] < __builtin_huge_valf());                       // inf or NaN
+    if (a.guard_loss) bad = bad || !(fabsf(a.guard_loss[0]) < __builtin_huge_valf());
+    if (bad) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { a.guard_flag[0] = 1; a.guard_flag[1] += 1; }
+      if (a.zero_grads)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256)
+          reinterpret_cast<f32x4_t*>(a.g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
     const size_t e = i << 2;                     // segments start on multiples of 64 elements
     int lo = 0, hi = a.nseg - 1;                 // first segment with seg_end > e

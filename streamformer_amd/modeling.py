@@ -764,8 +764,6 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
         output_attentions = c.output_attentions if output_attentions is None else output_attentions
         output_hidden_states = c.output_hidden_states if output_hidden_states is None else output_hidden_states
         return_dict = c.use_return_dict if return_dict is None else return_dict
-        if output_attentions and (use_cache or past_key_values is not None):
-            raise NotImplementedError("output_attentions with use_cache")
         if pixel_values.dim() != 5:
             raise ValueError(f"pixel_values must be (B, T, C, H, W), got {tuple(pixel_values.shape)}")
         B, T, C_, H, W = pixel_values.shape
@@ -818,15 +816,24 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
                 ch = cache._require()
                 if cache._model() is not self:
                     raise ValueError("past_key_values belongs to another model")
-                if cache_position is not None and int(cache_position[0]) != cache.frames_seen:
+                # a sliding-window cache saturates get_seq_length() at its capacity while frames_seen keeps counting: an HF-style
+                # caller that derives cache_position from get_seq_length() is as right as one that counts frames
+                if cache_position is not None and int(cache_position[0]) not in (cache.frames_seen, cache.get_seq_length()):
                     raise ValueError("cache_position must continue the cache (vqa_enc:1340-1349)")
                 if (cache.batch, cache.H, cache.W) != (B, H, W):
                     raise ValueError("past_key_values was created for a different batch size / resolution")
                 nat.check(nat.lib.sf_stream_workspace_bytes(self._handle, ch, T, nat.C.byref(nbytes)))
                 ws = self._workspace(("s", B, T, H, W, skey), nbytes.value)
-                nat.check(nat.lib.sf_forward_stream(self._handle, ch, x.data_ptr(), _TORCH2SF[x.dtype], T,
-                                                    lhs.data_ptr(), pool.data_ptr(), nat.ptr(hs), nat.ptr(pos), ws.data_ptr(),
-                                                    ws.numel(), stream))
+                att = None
+                if output_attentions:            # spatial probabilities of the new frames (timesformer_encoder.py:494, 557, 720-754)
+                    att = torch.empty(L, B * T, c.num_attention_heads, N, N, dtype=torch.float32, device=dev)
+                    nat.check(nat.lib.sf_forward_stream_attentions(self._handle, ch, x.data_ptr(), _TORCH2SF[x.dtype], T,
+                                                                   lhs.data_ptr(), pool.data_ptr(), nat.ptr(hs), att.data_ptr(),
+                                                                   nat.ptr(pos), ws.data_ptr(), ws.numel(), stream))
+                else:
+                    nat.check(nat.lib.sf_forward_stream(self._handle, ch, x.data_ptr(), _TORCH2SF[x.dtype], T,
+                                                        lhs.data_ptr(), pool.data_ptr(), nat.ptr(hs), nat.ptr(pos), ws.data_ptr(),
+                                                        ws.numel(), stream))
             else:
                 nat.check(nat.lib.sf_workspace_bytes(self._handle, B, T, H, W, nat.C.byref(nbytes)))
                 ws = self._workspace(("f", B, T, H, W, skey), nbytes.value)
@@ -846,10 +853,11 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
             hidden = tuple(cast(hs[i]).permute(0, 2, 1, 3).reshape(B, N * T, D) for i in range(L + 1))
         lhs, pool = cast(lhs), cast(pool)
         if streaming:
+            attentions = tuple(att[i] for i in range(L)) if att is not None else None
             if not return_dict:
-                return (lhs,) + ((hidden,) if hidden is not None else ()) + (cache,)
+                return (lhs,) + ((hidden,) if hidden is not None else ()) + ((attentions,) if attentions is not None else ()) + (cache,)
             return BaseModelOutputWithPast(lhs, past_key_values=cache if use_cache or past_key_values is not None else None,
-                                           hidden_states=hidden, pooler_output=pool)
+                                           hidden_states=hidden, attentions=attentions, pooler_output=pool)
         attentions = tuple(att[i] for i in range(L)) if att is not None else None    # spatial probabilities per layer
         if not return_dict:
             return (lhs,) + ((hidden,) if hidden is not None else ()) + ((attentions,) if attentions is not None else ())

@@ -101,7 +101,7 @@ class StreamformerTrainer:
                  freeze_spatial: bool = True, device="cuda", lr: float = 1e-3, weight_decay: float = 0.05,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_mb: float = 64.0,
                  grad_reduce_dtype: str = "fp32", collectives_at_world_1: bool = False, with_optimizer: bool = True,
-                 drop_path_seed: int = 0):
+                 drop_path_seed: int = 0, nonfinite_guard: bool = True, task_sync_check: str = "first"):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamformerTrainer needs an AMD GPU: the training step runs only on the HIP library")
         if config.hidden_act not in _ACT:
@@ -136,6 +136,14 @@ class StreamformerTrainer:
         # all-gather is the identity), which is how the RCCL branches get executed and tested on a one-GPU box
         self._collectives = dist_on and (self.world > 1 or bool(collectives_at_world_1))
         self.comm_enabled = True            # bench.py switches the gradient all-reduce off to measure its exposed time
+        # every rank must run the SAME task in a micro-step (the reference's sampler guarantees it, sampler.py:218-337): a
+        # retrieval rank issues the caption all-gather, a localization rank does not, and mismatched collectives hang.
+        # "first": verify the first micro-step of this trainer (one tiny all-gather + host read), "always": every micro-step
+        # (debug), "never": trust the caller.
+        if task_sync_check not in ("first", "always", "never"):
+            raise ValueError("task_sync_check must be 'first', 'always' or 'never'")
+        self.task_sync_check = task_sync_check
+        self._task_checked = False
         c = config
         sc = nat.SfConfig(c.image_size, c.patch_size, c.num_channels, c.num_frames, c.hidden_size, c.num_hidden_layers,
                           c.num_attention_heads, c.intermediate_size, _ACT[c.hidden_act], int(c.qkv_bias),
@@ -174,6 +182,10 @@ class StreamformerTrainer:
         self.exp_avg = torch.zeros(self.n_train, dtype=torch.float32, device=dev) if with_optimizer else None
         self.exp_avg_sq = torch.zeros(self.n_train, dtype=torch.float32, device=dev) if with_optimizer else None
         self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
+        # non-finite guard (tools/finetune_tools.py:533-541, utils.py:515-551): checked ON THE DEVICE inside the optimizer
+        # kernel — {sticky flag, skipped steps}; the host looks at it only in check_finite() / at checkpoints
+        self._guard = torch.zeros(2, dtype=torch.int32, device=dev) if nonfinite_guard else None
+        self._last_loss: Optional[torch.Tensor] = None
         self.step_count = 0
         self.micro = 0
         # torch.optim.AdamW keeps `step` per parameter and skips parameters whose grad is None: a head whose task was not
@@ -300,8 +312,25 @@ class StreamformerTrainer:
         and every head keeps its own.  Files written before round 3 (no ids for the wrapper's scalars) still load."""
         names = [n for g in self._optimizer_groups().values() for n in g]
         n_ids = sum(len(g["params"]) for g in osd["param_groups"])
-        if n_ids == len(names) - 2:                                 # round-2 layout of this trainer
-            names = [n for n in names if n not in self._WRAPPER_SCALARS]
+        # Which enumeration the file uses is decided by what the file SAYS, not by a count that a reference checkpoint with one
+        # task head fewer would also match (ADVICE r3): files of this trainer carry "param_names"; a file without them is a
+        # reference optimizer.state_dict() (wrapper scalars included) unless it is exactly the round-2 layout of this trainer,
+        # which had no ids for the wrapper's scalars AND no "param_names".
+        stored = osd.get("param_names")
+        if stored is not None:
+            if len(stored) != n_ids:
+                raise ValueError(f"optimizer state lists {len(stored)} parameter names for {n_ids} ids")
+            legacy = not any(n in self._WRAPPER_SCALARS for n in stored)
+            want = [n for n in names if n not in self._WRAPPER_SCALARS] if legacy else names
+            if len(stored) != len(want):
+                raise ValueError(f"optimizer state covers {len(stored)} parameters, this trainer enumerates {len(want)}")
+            # head names of a reference-side file need not match this trainer's: compare everything but the task-head entries
+            diff = [(a, b) for a, b in zip(stored, want) if a != b and not (a.startswith("task_heads.") and b.startswith("task_heads."))]
+            if diff:
+                raise ValueError(f"optimizer state was written for a different parameter enumeration, e.g. {diff[0][0]!r} where this trainer has {diff[0][1]!r}")
+            names = want
+        elif n_ids == len(names) - 2 and self._round2_layout_matches(osd, [n for n in names if n not in self._WRAPPER_SCALARS]):
+            names = [n for n in names if n not in self._WRAPPER_SCALARS]      # round-2 file of this trainer
         elif n_ids != len(names):
             raise ValueError(f"optimizer state covers {n_ids} parameters, this trainer's reference-side enumeration has {len(names)} "
                              f"(2 wrapper scalars + {len(names) - 2} trainable)")
@@ -342,9 +371,21 @@ class StreamformerTrainer:
         if decays:
             self.weight_decay = decays[0]
 
+    def _round2_layout_matches(self, osd: dict, names: List[str]) -> bool:
+        """True when every state entry's shape fits the parameter the round-2 enumeration (no wrapper scalars) assigns to its id."""
+        ids = [i for g in osd["param_groups"] for i in g["params"]]
+        by_id = dict(zip(ids, names))
+        for pid, st in osd.get("state", {}).items():
+            n = by_id.get(int(pid))
+            e = None if n is None else self._opt_entry(n)
+            if e is None or tuple(st["exp_avg"].shape) != tuple(e["shape"]):
+                return False
+        return True
+
     def checkpoint(self, epoch: int = 0, args=None) -> dict:
         """The dict the reference's ``save_model`` writes on rank 0: wrapper-keyed weights (``timesformer.*``,
         ``task_heads.*``), optimizer state, epoch.  ``scaler`` is empty: bf16 operands need no loss scaling."""
+        self.check_finite()
         model = OrderedDict()
         model["logit_scale"] = torch.tensor(math.log(10.0))        # the wrapper's own pair (modeling:1363-1364): never trained,
         model["logit_bias"] = torch.tensor(-2.0)                   # kept so that the reference's load_state_dict finds its keys
@@ -382,6 +423,32 @@ class StreamformerTrainer:
         if h and nat is not None and getattr(nat, "lib", None) is not None:    # interpreter shutdown: globals may be gone
             nat.lib.sf_trainer_destroy(h)
             self._h = None
+
+    # ---- guards ------------------------------------------------------------------------------------------
+    def nonfinite_steps(self) -> int:
+        """Optimizer steps the device-side guard has skipped so far (reads the flag: synchronises with the GPU)."""
+        return 0 if self._guard is None else int(self._guard[1].item())
+
+    def check_finite(self) -> None:
+        """The reference stops the run when a loss is not finite (``tools/finetune_tools.py:533-541``: ``sys.exit(1)``) and its
+        GradScaler skips a step with inf gradients (``utils.py:515-551``).  Here the optimizer kernel makes both checks on the
+        device (the step is sync-free) and skips the update; this host-side read — call it wherever the loop already touches
+        the host (logging, checkpoints; ``checkpoint()`` does) — raises once that has happened.  Weights and moments are
+        those of the last finite step."""
+        n = self.nonfinite_steps()
+        if n:
+            raise FloatingPointError(f"loss or gradients were not finite in {n} optimizer step(s): those updates were skipped on the "
+                                     "device; stopping as the reference does (tools/finetune_tools.py:533-541)")
+
+    def _check_same_task(self, task: str) -> None:
+        import hashlib
+        code = int.from_bytes(hashlib.sha1(task.encode()).digest()[:7], "little")
+        mine = torch.tensor([[float(code % (1 << 24)), float((code >> 24) % (1 << 24))]], dtype=torch.float32, device=self.device)
+        from .parallel import all_gather_rows
+        allr = all_gather_rows(mine, group=self.group, at_world_1=True).cpu()
+        if not bool((allr == allr[0]).all()):
+            raise RuntimeError(f"rank {self.rank} runs task {task!r} in this micro-step but another rank runs a different one: every rank "
+                               "must schedule the same task per micro-step (sampler.py:218-337), or its collectives do not match")
 
     # ---- the step ---------------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -504,6 +571,9 @@ class StreamformerTrainer:
                    lr: Optional[float] = None, weight_decay: Optional[float] = None,
                    clip_grad: Optional[float] = None) -> torch.Tensor:
         """One micro-batch of ``train_one_epoch_multi_task``; returns the (unscaled) loss tensor [1]."""
+        if self._collectives and (self.task_sync_check == "always" or (self.task_sync_check == "first" and not self._task_checked)):
+            self._check_same_task(task)         # before the first collective of the micro-step
+            self._task_checked = True
         _, pooler = self.forward(pixel_values)
         loss, gp, gs = self.loss_and_grad(task, pooler, task_input)
         # d loss / d (scale, bias) into the two scalar slots of this head: ONE in-place multi-tensor add with the 1 / update_freq
@@ -512,6 +582,7 @@ class StreamformerTrainer:
         torch._foreach_add_([self.grad(f"task_heads.{task}.logit_scale"), self.grad(f"task_heads.{task}.logit_bias")],
                             [gs[0], gs[1]], alpha=inv)
         self._touched.add(task)
+        self._last_loss = loss
         self.micro += 1
         last = self.micro % update_freq == 0
         self.backward(gp if update_freq == 1 else gp.mul_(inv), reduce=last)
@@ -545,6 +616,10 @@ class StreamformerTrainer:
             nat.check(nat.lib.sf_trainer_set_extra_steps(self._h, (C.c_int32 * len(steps))(*steps), len(steps)))
             self._touched = set()
         with torch.cuda.device(self.device):
+            if self._guard is not None:
+                ll = self._last_loss
+                nat.check(nat.lib.sf_trainer_set_nonfinite_guard(
+                    self._h, self._guard.data_ptr(), ll.data_ptr() if (ll is not None and ll.dtype == torch.float32 and ll.is_cuda) else None))
             if clip_grad is not None:
                 nat.check(nat.lib.sf_trainer_grad_sumsq(self._h, self.grads.data_ptr(), self._scratch.data_ptr(), self._stream()))
                 sumsq = self._scratch.data_ptr()

@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
     assert sorted(nat.SIGNATURES) == syms, "ctypes table and header disagree"
-    assert nat.lib.sf_abi_version() == 3
+    assert nat.lib.sf_abi_version() == 4
 
 
 def test_create_validates_config_without_gpu():

@@ -23,7 +23,11 @@ pytestmark = pytest.mark.gpu
 
 ACC_TOL = 1e-3
 ACC_CEIL = 5e-4
-BF16_LHS, BF16_POOL = 4e-2, 3e-2          # measured 3.1e-2 / 2.7e-2 on the SigLIP-base clip of bench.py (the bf16 operand floor)
+# bf16 mode.  pooler_output: 3e-2 until round 3 (measured 2.7e-2).  Round 4 runs the pooling head's per-frame tail in bf16x3 in both modes: the
+# head's own contribution fell from 1.5e-2 to 6.7e-3 and the SigLIP-base clip of bench.py measures 1.93e-2, of which 1.86e-2 is what the
+# encoder's bf16 tokens carry through an EXACT head (tools/pool_err.py) — the operand floor, not the head.  SURVEY's 2e-2 holds for the
+# SigLIP-base fixtures; the 128-wide two-layer fixture F7 (T = 32) measures 2.06e-2, hence 2.2e-2.
+BF16_LHS, BF16_POOL = 4e-2, 2.2e-2
 
 
 @pytest.fixture(scope="module")
@@ -717,8 +721,19 @@ def test_output_attentions(golden_dir, mode, tol):
     assert torch.equal(out.last_hidden_state, plain) if mode == "bf16" else maxabs(out.last_hidden_state, plain) <= 2e-5
     tup = m(x, output_attentions=True, output_hidden_states=True, return_dict=False)
     assert len(tup) == 3 and len(tup[2]) == cfg.num_hidden_layers
-    with pytest.raises(NotImplementedError):
-        m(x[:, :1], output_attentions=True, use_cache=True)
+    # output_attentions while streaming (timesformer_encoder.py:494, 557, 720-754): the new frames' probabilities, call by call,
+    # are the full clip's rows for those frames (causal temporal attention: a frame never sees later ones)
+    cache, pos = None, 0
+    for csz in (2, 1, 2):
+        o = m(x[:, pos:pos + csz], output_attentions=True, use_cache=True, past_key_values=cache)
+        cache = o.past_key_values
+        assert len(o.attentions) == cfg.num_hidden_layers and tuple(o.attentions[0].shape) == (2 * csz, 2, 9, 9)
+        want = got.reshape(cfg.num_hidden_layers, 2, 5, 2, 9, 9)[:, :, pos:pos + csz].reshape(cfg.num_hidden_layers, 2 * csz, 2, 9, 9)
+        assert maxabs(torch.stack(list(o.attentions)).cpu(), want) <= (5e-5 if mode == "fp32" else tol)
+        assert maxabs(o.last_hidden_state, out.last_hidden_state[:, pos:pos + csz]) <= (5e-5 if mode == "fp32" else BF16_LHS)
+        pos += csz
+    tup = m(x[:, :1], output_attentions=True, use_cache=True, return_dict=False)
+    assert len(tup) == 3 and len(tup[1]) == cfg.num_hidden_layers          # (lhs, attentions, cache)
     if mode == "bf16":      # N = 196, 12 heads: rows sum to one, softmax of what the kernel's own context used
         big = siglip_base(num_hidden_layers=1)
         mb = sa.TimesformerMultiTaskingModelSigLIP(big, compute_dtype="bf16")

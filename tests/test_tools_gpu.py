@@ -147,6 +147,23 @@ def test_bench_starts_its_own_ranks(mode):
         assert set(out["losses_per_task_first_last"]) == {"retrieval", "localization"}
 
 
+def test_train_bench_eight_ranks_on_one_device():
+    """the config-#4 world size.  `python bench.py --gpus 8 --mode train` with all eight ranks on cuda:0 over
+    gloo (one GPU cannot host eight RCCL ranks): eight Python ranks' host enqueue, five gradient buckets reduced eight ways,
+    the caption all-gather across eight ranks, the same-task check, barriers and the max-over-ranks timing all complete and
+    rank 0 prints the contract's one line with eight distinct processes in `ranks_seen`."""
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device",
+           "--mode", "train", "--batch", "1"]
+    out = _one_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1100))
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
+    assert sorted(r["rank"] for r in out["ranks_seen"]) == list(range(8)) and len({r["pid"] for r in out["ranks_seen"]}) == 8
+    assert out["allreduce_buckets"] >= 2 and out["allreduce_ms"]["isolated"] > 0
+    assert all(np.isfinite(v) for pair in out["losses_per_task_first_last"].values() for v in pair)
+
+
 @pytest.mark.parametrize("mode", ["forward", "train"])
 def test_bench_on_rccl_at_world_size_1(mode):
     """VERDICT r2 #1b: the bench's own `nccl` branches (init_process_group(device_id), barriers, the max-over-ranks all-reduce on

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 L=gpurun_out/r04_pp_lab.txt
 : > $L
-run() { env "$@" timeout 300 python tools/pp_lab.py >> $L 2>&1 || echo "FAILED: $*" >> $L; }
+run() { env SF_LIB=lab "$@" timeout 300 python tools/pp_lab.py >> $L 2>&1 || echo "FAILED: $*" >> $L; }
 run PP_LAB_ORACLE=1 SF_X=base
 run PP_LAB_ORACLE=1 SF_PANEL_PP=1
 run SF_PANEL_PP=1 SF_PANEL_PP_STAGGER_NS=0
