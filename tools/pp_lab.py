@@ -32,4 +32,8 @@ parts = []
 for which, name in ((1, "down"), (3, "out")):
     nat.check(nat.lib.sf_bench_gemm(m._handle, 25088, which, 30, ws.data_ptr(), ws.numel(), nat.current_stream_handle(dev), nat.C.byref(ms), nat.C.byref(fl)))
     parts.append(f"{name} {ms.value*1e3:.1f} us")
+by = nat.C.c_double()
+for which, name in ((0, "spatial"), (1, "temporal")):
+    nat.check(nat.lib.sf_bench_attention(m._handle, 8, 16, which, 20, ws.data_ptr(), ws.numel(), nat.current_stream_handle(dev), nat.C.byref(ms), nat.C.byref(by), nat.C.byref(fl)))
+    parts.append(f"{name} attn {ms.value*1e3:.1f} us ({by.value/ms.value/1e9:.2f} TB/s)")
 print(line + " | " + "; ".join(parts), flush=True)
