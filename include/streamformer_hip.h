@@ -101,6 +101,14 @@ int sf_forward(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, 
                float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
                const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 
+/* Measurement hook: ONE forward (same arguments as sf_forward, no hidden states) with HIP events around the launches of four kernel
+ * classes INSIDE it — 0: N = 768 residual projection at K = hidden_size, 1: the same at K = intermediate_size, 2: spatial attention,
+ * 3: temporal attention.  Synchronises the stream.  out_ms_host[2 c] = mean milliseconds per launch of class c (the event pair also
+ * spans the launch boundary in front of the kernel), out_ms_host[2 c + 1] = number of launches.  bench.py's `roofline` uses it.   */
+int sf_forward_profile(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, int T, int H, int W,
+                       float* last_hidden_dev, float* pooler_dev, void* workspace_dev, size_t workspace_bytes,
+                       sf_stream stream, float* out_ms_host);
+
 /* same, additionally returning the spatial attention probabilities of every layer
  * (output_attentions=True, modeling:703-716, 1052-1057): attentions_dev fp32 [L, B*T, heads, N, N];
  * N <= 224 patches per frame.                                                                     */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sf_set_pixel_normalization": (_I, [_P, _P, _P, _I, _F]),
     "sf_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "sf_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sf_forward_profile": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _SZ, _P, C.POINTER(_F)]),
     "sf_forward_attentions": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sf_embed": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "sf_layers": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),

@@ -88,7 +88,29 @@ struct sf_encoder {
   size_t weight_bytes = 0;
   uint64_t generation = 0;    // process-unique id of this handle's current weight packing (bumped by every finalize)
   SfPixelNorm pixel_norm = {{1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f}, {-1.f, -1.f, -1.f, -1.f}};
+  // sf_forward_profile: HIP events around the launches of four kernel classes INSIDE a real forward (0: N = 768 residual projection
+  // at K = D, 1: the same at K = I, 2: spatial attention, 3: temporal attention)
+  struct ProfSpan { int cls; hipEvent_t e0, e1; };
+  bool prof_on = false;
+  std::vector<ProfSpan> prof;
 };
+// run `launch` between two events on `s` when the encoder is in profiling mode
+template <typename F>
+static hipError_t prof_span(const sf_encoder* ce, int cls, hipStream_t s, F&& launch) {
+  sf_encoder* e = const_cast<sf_encoder*>(ce);
+  if (!e->prof_on) return launch();
+  sf_encoder::ProfSpan sp;
+  sp.cls = cls;
+  hipError_t err = hipEventCreate(&sp.e0);
+  if (err != hipSuccess) return err;
+  err = hipEventCreate(&sp.e1);
+  if (err != hipSuccess) return err;
+  (void)hipEventRecord(sp.e0, s);
+  err = launch();
+  (void)hipEventRecord(sp.e1, s);
+  e->prof.push_back(sp);
+  return err;
+}
 
 struct sf_cache {
   sf_encoder* enc = nullptr;
@@ -766,11 +788,12 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = slot;
       a.pos_dev = sp ? &sp->slot : nullptr;
       a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
-      HIP_TRY(sf_launch_temporal_attention(a, acc, s));
+      HIP_TRY(prof_span(e, 3, s, [&]() { return sf_launch_temporal_attention(a, acc, s); }));
     }
     if (e->fused_temporal) {
-      HIP_TRY(run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, l.gate_tanh,
-                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2));
+      HIP_TRY(prof_span(e, 0, s, [&]() {
+        return run_linear(e, l.t_fused, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, l.gate_tanh,
+                          0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2); }));
     } else {
       HIP_TRY(run_linear(e, l.t_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_BF16, s, nullptr, ws.tmp_hi, ws.tmp_lo));
       HIP_TRY(run_linear(e, l.t_dense, ws.tmp_hi, ws.tmp_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, l.gate_tanh,
@@ -792,16 +815,18 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
       a.probs = attentions ? attentions + (size_t)(li - la) * F * heads * N * N : nullptr;
-      HIP_TRY(sf_launch_spatial_attention(a, acc, s));
+      HIP_TRY(prof_span(e, 2, s, [&]() { return sf_launch_spatial_attention(a, acc, s); }));
     }
-    HIP_TRY(run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,
-                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2));
+    HIP_TRY(prof_span(e, 0, s, [&]() {
+      return run_linear(e, l.s_out, ws.ctx_hi, ws.ctx_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,
+                        0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2); }));
     // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
     HIP_TRY(run_linear(e, anyfold ? l.up_f : l.up, ln_in, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
                        0, 0, 0, 0, fold_st, nullptr, sfold));
-    HIP_TRY(run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,
-                       0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2));
+    HIP_TRY(prof_span(e, 1, s, [&]() {
+      return run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,
+                        0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2); }));
   }
   if (hidden_states && (stages & 2) && lb == e->L)
     HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
@@ -893,6 +918,32 @@ extern "C" int sf_forward(sf_encoder* e, const void* pixels, int pixel_dtype, in
                           void* workspace, size_t workspace_bytes, sf_stream stream) {
   return forward_common(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, nullptr, pos_dev, workspace,
                         workspace_bytes, stream);
+}
+
+// One forward with HIP events around the launches of four kernel classes (see sf_encoder::prof): the in-situ launch durations the
+// bench's roofline reports — isolated back-to-back launches of the same kernel run on an Infinity-Cache-warm working set and read
+// 4 % faster.  out_ms[2 c] = mean milliseconds per launch of class c, out_ms[2 c + 1] = launches of that class.
+extern "C" int sf_forward_profile(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W, float* last_hidden,
+                                  float* pooler, void* workspace, size_t workspace_bytes, sf_stream stream, float* out_ms) {
+  if (!e || !out_ms) return set_err(SF_ERR_INVALID, "null argument");
+  e->prof.clear();
+  e->prof_on = true;
+  int rc = forward_common(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+  e->prof_on = false;
+  hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+  double sum[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
+  for (auto& sp : e->prof) {
+    float ms = 0.f;
+    if (rc == SF_OK && se == hipSuccess && hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess && sp.cls >= 0 && sp.cls < 4) { sum[sp.cls] += ms; cnt[sp.cls]++; }
+    (void)hipEventDestroy(sp.e0);
+    (void)hipEventDestroy(sp.e1);
+  }
+  e->prof.clear();
+  for (int c = 0; c < 4; ++c) { out_ms[2 * c] = cnt[c] ? (float)(sum[c] / cnt[c]) : 0.f; out_ms[2 * c + 1] = (float)cnt[c]; }
+  if (rc != SF_OK) return rc;
+  if (se != hipSuccess) return set_err(SF_ERR_HIP, "sf_forward_profile: %s", hipGetErrorString(se));
+  return SF_OK;
 }
 
 extern "C" int sf_forward_attentions(sf_encoder* e, const void* pixels, int pixel_dtype, int B, int T, int H, int W,
