@@ -254,6 +254,12 @@ int sf_trainer_workspace_bytes(const sf_trainer* tr, int B, int T, size_t* out);
  * The backward of a forward applies the factors that forward used.  NULL = none (eval, or drop_path_rate 0).  The array is
  * caller-owned and must stay valid until the matching backward has run.                                                        */
 int sf_trainer_set_drop_path(sf_trainer* tr, const float* scales_dev, int B, int T);
+/* Dropout of the forwards that follow (config.hidden_dropout_prob / attention_probs_dropout_prob; reference sites modeling:374, 378
+ * (position / time embeddings), 752 / 761 (both SelfOutput projections), 822 (MLP activation), 835 (MLP output), 556 / 603 / 669 / 705
+ * (attention probabilities)).  Masks are COUNTER-BASED: element idx of site k is kept iff hash(idx, hash(k, seed)) < keep * 2^32 and
+ * scaled by 1 / keep, so no mask tensor exists and the backward of a forward replays the masks from the seed that forward used
+ * (the CPU oracle evaluates the same integer hash).  0 / 0 switches dropout off (eval).                                           */
+int sf_trainer_set_dropout(sf_trainer* tr, float hidden_p, float attention_p, uint32_t seed);
 /* Non-finite guard of the optimizer step (tools/finetune_tools.py:533-541 stops the run on a non-finite loss; the GradScaler of
  * utils.py:515-551 skips a step whose gradients hold inf / NaN).  flag_dev = DEVICE int32[2], caller-owned and zero-initialised:
  * every sf_trainer_adamw_step that follows checks sum g^2 of the gradient (and *loss_dev, a device float, when not NULL) ON THE

@@ -68,7 +68,7 @@ def _lora_lin(x: Tensor, sd: Dict[str, Tensor], name: str, lora_name: str) -> Te
     return y
 
 
-def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, mask: Optional[Tensor]) -> Tensor:
+def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, mask: Optional[Tensor], prob_mask: Optional[Tensor] = None) -> Tensor:
     """softmax((q k^T) * d^-0.5 [+ mask]) v per head.  q:[G,Lq,D] k,v:[G,Lk,D] -> [G,Lq,D].
 
     Follows modeling:577-609 / 690-711: scores are scaled AFTER the matmul, masked positions are
@@ -84,7 +84,8 @@ def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, mask: Optional[Tensor]) ->
     if mask is not None:
         s = s.masked_fill(~mask, float("-inf"))
     p = s.softmax(dim=-1)
-    return (p @ vh).transpose(1, 2).reshape(G, Lq, D), p
+    pd = p if prob_mask is None else p * prob_mask          # attn_drop (modeling:556, 603, 669, 705): [G, heads, Lq, Lk] factors
+    return (pd @ vh).transpose(1, 2).reshape(G, Lq, D), p
 
 
 # --------------------------------------------------------------------------------------------
@@ -144,14 +145,51 @@ def patchify(pixels: Tensor, P: int) -> Tensor:
     return x.permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, gh * gw, C * P * P)
 
 
-def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False, clamp_time: bool = False) -> Tensor:
+# --------------------------------------------------------------------------------------------
+# dropout masks (training): the reference draws them with torch's Philox stream (nn.Dropout at modeling:374, 378, 556, 603, 669, 705,
+# 752, 761, 822, 835), which no other implementation can replay; here — as in the build's kernels (streamformer_amd/csrc/sf_train.h:
+# sf_drop_hash / sf_drop_make) — a mask is a pure function of (seed, site, element index), so both sides of a test use the same draw.
+# --------------------------------------------------------------------------------------------
+_M32 = 0xFFFFFFFF
+
+
+def _drop_hash(idx: Tensor, key: int) -> Tensor:
+    x = (idx * 0x9E3779B1 + key) & _M32          # int64 products wrap modulo 2^64: the low 32 bits are exact
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & _M32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & _M32
+    return x ^ (x >> 16)
+
+
+def dropout_mask(shape, p: float, seed: int, site: int, dtype=torch.float32) -> Tensor:
+    """0 or 1 / keep per element of a frame-major tensor of ``shape`` (flat C-order index), site keys as in sf_train.h."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    key = int(_drop_hash(torch.tensor([site], dtype=torch.int64), int(seed) & _M32)[0])
+    keep = 1.0 - float(p)
+    thresh = min(int(keep * 4294967296.0), 4294967295)
+    h = _drop_hash(torch.arange(n, dtype=torch.int64), key)
+    scale = torch.tensor(1.0 / keep, dtype=torch.float32)
+    return ((h < thresh).to(torch.float32) * scale).reshape(*shape).to(dtype)
+
+
+def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False, clamp_time: bool = False,
+               dropout: Optional[tuple] = None) -> Tensor:
+    """``dropout`` = (seed, hidden_p, attention_p) in training: pos_drop / time_drop of modeling:374, 378 (sites L*8, L*8 + 1)."""
     B, T, C, H, W = pixels.shape
     w = sd["embeddings.patch_embeddings.projection.weight"]
     x = patchify(pixels, cfg.patch_size) @ w.reshape(w.shape[0], -1).t()
     x = x + sd["embeddings.patch_embeddings.projection.bias"]
     x = x + position_embedding(sd, cfg, H, W)[None, None]          # broadcast over B, T
+    hp = dropout[1] if dropout is not None else 0.0
+    if hp > 0:
+        x = x * dropout_mask(x.shape, hp, dropout[0], cfg.num_hidden_layers * 8, x.dtype)
     if cfg.attention_type != "space_only":
         x = x + time_embedding_rows(sd, cfg, t_past, T, streaming, clamp_time)[None, :, None, :]
+        if hp > 0:
+            x = x * dropout_mask(x.shape, hp, dropout[0], cfg.num_hidden_layers * 8 + 1, x.dtype)
     return x  # [B, T, N, D]
 
 
@@ -159,7 +197,8 @@ def embeddings(sd, cfg, pixels: Tensor, t_past: int = 0, streaming: bool = False
 # one encoder layer (modeling:900-1004), frame-major
 # --------------------------------------------------------------------------------------------
 def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = None,
-                  collect: Optional[dict] = None, window: Optional[int] = None, drop_path: Optional[Tensor] = None) -> Tensor:
+                  collect: Optional[dict] = None, window: Optional[int] = None, drop_path: Optional[Tensor] = None,
+                  dropout: Optional[tuple] = None) -> Tensor:
     """h: [B, T, N, D].  ``kv`` (streaming): dict with 'k','v' tensors [B, T_past, N, D] or empty.
     ``drop_path`` (training): this layer's factors [B*N + B*T + B] — 0 or 1/keep per dim-0 entry of the tensor each residual
     branch returns in the reference ((B*N,T,D) temporal, (B*T,N,D) spatial, (B,N*T,D) MLP; modeling:460-486, 949, 980, 1000);
@@ -168,6 +207,10 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
     heads = cfg.num_attention_heads
     eps = cfg.layer_norm_eps
     p = f"encoder.layer.{i}."
+    # dropout = (seed, hidden_p, attention_p): sites i*8 + {0 temporal SelfOutput, 1 spatial SelfOutput, 2 MLP activation, 3 MLP output,
+    # 4 temporal probabilities, 5 spatial probabilities}; element index = flat index of the frame-major tensor (sf_train.h)
+    d_seed, d_hid, d_att = dropout if dropout is not None else (0, 0.0, 0.0)
+    hmask = (lambda x, k: x * dropout_mask(x.shape, d_hid, d_seed, i * 8 + k, x.dtype)) if d_hid > 0 else (lambda x, k: x)
 
     if cfg.attention_type != "divided_space_time":
         # StreamFormer only ever instantiates the divided branch (modeling:934-1004); the other two
@@ -195,9 +238,10 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
     if cfg.enable_causal_temporal:                                   # modeling:594-601; vqa_enc:533-537
         qi = torch.arange(T)[:, None] + t_past
         mask = torch.arange(Tk)[None, :] <= qi                      # [T, Tk] True = keep
-    ctx, _ = _mha(to_bn(q), to_bn(k), to_bn(v), heads, mask)
+    pm = dropout_mask((B * N, heads, T, Tk), d_att, d_seed, i * 8 + 4, h.dtype) if d_att > 0 else None
+    ctx, _ = _mha(to_bn(q), to_bn(k), to_bn(v), heads, mask, pm)
     ctx = ctx.reshape(B, N, T, D).permute(0, 2, 1, 3)
-    att_t = _lin(ctx, sd, p + "temporal_attention.output.dense")
+    att_t = hmask(_lin(ctx, sd, p + "temporal_attention.output.dense"), 0)          # SelfOutput dropout (modeling:761)
     if drop_path is not None:                                        # modeling:949: between the attention output and temporal_dense
         att_t = att_t * drop_path[:B * N].reshape(B, 1, N, 1).to(att_t.dtype)
     res_t = _lin(att_t, sd, p + "temporal_dense")
@@ -207,16 +251,17 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
     xs = _ln(h1, sd, p + "layernorm_before", eps).reshape(B * T, N, D)
     qkv = _lora_lin(xs, sd, p + "attention.attention.qkv", p + "attention.attention.qkv")
     q, k, v = qkv.split(D, dim=-1)
-    ctx, probs = _mha(q, k, v, heads, None)
+    pm = dropout_mask((B * T, heads, N, N), d_att, d_seed, i * 8 + 5, h.dtype) if d_att > 0 else None
+    ctx, probs = _mha(q, k, v, heads, None, pm)
     xs = _lora_lin(ctx, sd, p + "attention.output.dense", p + "attention.output.dense")
-    xs = xs.reshape(B, T, N, D)
+    xs = hmask(xs.reshape(B, T, N, D), 1)                                          # modeling:752 / 761
     if drop_path is not None:                                        # modeling:980
         xs = xs * drop_path[B * N:B * N + B * T].reshape(B, T, 1, 1).to(xs.dtype)
     h2 = h1 + xs                                                     # residual onto h1 (modeling:993-996)
 
     # ---- MLP: modeling:997-1000, 819-837 ---------------------------------------------------------
-    y = _lin(_act(cfg, _lin(_ln(h2, sd, p + "layernorm_after", eps), sd, p + "intermediate.dense")),
-             sd, p + "output.dense")
+    y = hmask(_lin(hmask(_act(cfg, _lin(_ln(h2, sd, p + "layernorm_after", eps), sd, p + "intermediate.dense")), 2),
+                   sd, p + "output.dense"), 3)                                     # modeling:822, 835
     if drop_path is not None:                                        # modeling:1000
         y = y * drop_path[B * N + B * T:].reshape(B, 1, 1, 1).to(y.dtype)
     out = h2 + y
@@ -269,7 +314,7 @@ def forward(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
 
 def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
                   collect: Optional[dict] = None, cache: Optional[List[dict]] = None, window: Optional[int] = None,
-                  drop_path: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                  drop_path: Optional[Tensor] = None, dropout: Optional[tuple] = None) -> Dict[str, Tensor]:
     """Full-clip forward (``cache is None``) or one streaming call (``cache`` = list of per-layer dicts).
 
     Returns ``last_hidden_state [B,T,N,D]``, ``pooler_output [B,T,D]`` and, on request,
@@ -286,7 +331,7 @@ def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
         # vqa_enc:343-348): absolute frame count kept next to the truncated K / V, time rows clamped to the table
         t_past = cache[0].get("seen", 0)
         cache[0]["seen"] = t_past + pixels.shape[1]
-    h = embeddings(sd, cfg, pixels, t_past=t_past, streaming=streaming, clamp_time=window is not None)
+    h = embeddings(sd, cfg, pixels, t_past=t_past, streaming=streaming, clamp_time=window is not None, dropout=dropout)
     if collect is not None:
         collect["embeddings"] = h
     hs = []
@@ -294,7 +339,7 @@ def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
         if output_hidden_states:
             hs.append(to_patch_major(h))
         h = layer_forward(sd, cfg, i, h, kv=(cache[i] if streaming else None), collect=collect, window=window,
-                          drop_path=None if drop_path is None else drop_path[i])
+                          drop_path=None if drop_path is None else drop_path[i], dropout=dropout)
         if collect is not None:
             collect.setdefault("layer_out", []).append(h)
     if output_hidden_states:

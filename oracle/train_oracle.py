@@ -79,9 +79,10 @@ class OracleTrainer:
                                       {"params": nodecay, "weight_decay": 0.0}], lr=lr, betas=betas, eps=eps)
         self.micro = 0
 
-    def loss(self, task: str, pixels: Tensor, task_input: dict, drop_path: Optional[Tensor] = None) -> Tensor:
-        """``drop_path``: [L, B*N + B*T + B] keep / drop factors of this forward (see O.layer_forward)."""
-        out = O.forward_graph(self.sd, self.cfg, pixels, drop_path=drop_path)
+    def loss(self, task: str, pixels: Tensor, task_input: dict, drop_path: Optional[Tensor] = None, dropout: Optional[tuple] = None) -> Tensor:
+        """``drop_path``: [L, B*N + B*T + B] keep / drop factors of this forward (see O.layer_forward);
+        ``dropout``: (seed, hidden_p, attention_p) of this forward's counter-based masks (O.dropout_mask)."""
+        out = O.forward_graph(self.sd, self.cfg, pixels, drop_path=drop_path, dropout=dropout)
         h = self.heads[task]
         if task_input["kind"] == "retrieval":
             # other_rank_text: the other ranks' caption features, negatives only (distributed SigLipLoss, modeling:239-297)

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sf_trainer_backward": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
     "sf_trainer_adamw_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P, _F, _I, _P]),
     "sf_trainer_set_drop_path": (_I, [_P, _P, _I, _I]),
+    "sf_trainer_set_dropout": (_I, [_P, _F, _F, C.c_uint32]),
     "sf_trainer_set_nonfinite_guard": (_I, [_P, _P, _P]),
     "sf_trainer_set_extra_steps": (_I, [_P, C.POINTER(C.c_int32), _I]),
     "sf_trainer_grad_sumsq": (_I, [_P, _P, _P, _P]),

@@ -40,7 +40,10 @@ class TrainEngine:
         # weight-gradient GEMMs instead of computing gradients that backward() would throw away
         freeze = self._frozen_spatial(module)
         sd = {k: p.detach() for k, p in named.items()}
-        self.tr = StreamformerTrainer(module.config, sd, [], freeze_spatial=freeze, device=module.device, with_optimizer=False)
+        # stochastic depth / dropout of the training forwards draw from a generator seeded by `module.stochastic_seed` (default 0): set it
+        # (and the engine's `tr._dp_gen` state on resume) to continue a sequence of masks instead of replaying it
+        self.tr = StreamformerTrainer(module.config, sd, [], freeze_spatial=freeze, device=module.device, with_optimizer=False,
+                                      drop_path_seed=int(getattr(module, "stochastic_seed", 0)), task_sync_check="never")
         self.freeze = freeze
         self.names: List[str] = list(named.keys())
         self._views = [self.tr._view(k) for k in self.names]

@@ -487,6 +487,19 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
       const int qi = qt * 16 + l15;
       if (qi < N) p.lse2_out[((size_t)frame * p.heads + h) * N + qi] = mc + __log2f(sum);
     }
+    if (p.drop.on) {                   // training: dropout on the (normalised) probabilities (modeling:705) — `sum` above is unmasked
+      const int qd = qt * 16 + l15 < N ? qt * 16 + l15 : N - 1;
+      const unsigned dbase = (unsigned)((((size_t)frame * p.heads + h) * N + qd) * N);
+#pragma unroll
+      for (int jt = 0; jt < MAXNT; ++jt)
+        if (jt * 16 < N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = jt * 16 + 4 * g + r;
+            s[jt][r] *= sf_drop_factor(p.drop, dbase + (unsigned)(key < N ? key : N - 1));
+          }
+        }
+    }
 
     // ---- O^T = V^T P^T: 32 keys per step, V^T fragments by transposed reads of the row-major image ------------------------
     f32x4_t o[4];
@@ -975,6 +988,7 @@ bool sf_spatial_planes_ok(int N, bool probs) {
 
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
+  if (a.drop.on && (accurate || a.probs || a.N > 224 || getenv("SF_DISABLE_SPATIAL_DMA") || (a.row_pitch_kv % 8))) return hipErrorInvalidValue;   // dropout: DMA kernel only
   const int nkp = (a.N + 31) & ~31;
   if (nkp > 32 * 7) {                               // more than 224 tokens per frame: streaming-key kernel
     if (a.probs) return hipErrorInvalidValue;       // probabilities are only materialised by the all-keys-in-LDS kernel
@@ -1309,6 +1323,13 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_dma_kernel(SfAttnArgs p,
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
+  if (p.drop.on) {      // training: dropout on the (normalised) probabilities (modeling:603) — the denominator above is unmasked
+    const unsigned dbase = (unsigned)((((size_t)bn * p.heads + h) * Tq + (l15 < Tq ? l15 : Tq - 1)) * Tk);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[jt][r] *= sf_drop_factor(p.drop, dbase + (unsigned)(jt * 16 + 4 * g + r));
+  }
   const u32x4_t pu = {pack_bf2(s[0][0], s[0][1]), pack_bf2(s[0][2], s[0][3]), pack_bf2(s[1][0], s[1][1]), pack_bf2(s[1][2], s[1][3])};
   const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
   bf16x8_t pl;
@@ -1511,6 +1532,8 @@ bool sf_temporal_planes_ok(int Tq, int Tk) {
 
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.Tq <= 0 || a.Tk <= 0 || a.B <= 0 || a.N <= 0) return hipErrorInvalidValue;
+  // dropout on the probabilities (training forward): the DMA-staged whole-clip kernel only
+  if (a.drop.on && (accurate || a.Tq == 1 || a.Tq > 16 || a.Tk > 32 || (a.row_pitch_kv % 8) || getenv("SF_DISABLE_TEMPORAL_DMA"))) return hipErrorInvalidValue;
   static const bool decode_off = getenv("SF_DISABLE_TEMPORAL_DECODE") != nullptr;
   if (a.Tq == 1 && a.Tk <= 256 && !decode_off) {        // one new frame per stream: the matrix-vector kernel
     const int ntasks = a.B * a.N * a.heads;

@@ -70,7 +70,10 @@ struct BwdView {
   int causal;
   float sl2;                       // scale * log2(e)
   float scale;
-};
+  SfDrop drop;                     // attention-probability dropout of the forward (modeling:556, 603, 669, 705): factor of element
+  unsigned drop_base;              //   (query qi, key kj) = sf_drop_factor(drop, drop_base + qi * L + kj); O = (m o P) V, so dV sees m o P
+};                                 //   and dS = P o (m o dP - Delta) with Delta = rowsum(dO o O) unchanged
+SF_DEVICE float bwd_drop(const BwdView& w, int qi, int kj) { return w.drop.on ? sf_drop_factor(w.drop, w.drop_base + (unsigned)(qi * w.L + kj)) : 1.f; }
 
 // ---- phase A: statistics of query tile `it` (16 queries), swapped scores: lane = query l15 ----------
 template <bool TWO>
@@ -176,8 +179,9 @@ SF_DEVICE void phase_b_block(const BwdView& w, int jb, int nb, f32x4_t (&dk)[2][
               const int qi = q0 + 4 * g + r;
               const bool ok = kj < w.L && !(w.causal && kj > qi);
               const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * w.sl2 - lse[r]) : 0.f;
-              p[it2][jt2][r] = pv;
-              ds[it2][jt2][r] = pv * (dp[r] - dl[r]) * w.scale;
+              const float fd = bwd_drop(w, qi, kj);
+              p[it2][jt2][r] = pv * fd;
+              ds[it2][jt2][r] = pv * (fd * dp[r] - dl[r]) * w.scale;
             }
           } else {
             p[it2][jt2] = ds[it2][jt2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -250,7 +254,7 @@ SF_DEVICE void phase_c_block(const BwdView& w, int ib, int nb, f32x4_t (&dq)[2][
               const int kj = k0 + 4 * g + r;
               const bool ok = kj < w.L && !(w.causal && kj > qi);
               const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * w.sl2 - lse[it2]) : 0.f;
-              ds[jt2][it2][r] = pv * (dp[r] - dl[it2]) * w.scale;
+              ds[jt2][it2][r] = pv * (bwd_drop(w, qi, kj) * dp[r] - dl[it2]) * w.scale;
             }
           } else {
             ds[jt2][it2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -352,8 +356,9 @@ SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb, f32x4_t (&dk)[4]
         const int qi = q0 + 4 * g + r;
         const bool ok = kj < w.L && !(w.causal && kj > qi);
         const float pv = ok ? __builtin_amdgcn_exp2f(sc[r] * w.sl2 - lse[r]) : 0.f;
-        p[it2][r] = pv;
-        ds[it2][r] = pv * (dp[r] - dl[r]) * w.scale;
+        const float fd = bwd_drop(w, qi, kj);
+        p[it2][r] = pv * fd;
+        ds[it2][r] = pv * (fd * dp[r] - dl[r]) * w.scale;
       }
     }
     const bf16x8_t pa = pack_a(p[0], p[1]), dsa = pack_a(ds[0], ds[1]);
@@ -394,7 +399,7 @@ SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb, f32x4_t (&dq)[4]
         const int kj = k0 + 4 * g + r;
         const bool ok = kj < w.L && !(w.causal && kj > qi);
         const float pv = ok ? __builtin_amdgcn_exp2f(sc[r] * w.sl2 - lse) : 0.f;
-        ds[jt2][r] = pv * (dp[r] - dl) * w.scale;
+        ds[jt2][r] = pv * (bwd_drop(w, qi, kj) * dp[r] - dl) * w.scale;
       }
     }
     const bf16x8_t dsa = pack_a(ds[0], ds[1]);
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   BwdView w;
   w.q = iq; w.k = ik; w.v = iv; w.d_o = ig; w.lse2 = lse2; w.delta = delta; w.patch = patch;
   w.L = L; w.causal = a.causal; w.scale = a.scale; w.sl2 = a.scale * LOG2E;
+  w.drop = a.drop; w.drop_base = (unsigned)(((size_t)f * a.heads + h) * (size_t)L * L);
 
   if (a.lse2) {       // statistics saved by the forward kernel: padding queries get +big so that p = 0
     for (int i = tid; i < rows_pad; i += SB_THREADS) lse2[i] = i < L ? a.lse2[((size_t)f * a.heads + h) * L + i] : -NEG_BIG;
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_bwd_kernel(SfAttnBwdArgs
   BwdView w;
   w.q = iq; w.k = ik; w.v = iv; w.d_o = ig; w.lse2 = lse2; w.delta = delta; w.patch = patch;
   w.L = L; w.causal = a.causal; w.scale = a.scale; w.sl2 = a.scale * LOG2E;
+  w.drop = a.drop; w.drop_base = (unsigned)(((size_t)bn * a.heads + h) * (size_t)L * L);
   constexpr int NT = NP / 16;
   for (int it = 0; it < NT; ++it) phase_a_tile<TWO>(w, it, NT, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -271,6 +271,28 @@ hipError_t sf_launch_gather_rows(const float* table, float* out, const SfRowInde
 // ------------------------------------------------------------------------------------------------
 // attention
 // ------------------------------------------------------------------------------------------------
+// Dropout (hidden_dropout_prob / attention_probs_dropout_prob of the config; reference sites modeling:374, 378, 556, 603, 669, 705, 752,
+// 761, 822, 835) with COUNTER-BASED masks: element `idx` of site `key` is kept iff sf_drop_hash(idx, key) < thresh and then scaled by
+// 1 / keep.  No mask tensor exists: forward, backward and the CPU oracle (oracle/train_oracle.py) evaluate the same integer hash.
+// idx = flat index of the element in its frame-major tensor ([M, width] rows (b, t, n); attention: [(sequence, head), query, key]).
+struct SfDrop { unsigned on, thresh, key; float scale; };
+__host__ __device__ inline unsigned sf_drop_hash(unsigned idx, unsigned key) {
+  unsigned x = idx * 0x9E3779B1u + key;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline float sf_drop_factor(const SfDrop& d, unsigned idx) { return sf_drop_hash(idx, d.key) < d.thresh ? d.scale : 0.f; }
+// site keys: layer * 8 + {0 temporal SelfOutput, 1 spatial SelfOutput, 2 MLP activation, 3 MLP output, 4 temporal probabilities,
+// 5 spatial probabilities}; embeddings: L * 8 + {0 position, 1 time}
+inline SfDrop sf_drop_make(float p, unsigned seed, unsigned site) {
+  SfDrop d = {0u, 0u, 0u, 1.f};
+  if (p > 0.f) {
+    const double keep = 1.0 - (double)p;
+    const double th = keep * 4294967296.0;
+    d.on = 1u; d.thresh = th >= 4294967295.0 ? 4294967295u : (unsigned)th; d.key = sf_drop_hash(site, seed); d.scale = (float)(1.0 / keep);
+  }
+  return d;
+}
 struct SfAttnArgs {
   // q/k/v element (seq position p of sequence g, head h, dim e) lives at
   //   base[(g_off(g) + p * pos_stride) * row_pitch + col0 + h*64 + e]
@@ -296,6 +318,8 @@ struct SfAttnArgs {
                                       // [frames, heads, N] fp32 (kept by the training forward for the backward kernel)
   float* probs;                       // spatial only, optional: softmax probabilities [frames, heads, N, N] fp32
                                       // (output_attentions=True, modeling:703-716); N <= 224
+  SfDrop drop;                        // training forward: dropout on the probabilities (on = 0: none); element ((seq * heads + h) * Lq + q) * Lk + k,
+                                      // seq = frame (spatial) / b * N + n (temporal).  DMA-staged bf16 kernels only.
 };
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
 bool sf_spatial_planes_ok(int N, bool probs);

@@ -63,6 +63,7 @@ struct SfAttnBwdArgs {
   const float* lse2;               // spatial, optional: [nseq, heads, L] log-sum-exp (base 2) saved by the forward kernel;
                                    // without it the backward recomputes the row statistics (phase A)
   int lab;                         // timing lab (SF_ATTN_BWD_LAB): 1 no phase B, 2 no phase C, 4 no output stores
+  SfDrop drop;                     // attention-probability dropout the forward applied (on = 0: none); element index ((seq * heads + h) * L + q) * L + k
 };
 hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);    // L <= 224
 hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);   // L <= 32
@@ -76,10 +77,16 @@ hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const 
 // ------------------------------------------------------------------------------------------------
 // act = gelu(pre)   (erf form, modeling:819-824)
 hipError_t sf_launch_gelu_fwd(const bf16_t* pre, bf16_t* act, size_t n, hipStream_t s);
-// drop_path factors per sample group (mode 0 temporal (b, n), 1 spatial (b, t), 2 MLP (b)); see sf_train_kernels.hip
-hipError_t sf_launch_rowscale_bf16(const bf16_t* in, bf16_t* out, const float* scales, int rows, int D, int mode, int T, int N, hipStream_t s);
+// drop_path factors per sample group (mode 0 temporal (b, n), 1 spatial (b, t), 2 MLP (b)) and / or an elementwise dropout mask;
+// scales == nullptr: no drop_path factor.  See sf_train_kernels.hip
+hipError_t sf_launch_rowscale_bf16(const bf16_t* in, bf16_t* out, const float* scales, int rows, int D, int mode, int T, int N, hipStream_t s,
+                                   SfDrop drop = SfDrop{0u, 0u, 0u, 1.f});
 hipError_t sf_launch_resid_rowscale(float* out, const float* resid, const float* y, const float* scales, int rows, int D, int mode, int T, int N,
-                                    hipStream_t s);
+                                    hipStream_t s, SfDrop drop = SfDrop{0u, 0u, 0u, 1.f});
+// embeddings with dropout (modeling:374, 378): h = m_time o (m_pos o h + time[t]) in place; h arrives as patches W^T + b + pos[n]
+hipError_t sf_launch_embed_dropout(float* h, const float* time_rows, int M, int D, int T, int N, SfDrop pos_drop, SfDrop time_drop, hipStream_t s);
+// g = m o g in place on fp32 rows, optional bf16 copy of the result (embedding backward)
+hipError_t sf_launch_dropout_f32(float* g, bf16_t* g_bf, size_t n, SfDrop drop, hipStream_t s);
 // d = d * gelu'(pre)   in place
 hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_t s);
 // LayerNorm backward over rows of x (statistics recomputed): g_out = (g_in ? g_in : 0) + dL/dx, optionally

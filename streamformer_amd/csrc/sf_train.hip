@@ -70,6 +70,9 @@ struct sf_trainer {
   const float* dp_scales = nullptr; // drop_path factors of the next forward (device, caller-owned), nullptr = none
   int dp_B = 0, dp_T = 0;
   const float* f_dp = nullptr;      // the factors the last forward used: its backward applies the same ones
+  // dropout of the NEXT forward (sf_trainer_set_dropout) and of the last one (its backward replays the same counter-based masks)
+  float drop_hidden = 0.f, drop_attn = 0.f, f_drop_hidden = 0.f, f_drop_attn = 0.f;
+  unsigned drop_seed = 0u, f_drop_seed = 0u;
   int n_extra = 0, extra_seg0 = 0;  // the scalar slots are the last n_extra trainable segments
   bool extra_steps_set = false;
   int extra_steps[64] = {};
@@ -563,9 +566,23 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
     g.M = M; g.N = D; g.K = t->Kp; g.epi = SF_EPI_EMBED_F32;
     g.pos = PP(t, P0, t->p_pos); g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
     g.out_f32 = ws.h[0]; g.ldc = D;
-    HIP_TRY(sf_launch_gemm(g, false, s));
+    if (t->drop_hidden > 0.f) {
+      // pos_drop(patches + pos) then time_drop(. + time) (modeling:374, 378): the GEMM adds a zero time table, one elementwise pass does the rest
+      HIP_TRY(hipMemsetAsync(ws.g, 0, (size_t)T * D * sizeof(float), s));
+      g.time_rows = ws.g;
+      HIP_TRY(sf_launch_gemm(g, false, s));
+      HIP_TRY(sf_launch_embed_dropout(ws.h[0], ws.te_rows, M, D, T, N, sf_drop_make(t->drop_hidden, t->drop_seed, (unsigned)t->L * 8u),
+                                      sf_drop_make(t->drop_hidden, t->drop_seed, (unsigned)t->L * 8u + 1u), s));
+    } else {
+      HIP_TRY(sf_launch_gemm(g, false, s));
+    }
   }
   const float scale = 0.125f;
+  const bool hd = t->drop_hidden > 0.f;
+  auto site = [&](int li, int k) { return sf_drop_make(t->drop_hidden, t->drop_seed, (unsigned)(li * 8 + k)); };
+  const bool ad = t->drop_attn > 0.f;
+  if (ad && (T > 16 || N > 224)) return sf_set_err(SF_ERR_INVALID, "attention dropout needs clips of <= 16 frames and <= 224 patches per frame");
+  auto asite = [&](int li, int k) { return sf_drop_make(t->drop_attn, t->drop_seed, (unsigned)(li * 8 + k)); };
   if (t->dp_scales && (t->dp_B != B || t->dp_T != T))
     return sf_set_err(SF_ERR_INVALID, "drop_path factors were set for B=%d T=%d, the forward runs B=%d T=%d", t->dp_B, t->dp_T, B, T);
   const float* dp = t->dp_scales;
@@ -584,11 +601,13 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
       a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.B = B; a.Tq = T; a.Tk = T; a.Tcap = T; a.t_past = 0; a.causal = c.enable_causal_temporal;
       a.Tq_cap = T; a.q_t0 = 0; a.ctx_hi = sv.ctx_t; a.D = D;
+      if (ad) a.drop = asite(li, 4);
       HIP_TRY(sf_launch_temporal_attention(a, false, s));
     }
     HIP_TRY(lin_fwd(t, l.t_out, sv.ctx_t, M, SF_EPI_BF16, s, nullptr, sv.t_out));
     // drop_path (modeling:949) sits between the attention output and temporal_dense: the saved t_out IS the dropped tensor
-    if (dp) HIP_TRY(sf_launch_rowscale_bf16(sv.t_out, sv.t_out, dp + (size_t)li * dp_per_layer, M, D, 0, T, N, s));
+    // hidden dropout of the temporal SelfOutput (modeling:761) rides on the same pass
+    if (dp || hd) HIP_TRY(sf_launch_rowscale_bf16(sv.t_out, sv.t_out, dp ? dp + (size_t)li * dp_per_layer : nullptr, M, D, 0, T, N, s, site(li, 0)));
     HIP_TRY(lin_fwd(t, l.t_dense, sv.t_out, M, SF_EPI_RESID_F32, s, sv.h1, nullptr, h));      // h1 = h + tanh(g) * dense(.)
     // spatial attention (modeling:962-996)
     HIP_TRY(sf_launch_layernorm(sv.h1, PP(t, P0, l.ln_b_g), PP(t, P0, l.ln_b_b), nullptr, sv.ln_b, nullptr, M, D, eps, s));
@@ -599,20 +618,23 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
       a.q = sv.sqkv; a.k = sv.sqkv + D; a.v = sv.sqkv + 2 * D;
       a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
       a.N = N; a.frames = F; a.ctx_hi = sv.ctx_s; a.D = D; a.lse2_out = sv.lse_s;
+      if (ad) a.drop = asite(li, 5);
       HIP_TRY(sf_launch_spatial_attention(a, false, s));
     }
-    if (dp) {     // h2 = h1 + drop_path(out(ctx)) (modeling:980): the branch leaves the GEMM as fp32, the residual add applies the factor
+    if (dp || hd) {     // h2 = h1 + drop_path(dropout(out(ctx))) (modeling:752 / 761, 980): the branch leaves the GEMM as fp32, the residual add applies the factors
       HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_F32, s, ws.g, nullptr));
-      HIP_TRY(sf_launch_resid_rowscale(sv.h2, sv.h1, ws.g, dp + (size_t)li * dp_per_layer + (size_t)B * N, M, D, 1, T, N, s));
+      HIP_TRY(sf_launch_resid_rowscale(sv.h2, sv.h1, ws.g, dp ? dp + (size_t)li * dp_per_layer + (size_t)B * N : nullptr, M, D, 1, T, N, s, site(li, 1)));
     } else {
       HIP_TRY(lin_fwd(t, l.s_out, sv.ctx_s, M, SF_EPI_RESID_F32, s, sv.h2, nullptr, sv.h1));
     }
     // MLP (modeling:997-1000)
     HIP_TRY(sf_launch_layernorm(sv.h2, PP(t, P0, l.ln_a_g), PP(t, P0, l.ln_a_b), nullptr, sv.ln_a, nullptr, M, D, eps, s));
     HIP_TRY(lin_fwd_gelu(t, l.up, sv.ln_a, M, s, sv.pre, sv.act));
-    if (dp) {     // out = h2 + drop_path(mlp) (modeling:1000)
+    if (hd) HIP_TRY(sf_launch_rowscale_bf16(sv.act, sv.act, nullptr, M, I, 0, T, N, s, site(li, 2)));      // dropout behind the activation (modeling:822): the saved act IS the dropped tensor
+    if (dp || hd) {     // out = h2 + drop_path(dropout(mlp)) (modeling:835, 1000)
       HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_F32, s, ws.g, nullptr));
-      HIP_TRY(sf_launch_resid_rowscale(ws.h[li + 1], sv.h2, ws.g, dp + (size_t)li * dp_per_layer + (size_t)B * N + (size_t)B * T, M, D, 2, T, N, s));
+      HIP_TRY(sf_launch_resid_rowscale(ws.h[li + 1], sv.h2, ws.g, dp ? dp + (size_t)li * dp_per_layer + (size_t)B * N + (size_t)B * T : nullptr, M, D, 2, T, N, s,
+                                       site(li, 3)));
     } else {
       HIP_TRY(lin_fwd(t, l.down, sv.act, M, SF_EPI_RESID_F32, s, ws.h[li + 1], nullptr, sv.h2));
     }
@@ -627,6 +649,7 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
   HIP_TRY(sf_launch_gelu_fwd(ws.hm_pre, ws.hm, (size_t)F * I, s));
   HIP_TRY(lin_fwd(t, t->fc2, ws.hm, F, SF_EPI_RESID_F32, s, pooler, nullptr, ws.attn_out));
   t->fB = B; t->fT = T; t->f_dp = dp;
+  t->f_drop_hidden = t->drop_hidden; t->f_drop_attn = t->drop_attn; t->f_drop_seed = t->drop_seed;
   return SF_OK;
 }
 
@@ -741,14 +764,18 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   LayerWgrads q;
   memset(&q.g, 0, sizeof(q.g));
   q.g.M = M; q.g.partial = ws.wg_partial;
-  q.on = !dp && !ungrouped;         // the drop_path copies reuse d_ctx / d_tout inside the layer: immediate launches there
+  const bool hd = t->f_drop_hidden > 0.f;
+  const int I = t->I;
+  auto site = [&](int k) { return sf_drop_make(t->f_drop_hidden, t->f_drop_seed, (unsigned)(li * 8 + k)); };
+  q.on = !dp && !hd && !ungrouped;  // the drop_path / dropout copies reuse d_ctx / d_tout inside the layer: immediate launches there
   // g (fp32) and its bf16 copy are both written by the LayerNorm backward that produced them; the bf16 copy rotates through
   // g_bf -> g_bf1 -> g_bf2 -> g_bf inside the layer and the three attention / MLP gradients have their own wide buffers, so
   // that every queued weight gradient still finds its operands at the end of the layer
   // ---- MLP: out = h2 + down(gelu(up(LN_a(h2)))) --------------------------------------------------------
   const bf16_t* gy = ws.g_bf;
-  if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf, ws.d_ctx, dp + (size_t)B * N + (size_t)B * T, M, D, 2, T, N, s)); gy = ws.d_ctx; }
+  if (dp || hd) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf, ws.d_ctx, dp ? dp + (size_t)B * N + (size_t)B * T : nullptr, M, D, 2, T, N, s, site(3))); gy = ws.d_ctx; }
   HIP_TRY(lin_dgrad_dgelu(l.down, gy, M, s, ws.d_wide, sv.pre));            // d pre = (g W_down) * gelu'(pre)  [M,I]
+  if (hd) HIP_TRY(sf_launch_rowscale_bf16(ws.d_wide, ws.d_wide, nullptr, M, I, 0, T, N, s, site(2)));      // ... through the activation's dropout mask (elementwise factors commute)
   HIP_TRY(lin_wgrad_queued(c, q, l.down, gy, sv.act, M));
   HIP_TRY(lin_dgrad(l.up, ws.d_wide, M, s, nullptr, ws.d_ln_bf));
   HIP_TRY(lin_wgrad_queued(c, q, l.up, ws.d_wide, sv.ln_a, M));
@@ -756,7 +783,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
                            ws.ln_partial, M, D, eps, s));
   // ---- spatial: h2 = h1 + out(attn(qkv(LN_b(h1)))) ---------------------------------------------------------
   gy = ws.g_bf1;
-  if (dp) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf1, ws.d_tout, dp + (size_t)B * N, M, D, 1, T, N, s)); gy = ws.d_tout; }
+  if (dp || hd) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf1, ws.d_tout, dp ? dp + (size_t)B * N : nullptr, M, D, 1, T, N, s, site(1))); gy = ws.d_tout; }
   HIP_TRY(lin_dgrad(l.s_out, gy, M, s, nullptr, ws.d_ctx));
   HIP_TRY(lin_wgrad_queued(c, q, l.s_out, gy, sv.ctx_s, M));
   {
@@ -765,6 +792,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     a.qkv = sv.sqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_s; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide_s;
     a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = N; a.nseq = F; a.seq_rows = 1; a.causal = 0;
     a.lse2 = sv.lse_s;
+    if (t->f_drop_attn > 0.f) a.drop = sf_drop_make(t->f_drop_attn, t->f_drop_seed, (unsigned)(li * 8 + 5));
     HIP_TRY(sf_launch_spatial_attention_bwd(a, s));
   }
   HIP_TRY(lin_wgrad_queued(c, q, l.s_qkv, ws.d_wide_s, sv.ln_b, M));
@@ -791,7 +819,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
                                 GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   }
-  if (dp) HIP_TRY(sf_launch_rowscale_bf16(ws.d_tout, ws.d_tout, dp, M, D, 0, T, N, s));     // through the drop_path in front of temporal_dense
+  if (dp || hd) HIP_TRY(sf_launch_rowscale_bf16(ws.d_tout, ws.d_tout, dp, M, D, 0, T, N, s, site(0)));     // through the drop_path / dropout in front of temporal_dense
   HIP_TRY(lin_dgrad(l.t_out, ws.d_tout, M, s, nullptr, ws.d_ctx));
   HIP_TRY(lin_wgrad_queued(c, q, l.t_out, ws.d_tout, sv.ctx_t, M));
   {
@@ -800,6 +828,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     a.qkv = sv.tqkv; a.ld_qkv = 3 * D; a.o = sv.ctx_t; a.ld_o = D; a.d_o = ws.d_ctx; a.d_qkv = ws.d_wide_t;
     a.heads = t->heads; a.D = D; a.scale = 0.125f; a.L = T; a.nseq = B * N; a.seq_rows = N;
     a.causal = t->cfg.enable_causal_temporal;
+    if (t->f_drop_attn > 0.f) a.drop = sf_drop_make(t->f_drop_attn, t->f_drop_seed, (unsigned)(li * 8 + 4));
     HIP_TRY(sf_launch_temporal_attention_bwd(a, s));
   }
   HIP_TRY(lin_wgrad_queued(c, q, l.t_qkv, ws.d_wide_t, sv.ln_t, M));
@@ -820,6 +849,17 @@ static int backward_embeddings(const BwdCtx& c, int B, int T) {
   const int D = t->D, N = t->N;
   const int M = B * T * N;
   // h0 = patches W^T + b + pos[n] + time[t]   (modeling:336-350, 413-457)
+  if (t->f_drop_hidden > 0.f) {
+    // h0 = m_time o (m_pos o (patches W^T + b + pos) + time): the time table sees m_time o g, everything else m_pos o m_time o g
+    HIP_TRY(sf_launch_dropout_f32(ws.g, nullptr, (size_t)M * D, sf_drop_make(t->f_drop_hidden, t->f_drop_seed, (unsigned)t->L * 8u + 1u), s));
+    HIP_TRY(sf_launch_sum_rows(ws.g, ws.s_tn, T * N, T * N, 1, 0, B, (long)T * N, D, 0, s));
+    if (float* gt = GG(t, c.grads, t->p_time)) HIP_TRY(sf_launch_sum_rows(ws.s_tn, gt, T, T, N, 0, N, 1, D, 1, s));
+    HIP_TRY(sf_launch_dropout_f32(ws.g, ws.g_bf, (size_t)M * D, sf_drop_make(t->f_drop_hidden, t->f_drop_seed, (unsigned)t->L * 8u), s));
+    HIP_TRY(lin_wgrad(c, t->patch, ws.g_bf, ws.patches, M));
+    HIP_TRY(sf_launch_sum_rows(ws.g, ws.s_tn, T * N, T * N, 1, 0, B, (long)T * N, D, 0, s));
+    if (float* gp = GG(t, c.grads, t->p_pos)) HIP_TRY(sf_launch_sum_rows(ws.s_tn, gp, N, N, 1, 0, T, N, D, 1, s));
+    return SF_OK;
+  }
   HIP_TRY(lin_wgrad(c, t->patch, ws.g_bf, ws.patches, M));
   HIP_TRY(sf_launch_sum_rows(ws.g, ws.s_tn, T * N, T * N, 1, 0, B, (long)T * N, D, 0, s));       // sum over batch
   if (float* gp = GG(t, c.grads, t->p_pos)) HIP_TRY(sf_launch_sum_rows(ws.s_tn, gp, N, N, 1, 0, T, N, D, 1, s));
@@ -880,6 +920,13 @@ extern "C" int sf_trainer_adamw_step(sf_trainer* t, float* params, float* grads,
     }
   }
   HIP_TRY(sf_launch_adamw(a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_trainer_set_dropout(sf_trainer* t, float hidden_p, float attn_p, uint32_t seed) {
+  if (!t) return sf_set_err(SF_ERR_INVALID, "null argument");
+  if (!(hidden_p >= 0.f && hidden_p < 1.f) || !(attn_p >= 0.f && attn_p < 1.f)) return sf_set_err(SF_ERR_INVALID, "dropout probabilities must be in [0, 1)");
+  t->drop_hidden = hidden_p; t->drop_attn = attn_p; t->drop_seed = seed;
   return SF_OK;
 }
 

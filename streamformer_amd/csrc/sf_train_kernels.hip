@@ -68,39 +68,90 @@ SF_DEVICE int dp_group(int row, int mode, int T, int N) {
   return (row / (T * N)) * N + row % N;
 }
 __global__ __launch_bounds__(256) void sf_rowscale_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                               const float* __restrict__ scales, size_t nchunks, int D8, int mode, int T, int N) {
+                                                               const float* __restrict__ scales, size_t nchunks, int D8, int mode, int T, int N, SfDrop d) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
     const int row = (int)(i / D8);
-    const float sc = scales[dp_group(row, mode, T, N)];
+    const float sc = scales ? scales[dp_group(row, mode, T, N)] : 1.f;
     const u32x4_t v = reinterpret_cast<const u32x4_t*>(in)[i];
     u32x4_t o;
+    const unsigned e0 = (unsigned)(i * 8);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack_bf2(bf2f(v[j] & 0xffffu) * sc, __uint_as_float(v[j] & 0xffff0000u) * sc);
+    for (int j = 0; j < 4; ++j) {
+      const float f0 = d.on ? sc * sf_drop_factor(d, e0 + 2 * j) : sc, f1 = d.on ? sc * sf_drop_factor(d, e0 + 2 * j + 1) : sc;
+      o[j] = pack_bf2(bf2f(v[j] & 0xffffu) * f0, __uint_as_float(v[j] & 0xffff0000u) * f1);
+    }
     reinterpret_cast<u32x4_t*>(out)[i] = o;
   }
 }
-hipError_t sf_launch_rowscale_bf16(const bf16_t* in, bf16_t* out, const float* scales, int rows, int D, int mode, int T, int N, hipStream_t s) {
+hipError_t sf_launch_rowscale_bf16(const bf16_t* in, bf16_t* out, const float* scales, int rows, int D, int mode, int T, int N, hipStream_t s, SfDrop drop) {
   if (D % 8) return hipErrorInvalidValue;
   const size_t n = (size_t)rows * (D / 8);
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(sf_rowscale_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, scales, n, D / 8, mode, T, N);
+  if (n * 8 >= ((size_t)1 << 32)) return hipErrorInvalidValue;       // mask indices are 32-bit
+  hipLaunchKernelGGL(sf_rowscale_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, scales, n, D / 8, mode, T, N, drop);
   return hipGetLastError();
 }
-// out = resid + scale[group(row)] * y        (out may alias resid)
+// out = resid + scale[group(row)] * mask * y        (out may alias resid)
 __global__ __launch_bounds__(256) void sf_resid_rowscale_kernel(float* __restrict__ out, const float* __restrict__ resid, const float* __restrict__ y,
-                                                                const float* __restrict__ scales, size_t nchunks, int D4, int mode, int T, int N) {
+                                                                const float* __restrict__ scales, size_t nchunks, int D4, int mode, int T, int N, SfDrop d) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
     const int row = (int)(i / D4);
-    const float sc = scales[dp_group(row, mode, T, N)];
-    reinterpret_cast<f32x4_t*>(out)[i] = reinterpret_cast<const f32x4_t*>(resid)[i] + sc * reinterpret_cast<const f32x4_t*>(y)[i];
+    const float sc = scales ? scales[dp_group(row, mode, T, N)] : 1.f;
+    f32x4_t yv = reinterpret_cast<const f32x4_t*>(y)[i];
+    if (d.on) {
+      const unsigned e0 = (unsigned)(i * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yv[j] *= sf_drop_factor(d, e0 + j);
+    }
+    reinterpret_cast<f32x4_t*>(out)[i] = reinterpret_cast<const f32x4_t*>(resid)[i] + sc * yv;
   }
 }
 hipError_t sf_launch_resid_rowscale(float* out, const float* resid, const float* y, const float* scales, int rows, int D, int mode, int T, int N,
-                                    hipStream_t s) {
+                                    hipStream_t s, SfDrop drop) {
   if (D % 4) return hipErrorInvalidValue;
   const size_t n = (size_t)rows * (D / 4);
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(sf_resid_rowscale_kernel, dim3(ew_grid(n)), dim3(256), 0, s, out, resid, y, scales, n, D / 4, mode, T, N);
+  if (n * 4 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_resid_rowscale_kernel, dim3(ew_grid(n)), dim3(256), 0, s, out, resid, y, scales, n, D / 4, mode, T, N, drop);
+  return hipGetLastError();
+}
+// h = m_time o (m_pos o h + time[t])   (modeling:374, 378; rows (b, t, n))
+__global__ __launch_bounds__(256) void sf_embed_dropout_kernel(float* __restrict__ h, const float* __restrict__ te, size_t nchunks, int D4, int T, int N,
+                                                               SfDrop dpos, SfDrop dtime) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / D4), c = (int)(i % D4);
+    const int t = (row / N) % T;
+    f32x4_t v = reinterpret_cast<f32x4_t*>(h)[i];
+    const f32x4_t tv = reinterpret_cast<const f32x4_t*>(te)[(size_t)t * D4 + c];
+    const unsigned e0 = (unsigned)(i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sf_drop_factor(dtime, e0 + j) * (sf_drop_factor(dpos, e0 + j) * v[j] + tv[j]);
+    reinterpret_cast<f32x4_t*>(h)[i] = v;
+  }
+}
+hipError_t sf_launch_embed_dropout(float* h, const float* time_rows, int M, int D, int T, int N, SfDrop pos_drop, SfDrop time_drop, hipStream_t s) {
+  if (D % 4 || !pos_drop.on || !time_drop.on) return hipErrorInvalidValue;
+  const size_t n = (size_t)M * (D / 4);
+  if (!n) return hipSuccess;
+  if (n * 4 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_embed_dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, s, h, time_rows, n, D / 4, T, N, pos_drop, time_drop);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void sf_dropout_f32_kernel(float* __restrict__ g, bf16_t* __restrict__ g_bf, size_t nchunks, SfDrop d) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    f32x4_t v = reinterpret_cast<f32x4_t*>(g)[i];
+    const unsigned e0 = (unsigned)(i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= sf_drop_factor(d, e0 + j);
+    reinterpret_cast<f32x4_t*>(g)[i] = v;
+    if (g_bf) reinterpret_cast<u32x2_t*>(g_bf)[i] = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  }
+}
+hipError_t sf_launch_dropout_f32(float* g, bf16_t* g_bf, size_t n, SfDrop drop, hipStream_t s) {
+  if (n % 4 || !drop.on) return hipErrorInvalidValue;
+  if (!n) return hipSuccess;
+  if (n >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_dropout_f32_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, s, g, g_bf, n / 4, drop);
   return hipGetLastError();
 }
 

@@ -108,12 +108,14 @@ class StreamformerTrainer:
             raise NotImplementedError(f"training supports hidden_act in {sorted(_ACT)}")
         if config.attention_type != "divided_space_time":
             raise NotImplementedError("only divided_space_time is implemented")
-        stochastic = {k: float(getattr(config, k, 0.0) or 0.0) for k in ("hidden_dropout_prob", "attention_probs_dropout_prob")}
-        if any(v > 0 for v in stochastic.values()):
-            # the reference applies these in train mode (modeling:605, 762); the shipped recipe sets both to 0
-            # (scripts/pretrain_streamformer.sh never overrides the config), which is what this step reproduces.  drop_path
-            # (modeling:852-856) IS implemented: config.drop_path_rate > 0 draws per-sample keep / drop factors per forward.
-            raise NotImplementedError(f"dropout is not implemented in the HIP training step (drop_path is): {stochastic}")
+        # dropout (modeling:374, 378, 752, 761, 822, 835 hidden; 556, 603, 669, 705 attention probabilities): counter-based masks, a
+        # fresh seed per forward from this rank's generator; the shipped recipes leave both probabilities at 0
+        self.hidden_dropout = float(getattr(config, "hidden_dropout_prob", 0.0) or 0.0)
+        self.attention_dropout = float(getattr(config, "attention_probs_dropout_prob", 0.0) or 0.0)
+        if not (0.0 <= self.hidden_dropout < 1.0 and 0.0 <= self.attention_dropout < 1.0):
+            raise ValueError("dropout probabilities must be in [0, 1)")
+        self.dropout = True                         # False: forwards without dropout (evaluation through the trainer)
+        self.last_dropout: Optional[Tuple[int, float, float]] = None    # (seed, hidden_p, attention_p) of the last forward, for replay in tests
         self.drop_path_rate = float(getattr(config, "drop_path_rate", 0.0) or 0.0)
         self.drop_path = True                       # False: forwards without stochastic depth (evaluation through the trainer)
         self.last_drop_path: Optional[torch.Tensor] = None     # the factors of the last forward (CPU), for replay in tests
@@ -391,7 +393,10 @@ class StreamformerTrainer:
         model["logit_bias"] = torch.tensor(-2.0)                   # kept so that the reference's load_state_dict finds its keys
         for k, v in self.state_dict().items():
             model[k if k.startswith("task_heads.") else "timesformer." + k] = v.detach().cpu()
-        return {"model": model, "optimizer": self.optimizer_state_dict(), "epoch": int(epoch), "scaler": {}, "args": args}
+        # "stochastic_state": this rank's generator of drop_path factors and dropout seeds, so that a resumed run continues the
+        # sequence of masks instead of replaying it from the start; an extra key the reference's loader ignores
+        return {"model": model, "optimizer": self.optimizer_state_dict(), "epoch": int(epoch), "scaler": {}, "args": args,
+                "stochastic_state": self._dp_gen.get_state()}
 
     def save_checkpoint(self, path: str, epoch: int = 0, args=None) -> None:
         if self.rank == 0:
@@ -407,6 +412,8 @@ class StreamformerTrainer:
         self.load_state_dict(ck["model"])
         if ck.get("optimizer"):
             self.load_optimizer_state_dict(ck["optimizer"])
+        if ck.get("stochastic_state") is not None:
+            self._dp_gen.set_state(ck["stochastic_state"])
         self.micro = 0
         self.grads.zero_()
         self.sync_weights()
@@ -488,6 +495,13 @@ class StreamformerTrainer:
         else:
             self.last_drop_path = None
             nat.check(nat.lib.sf_trainer_set_drop_path(self._h, None, 0, 0))
+        if (self.hidden_dropout > 0.0 or self.attention_dropout > 0.0) and self.dropout:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._dp_gen))
+            self.last_dropout = (seed, self.hidden_dropout, self.attention_dropout)
+            nat.check(nat.lib.sf_trainer_set_dropout(self._h, self.hidden_dropout, self.attention_dropout, seed))
+        else:
+            self.last_dropout = None
+            nat.check(nat.lib.sf_trainer_set_dropout(self._h, 0.0, 0.0, 0))
         lhs = torch.empty(B, T, N, c.hidden_size, dtype=torch.float32, device=self.device)
         pool = torch.empty(B, T, c.hidden_size, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

@@ -737,8 +737,44 @@ def test_drop_path_gradients_match_the_oracle_on_the_same_draw(task_idx):
     want = orc.loss(task, x, ti)
     l3, _, _ = tr.loss_and_grad(task, p3, _to_dev(ti, dev))
     assert tr.last_drop_path is None and abs(float(l3) - float(want.detach())) < 2e-2 * abs(float(want.detach()))
-    with pytest.raises(NotImplementedError):
-        StreamformerTrainer(small_cfg(hidden_dropout_prob=0.1), make_state_dict(small_cfg(), seed=1), ["retrieval"], device=dev)
+
+
+@pytest.mark.parametrize("task_idx,hid,att,dpr", [(0, 0.2, 0.0, 0.0), (1, 0.15, 0.0, 0.3), (0, 0.0, 0.2, 0.0), (1, 0.1, 0.1, 0.0)])
+def test_dropout_gradients_match_the_oracle_on_the_same_masks(task_idx, hid, att, dpr):
+    """VERDICT r3 missing #2: config.hidden_dropout_prob / attention_probs_dropout_prob in the training step, at the reference's
+    sites (modeling:374, 378 embeddings; 752, 761 SelfOutput; 822, 835 MLP; 556, 603, 669, 705 attention probabilities).  Masks are
+    counter-based — a function of (seed, site, element index) — so the oracle's autograd replays exactly the draw of the forward;
+    also together with drop_path.  A new seed per forward; `dropout = False` gives the plain forward."""
+    from oracle import train_oracle as TO
+    from streamformer_amd.init_weights import make_state_dict
+    from streamformer_amd.training import StreamformerTrainer
+    cfg = small_cfg(add_lora_spatial=True, hidden_dropout_prob=hid, attention_probs_dropout_prob=att, drop_path_rate=dpr, num_hidden_layers=3)
+    sd = make_state_dict(cfg, seed=8, lora=True)
+    dev = _dev()
+    tr = StreamformerTrainer(cfg, sd, ["retrieval", "localization"], freeze_spatial=True, device=dev, drop_path_seed=7)
+    orc = TO.OracleTrainer(sd, cfg, ["retrieval", "localization"], freeze_spatial=True)
+    task, x, ti, _ = TO.schedule(cfg, B=4)[task_idx]
+    _, pooler = tr.forward(x.to(dev))
+    drop = tr.last_dropout
+    assert drop is not None and drop[1:] == (hid, att)
+    loss, gp, gs = tr.loss_and_grad(task, pooler, _to_dev(ti, dev))
+    tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+    tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+    tr.backward(gp)
+    torch.cuda.synchronize()
+    want_loss = orc.loss(task, x, ti, drop_path=tr.last_drop_path, dropout=drop)
+    want_loss.backward()
+    assert abs(float(loss) - float(want_loss)) < 2e-2 * abs(float(want_loss))
+    _compare_grads(tr, orc, scalar_rel=0.2)
+    plain = float(orc.loss(task, x, ti).detach())
+    assert abs(plain - float(want_loss)) > 1e-4 * abs(plain)                      # the masks really change the forward
+    tr.forward(x.to(dev))
+    assert tr.last_dropout[0] != drop[0]                                           # a new seed per forward
+    tr.dropout = False
+    tr.drop_path = False
+    _, p3 = tr.forward(x.to(dev))
+    l3, _, _ = tr.loss_and_grad(task, p3, _to_dev(ti, dev))
+    assert tr.last_dropout is None and abs(float(l3) - plain) < 2e-2 * abs(plain)
 
 
 def test_trainer_rejects_what_it_cannot_do():
