@@ -188,6 +188,7 @@ class StreamformerTrainer:
         # kernel — {sticky flag, skipped steps}; the host looks at it only in check_finite() / at checkpoints
         self._guard = torch.zeros(2, dtype=torch.int32, device=dev) if nonfinite_guard else None
         self._last_loss: Optional[torch.Tensor] = None
+        self._wire: Optional[torch.Tensor] = None       # bf16 wire format of the gradient all-reduce (grad_reduce_dtype="bf16")
         self.step_count = 0
         self.micro = 0
         # torch.optim.AdamW keeps `step` per parameter and skips parameters whose grad is None: a head whose task was not
@@ -532,7 +533,12 @@ class StreamformerTrainer:
                     if self.grad_reduce_dtype == "bf16":
                         # half the bytes on the xGMI links (204 MB instead of 407 MB per step for SigLIP-base);
                         # the sum over <= 8 ranks is taken in bf16, the optimizer state stays fp32
-                        half = sl.to(torch.bfloat16)
+                        # persistent wire buffer (no allocation per bucket and step); the copy back after wait() stays: the clip /
+                        # guard passes and AdamW read the fp32 buffer
+                        if self._wire is None:
+                            self._wire = torch.empty(self.n_train, dtype=torch.bfloat16, device=self.device)
+                        half = self._wire[off: off + n]
+                        half.copy_(sl)
                         works.append((torch.distributed.all_reduce(half, group=self.group, async_op=True), sl, half))
                     else:
                         works.append((torch.distributed.all_reduce(sl, group=self.group, async_op=True), None, None))
