@@ -371,7 +371,9 @@ SF_DEVICE bf16x8_t sp_tr_frag(const char* img, int r0, int et, int lane) {
 // ACC = the fp32-accurate mode on the same structure: q / k / v arrive as hi + lo bf16 planes (the qkv GEMM writes them
 // instead of fp32, same bytes), four images (K hi, V hi, K lo, V lo) land by DMA, every product is three MFMAs
 // (lo*hi + hi*lo + hi*hi) and the probabilities are split into hi + lo in registers.
-template <int MAXNT, bool ACC>       // 16-key tiles held in registers: 14 -> N <= 224
+// DROP = dropout on the probabilities (training forward with attention_probs_dropout_prob > 0): its own instance, so that the mask
+// arithmetic costs the plain kernel no registers (117 VGPRs = two workgroups per CU; with the branch compiled in: 156, one workgroup)
+template <int MAXNT, bool ACC, bool DROP = false>       // 16-key tiles held in registers: 14 -> N <= 224
 __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAttnArgs p, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
       const int qi = qt * 16 + l15;
       if (qi < N) p.lse2_out[((size_t)frame * p.heads + h) * N + qi] = mc + __log2f(sum);
     }
-    if (p.drop.on) {                   // training: dropout on the (normalised) probabilities (modeling:705) — `sum` above is unmasked
+    if (DROP && p.drop.on) {           // training: dropout on the (normalised) probabilities (modeling:705) — `sum` above is unmasked
       const int qd = qt * 16 + l15 < N ? qt * 16 + l15 : N - 1;
       const unsigned dbase = (unsigned)((((size_t)frame * p.heads + h) * N + qd) * N);
 #pragma unroll
@@ -1048,6 +1050,13 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
     }
 #endif
     const size_t lds2 = (size_t)nkp * 256 + SP_WAVES * 2048;
+    if (a.drop.on) {
+      static SfPerDeviceOnce attr4;
+      if (attr4.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false, true>), grid, block, lds2, s, a, qsplit);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false>), grid, block, lds2, s, a, qsplit);
     return hipGetLastError();
   }

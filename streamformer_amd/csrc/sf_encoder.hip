@@ -694,6 +694,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const float scale = 1.0f / sqrtf(64.0f);
 
   bool embed_emitted_stats = false;
+  // statistics rows of the bf16 fold are 8 floats = four pairs; the 384-column panel kernel fills pairs 0 and 2 only
+  if (e->compute == SF_COMPUTE_BF16 && !streaming && (stages & 3) && ln_fold_ok(e, B * T * ((H / e->cfg.patch_size) * (W / e->cfg.patch_size))))
+    HIP_TRY(hipMemsetAsync(ws.ln_stats, 0, (size_t)B * T * ((H / e->cfg.patch_size) * (W / e->cfg.patch_size)) * 8 * sizeof(float), s));
   // pm: the residual stream of a whole bf16 forward at BASELINE-sized M travels as hi + lo bf16 planes (hi = xn_hi, the A operand
   // of the folded Linears; lo = res_lo) instead of fp32: every residual producer moves 154 MB instead of 192 (no separate bf16
   // copy).  Only for complete forwards without hidden_states (the fp32 tensor is the interface of the stage-wise entry points).
@@ -1369,6 +1372,7 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   const bool pm = !planes_off && !acc && epi == SF_EPI_RESID_F32 && ln_fold_ok(e, M);
   float* st = pm ? c.take<float>((size_t)M * 8) : nullptr;
   if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
+  if (st) HIP_TRY(hipMemsetAsync(st, 0, (size_t)M * 8 * sizeof(float), (hipStream_t)stream));
   auto go = [&]() {
     return pm ? run_linear(e, *lin, ah, al, M, epi, s, nullptr, oh, ol, nullptr, 0.f, 0, 0, 0, 0, nullptr, st, false, nullptr, 0, oh, ol)
               : run_linear(e, *lin, ah, al, M, epi, s, of, oh, ol, of, 0.f);

@@ -263,12 +263,10 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
           s1 = wave_sum_dpp(s1);
           s2 = wave_sum_dpp(s2);
           if (elane == 0) {
-            if (p.ln_stats_wide) {      // rows of 8 floats = four pairs (sf_gemm_pp.hip writes one per 192-column quarter): this half's pair + an empty one
-              *reinterpret_cast<f32x4_t*>(p.ln_stats_out + (size_t)m * 8 + nh * 4) = (f32x4_t){s1, s2, 0.f, 0.f};
-            } else {
-              p.ln_stats_out[(size_t)m * 4 + nh * 2 + 0] = s1;
-              p.ln_stats_out[(size_t)m * 4 + nh * 2 + 1] = s2;
-            }
+            // rows of 8 floats = four pairs (the lab kernels sf_gemm_pp / sf_gemm_pipe write one per 192-column quarter): this half's
+            // pair; pairs 1 and 3 stay at the zeros run_forward put there once per forward
+            p.ln_stats_out[(size_t)m * 8 + nh * 4 + 0] = s1;
+            p.ln_stats_out[(size_t)m * 8 + nh * 4 + 1] = s2;
           }
         }
       }
@@ -319,6 +317,7 @@ bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split) {
   if (a.resid_hi && (!a.resid_lo || !a.out_lo || a.epi != SF_EPI_RESID_F32 || a.resid_mod > 0)) return false;
   if (a.epi != SF_EPI_RESID_F32 && a.epi != SF_EPI_F32 && a.epi != SF_EPI_BF16) return false;
   if (a.ln_stats) return false;                     // LN-folded consumers run on the 256^2 kernel
+  if (a.ln_stats_out && !a.ln_stats_wide) return false;   // statistics rows are 8 floats wide (SfGemmArgs::ln_stats_wide)
   if (a.K % 32 || a.K < 128) return false;
   if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32)) return false;
   return panel_plan(a.M).ok != 0;
