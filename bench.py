@@ -525,7 +525,7 @@ def main():
         panel_tflops = panel_flop / panel_ms / 1e9
         traffic, traffic_note, traffic_from = None, "no PMC file", None
         try:   # HBM-side bytes per launch IMPORTED from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             traffic_from = "profiles/" + pmc_file
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)

@@ -157,7 +157,11 @@ def test_train_bench_eight_ranks_on_one_device():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device",
            "--mode", "train", "--batch", "1"]
-    out = _one_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1100))
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1100)
+    if r.returncode != 0:      # eight processes importing torch and meeting over gloo on a busy box: one retry, then the evidence
+        print("first attempt failed:", r.stdout[-800:], r.stderr[-2500:])
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1100)
+    out = _one_line(r)
     assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
     assert sorted(r["rank"] for r in out["ranks_seen"]) == list(range(8)) and len({r["pid"] for r in out["ranks_seen"]}) == 8
     assert out["allreduce_buckets"] >= 2 and out["allreduce_ms"]["isolated"] > 0
