@@ -110,8 +110,8 @@ int sf_forward_profile(sf_encoder* enc, const void* pixels_dev, int pixel_dtype,
                        sf_stream stream, float* out_ms_host);
 
 /* same, additionally returning the spatial attention probabilities of every layer
- * (output_attentions=True, modeling:703-716, 1052-1057): attentions_dev fp32 [L, B*T, heads, N, N];
- * N <= 224 patches per frame.                                                                     */
+ * (output_attentions=True, modeling:703-716, 1052-1057): attentions_dev fp32 [L, B*T, heads, N, N]
+ * (any N the attention kernels take: above 224 patches the streamed-keys kernel makes a second sweep).  */
 int sf_forward_attentions(sf_encoder* enc, const void* pixels_dev, int pixel_dtype, int B, int T, int H, int W,
                           float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
                           float* attentions_dev, const float* pos_dev, void* workspace_dev,
@@ -161,7 +161,7 @@ int sf_forward_stream(sf_encoder* enc, sf_cache* cache, const void* pixels_dev, 
                       int T_new, float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev,
                       const float* pos_dev, void* workspace_dev, size_t workspace_bytes, sf_stream stream);
 /* The same call with output_attentions (timesformer_encoder.py:494, 557, 633, 659, 720-754): attentions_dev receives the
- * spatial attention probabilities of the NEW frames, [L, B * T_new, heads, N, N] fp32 (N <= 224), as sf_forward_attentions
+ * spatial attention probabilities of the NEW frames, [L, B * T_new, heads, N, N] fp32, as sf_forward_attentions
  * returns them for whole clips.  Runs the launches eagerly (no graph replay).                                            */
 int sf_forward_stream_attentions(sf_encoder* enc, sf_cache* cache, const void* pixels_dev, int pixel_dtype, int T_new,
                                  float* last_hidden_dev, float* pooler_dev, float* hidden_states_dev, float* attentions_dev,

@@ -942,10 +942,61 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_large_kernel(Sf
       }
     }
   }
-  if (!active) return;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
+  const float inv = active ? 1.0f / l : 0.f;
+  if (p.probs) {
+    // output_attentions above 224 patches (round 4): a second sweep over the keys with the FINAL row maximum and sum — the scores of a
+    // chunk are recomputed from the re-staged K rows and leave as probabilities, [frames, heads, N, N] fp32 (modeling:703-716)
+    const float mc = m * c;
+    for (int key0 = 0; key0 < N; key0 += SL_KC) {
+      __syncthreads();
+      for (int i = tid; i < SL_KC * 8; i += SP_WAVES * 64) {
+        const int key = i >> 3, ch = i & 7;
+        u32x4_t hv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+        if (key0 + key < N) {
+          bf16x8_t a, b;
+          load_frag<ACC>(p.k, (row0 + key0 + key) * p.row_pitch_kv + h * HD + ch * 8, a, b);
+          hv = __builtin_bit_cast(u32x4_t, a);
+          lv = __builtin_bit_cast(u32x4_t, b);
+        }
+        const int off = key * 128 + ((ch ^ kswz(key)) << 4);
+        *reinterpret_cast<u32x4_t*>(k_hi + off) = hv;
+        if (ACC) *reinterpret_cast<u32x4_t*>(k_lo + off) = lv;
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int qi = qt * 16 + l15;
+#pragma unroll
+      for (int kt2 = 0; kt2 < 4; ++kt2)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+          const int key = kt2 * 32 + (l15 >> 2) * 8 + hh * 4 + (l15 & 3);
+          const int sw = kswz(key);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int off = key * 128 + (((ks * 4 + g) ^ sw) << 4);
+            const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(k_hi + off);
+            if (ACC) {
+              const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(k_lo + off);
+              acc = mfma16(kl, qh[ks], acc);
+              acc = mfma16(kh, ql[ks], acc);
+            }
+            acc = mfma16(kh, qh[ks], acc);
+          }
+          // lane: query l15; keys key0 + 32 kt2 + 8 g + 4 hh + r
+          const int kbase = key0 + kt2 * 32 + g * 8 + hh * 4;
+          if (qi < N) {
+            float* dst = p.probs + (((size_t)frame * p.heads + h) * N + qi) * (size_t)N + kbase;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kbase + r < N) dst[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c, -mc)) * inv;
+          }
+        }
+    }
+  }
+  if (!active) return;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     unsigned int hb[4], lb[4];
@@ -993,7 +1044,6 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (a.drop.on && (accurate || a.probs || a.N > 224 || getenv("SF_DISABLE_SPATIAL_DMA") || (a.row_pitch_kv % 8))) return hipErrorInvalidValue;   // dropout: DMA kernel only
   const int nkp = (a.N + 31) & ~31;
   if (nkp > 32 * 7) {                               // more than 224 tokens per frame: streaming-key kernel
-    if (a.probs) return hipErrorInvalidValue;       // probabilities are only materialised by the all-keys-in-LDS kernel
     const int qblocks = (a.N + 127) / 128;
     const size_t lds = (size_t)(SL_KC * 128 + HD * 2 * SL_KC + SP_WAVES * 2048) * (accurate ? 2 : 1);
     static SfPerDeviceOnce attr_l;

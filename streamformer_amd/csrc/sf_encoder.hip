@@ -908,8 +908,6 @@ static int forward_common(sf_encoder* e, const void* pixels, int pixel_dtype, in
   if (!pixels || !last_hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
   if (pixel_dtype != SF_F32 && pixel_dtype != SF_BF16 && pixel_dtype != SF_U8) return set_err(SF_ERR_INVALID, "pixels must be fp32, bf16 or uint8");
   if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per clip");
-  if (attentions && N > 224)
-    return set_err(SF_ERR_INVALID, "attention probabilities are materialised for <= 224 patches per frame (got %d)", N);
   Workspace ws = carve(e, workspace, B, T, N, true);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
   return run_forward(e, pixels, pixel_dtype, B, T, H, W, last_hidden, pooler, hidden_states, pos_dev, ws, nullptr, T, 0,
@@ -970,7 +968,6 @@ static int stage_common(sf_encoder* e, const void* pixels, int pixel_dtype, int 
   if (!hidden || !workspace) return set_err(SF_ERR_INVALID, "null buffer");
   if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per clip");
   if ((stages & 2) && (la < 0 || lb > e->L || la > lb)) return set_err(SF_ERR_INVALID, "layer range [%d, %d) outside [0, %d)", la, lb, e->L);
-  if (attentions && N > 224) return set_err(SF_ERR_INVALID, "attention probabilities need <= 224 patches per frame");
   Workspace ws = carve(e, workspace, B, T, N, true);
   if (ws.bytes > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, ws.bytes);
   ws.resid = hidden;                       // the caller's tensor IS the residual stream
@@ -1108,8 +1105,6 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
   static const bool graphs_off = getenv("SF_DISABLE_STREAM_GRAPH") != nullptr;
-  if (attentions && N > 224)
-    return set_err(SF_ERR_INVALID, "attention probabilities are materialised for <= 224 patches per frame (got %d)", N);
   const bool use_graph = !graphs_off && !hidden_states && !attentions && cap == hipStreamCaptureStatusNone && T_new < 256 && c->len < 65536;
   if (!use_graph) {
     rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,

@@ -695,6 +695,15 @@ def test_forward_more_than_224_patches(mode, tol):
     cache = m.new_cache(1, 4)
     outs = [m(x[:, t:t + 1].cuda(), use_cache=True, past_key_values=cache).last_hidden_state for t in range(4)]
     assert maxabs(torch.cat(outs, 1), want["last_hidden_state"]) <= tol
+    # output_attentions above 224 patches (round 4): the streamed-keys kernel's second sweep, against the oracle's probabilities
+    col = {}
+    O.forward(sd, cfg, x[:, :2], collect=col)
+    oa = m(x[:, :2].cuda(), output_attentions=True)
+    assert len(oa.attentions) == cfg.num_hidden_layers and tuple(oa.attentions[0].shape) == (2, cfg.num_attention_heads, 576, 576)
+    for li in range(cfg.num_hidden_layers):
+        assert maxabs(oa.attentions[li], col["attentions"][li]) <= (2e-5 if mode == "fp32" else 2e-2)
+        assert float((oa.attentions[li].sum(-1) - 1).abs().max()) < 1e-4
+    assert maxabs(oa.last_hidden_state, want["last_hidden_state"][:, :2]) <= tol
 
 
 @pytest.mark.gpu
