@@ -373,7 +373,11 @@ SF_DEVICE bf16x8_t sp_tr_frag(const char* img, int r0, int et, int lane) {
 // (lo*hi + hi*lo + hi*hi) and the probabilities are split into hi + lo in registers.
 // DROP = dropout on the probabilities (training forward with attention_probs_dropout_prob > 0): its own instance, so that the mask
 // arithmetic costs the plain kernel no registers (117 VGPRs = two workgroups per CU; with the branch compiled in: 156, one workgroup)
-template <int MAXNT, bool ACC, bool DROP = false>       // 16-key tiles held in registers: 14 -> N <= 224
+// NTC = compile-time number of score tiles that hold real keys (13 for the 196 patches of a 224^2 frame), 0 = decided at run time.
+// With the count known every `if (tile exists)` of the score / PV loops folds away: hipcc then schedules the 28 K-fragment reads and
+// MFMAs of a query tile as ONE block (reads of the next tiles in flight under the MFMAs of this one) instead of fourteen basic blocks
+// of [2 ds_read -> wait -> MFMA -> wait -> MFMA] — round 4, found in the ISA, not in a profile.
+template <int MAXNT, bool ACC, bool DROP = false, int NTC = 0>       // 16-key tiles held in registers: 14 -> N <= 224
 __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAttnArgs p, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
   const int fhq = blockIdx.x / qsplit, qs = blockIdx.x % qsplit;
   const int frame = fhq / p.heads, h = fhq % p.heads;
   const int N = p.N;
-  const int nkp = (N + 31) & ~31;                        // keys padded to whole 32-key pairs of tiles
+  const int nkp = NTC ? ((NTC + 1) & ~1) * 16 : (N + 31) & ~31;      // keys padded to whole 32-key pairs of tiles
   const int nt = nkp >> 4;
   char* k_img = smem;
   char* v_img = k_img + nkp * 128;
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 #pragma unroll
     for (int jt = 0; jt < MAXNT; ++jt) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      if (jt * 16 < N) {                                   // tiles made of padding keys only are never computed
+      if (NTC ? jt < NTC : jt * 16 < N) {                  // tiles made of padding keys only are never computed
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8_t kh = sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g);
@@ -460,8 +464,8 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < MAXNT; ++jt) {
-      if (jt * 16 < N) {
-        if (jt * 16 + 16 > N) {                           // the tile that holds the first padding keys
+      if (NTC ? jt < NTC : jt * 16 < N) {
+        if (NTC ? jt == NTC - 1 : jt * 16 + 16 > N) {      // the tile that holds the first padding keys
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (jt * 16 + 4 * g + r >= N) s[jt][r] = -INFINITY;
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = 0.f;
-        if (jt * 16 < N) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
+        if (NTC ? jt < NTC : jt * 16 < N) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
         s[jt][r] = e;
         sum += e;
       }
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
       const unsigned dbase = (unsigned)((((size_t)frame * p.heads + h) * N + qd) * N);
 #pragma unroll
       for (int jt = 0; jt < MAXNT; ++jt)
-        if (jt * 16 < N) {
+        if (NTC ? jt < NTC : jt * 16 < N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = jt * 16 + 4 * g + r;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j2 = 0; j2 < MAXNT / 2; ++j2) {
-      if (2 * j2 < nt) {
+      if (NTC ? 2 * j2 < ((NTC + 1) & ~1) : 2 * j2 < nt) {
         const u32x4_t pu = {pack_bf2(s[2 * j2][0], s[2 * j2][1]), pack_bf2(s[2 * j2][2], s[2 * j2][3]),
                             pack_bf2(s[2 * j2 + 1][0], s[2 * j2 + 1][1]), pack_bf2(s[2 * j2 + 1][2], s[2 * j2 + 1][3])};
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
@@ -1107,12 +1111,21 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
       hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false, true>), grid, block, lds2, s, a, qsplit);
       return hipGetLastError();
     }
+    static const bool ntc_off = getenv("SF_DISABLE_SPATIAL_NTC") != nullptr;      // A/B switch
+    if (!ntc_off && ((a.N + 15) >> 4) == 13) {       // 193 .. 208 tokens per frame (224^2 inputs): the tile count as a compile-time constant
+      static SfPerDeviceOnce attr5;
+      if (attr5.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14, false, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false, false, 13>), grid, block, lds2, s, a, qsplit);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false>), grid, block, lds2, s, a, qsplit);
     return hipGetLastError();
   }
   if (accurate && !a.in_is_f32) {       // hi + lo bf16 planes (sf_spatial_planes_ok): the DMA kernel with three products
     if (a.probs || a.lo_plane_off <= 0 || (a.row_pitch_kv % 8) || (a.lo_plane_off % 8)) return hipErrorInvalidValue;
     const size_t lds2 = (size_t)nkp * 512 + SP_WAVES * 4096;
+    // (the compile-time tile count of the bf16 instance does not pay here: the accurate forward measured 20.6 against 18.7 ms with it)
     hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, true>), grid, block, lds2, s, a, qsplit);
     return hipGetLastError();
   }
