@@ -181,7 +181,7 @@ SF_DEVICE void phase_b_block(const BwdView& w, int jb, int nb, f32x4_t (&dk)[2][
             for (int r = 0; r < 4; ++r) {
               const int qi = q0 + 4 * g + r;
               const bool ok = kj < w.L && !(w.causal && kj > qi);
-              const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * w.sl2 - lse[r]) : 0.f;
+              const float pv = __builtin_amdgcn_exp2f(ok ? (s[r] * w.sl2 - lse[r]) : -INFINITY);   // mask the ARGUMENT: `ok ? exp2f() : 0` compiles to one exec-masked branch per element
               const float fd = bwd_drop(w, qi, kj);
               p[it2][jt2][r] = pv * fd;
               ds[it2][jt2][r] = pv * (fd * dp[r] - dl[r]) * w.scale;
@@ -256,7 +256,7 @@ SF_DEVICE void phase_c_block(const BwdView& w, int ib, int nb, f32x4_t (&dq)[2][
             for (int r = 0; r < 4; ++r) {
               const int kj = k0 + 4 * g + r;
               const bool ok = kj < w.L && !(w.causal && kj > qi);
-              const float pv = ok ? __builtin_amdgcn_exp2f(s[r] * w.sl2 - lse[it2]) : 0.f;
+              const float pv = __builtin_amdgcn_exp2f(ok ? (s[r] * w.sl2 - lse[it2]) : -INFINITY);
               ds[jt2][it2][r] = pv * (bwd_drop(w, qi, kj) * dp[r] - dl[it2]) * w.scale;
             }
           } else {
@@ -329,8 +329,13 @@ SF_DEVICE void stage_do_delta(char* img, float* delta, const bf16_t* d_o, const 
 // ---- 16-row owners (spatial kernel): the same products with one 16-key tile (phase B) or one 16-query tile (phase C) per
 // wave, so that 13 of 16 waves (L = 196) work instead of 7 of 8 and every SIMD has four waves to hide the
 // LDS -> MFMA -> exp2 -> MFMA chain behind.  The contraction over tokens still runs 32 rows per MFMA.
-template <bool DROP>
-SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb, f32x4_t (&dk)[4], f32x4_t (&dv)[4], int lane) {
+// NB > 0: the number of 32-row blocks as a compile-time constant (non-causal only) — the block loop unrolls into one
+// schedulable region, so the next block's row fragments are in flight under this block's MFMAs (same finding as the
+// forward kernel's NTC instance)
+template <bool DROP, int NB = 0>
+SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb_rt, f32x4_t (&dk)[4], f32x4_t (&dv)[4], int lane) {
+  const int nb = NB ? NB : nb_rt;
+  const bool causal = NB ? false : (w.causal != 0);
   const int l15 = lane & 15, g = lane >> 4;
   bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -341,7 +346,8 @@ SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb, f32x4_t (&dk)[4]
 #pragma unroll
   for (int b = 0; b < 4; ++b) dk[b] = dv[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int kj = jt * 16 + l15;
-  const int ib0 = w.causal ? (jt >> 1) : 0;
+  const int ib0 = causal ? (jt >> 1) : 0;
+#pragma unroll (NB ? NB : 1)
   for (int ib = ib0; ib < nb; ++ib) {
     f32x4_t p[2], ds[2];                   // [query tile]
 #pragma unroll
@@ -358,8 +364,8 @@ SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb, f32x4_t (&dk)[4]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = q0 + 4 * g + r;
-        const bool ok = kj < w.L && !(w.causal && kj > qi);
-        const float pv = ok ? __builtin_amdgcn_exp2f(sc[r] * w.sl2 - lse[r]) : 0.f;
+        const bool ok = kj < w.L && !(causal && kj > qi);
+        const float pv = __builtin_amdgcn_exp2f(ok ? (sc[r] * w.sl2 - lse[r]) : -INFINITY);
         const float fd = bwd_drop_t<DROP>(w, qi, kj);
         p[it2][r] = pv * fd;
         ds[it2][r] = pv * (fd * dp[r] - dl[r]) * w.scale;
@@ -374,8 +380,10 @@ SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb, f32x4_t (&dk)[4]
   }
 }
 
-template <bool DROP>
-SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb, f32x4_t (&dq)[4], int lane) {
+template <bool DROP, int NB = 0>
+SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb_rt, f32x4_t (&dq)[4], int lane) {
+  const int nb = NB ? NB : nb_rt;
+  const bool causal = NB ? false : (w.causal != 0);
   const int l15 = lane & 15, g = lane >> 4;
   bf16x8_t qf[2], gf[2];
 #pragma unroll
@@ -387,7 +395,8 @@ SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb, f32x4_t (&dq)[4]
   const float lse = w.lse2[qi], dl = w.delta[qi];
 #pragma unroll
   for (int b = 0; b < 4; ++b) dq[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int jb1 = w.causal ? (it >> 1) + 1 : nb;
+  const int jb1 = causal ? (it >> 1) + 1 : nb;
+#pragma unroll (NB ? NB : 1)
   for (int jb = 0; jb < jb1; ++jb) {
     f32x4_t ds[2];                          // [key tile]
 #pragma unroll
@@ -402,8 +411,8 @@ SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb, f32x4_t (&dq)[4]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kj = k0 + 4 * g + r;
-        const bool ok = kj < w.L && !(w.causal && kj > qi);
-        const float pv = ok ? __builtin_amdgcn_exp2f(sc[r] * w.sl2 - lse) : 0.f;
+        const bool ok = kj < w.L && !(causal && kj > qi);
+        const float pv = __builtin_amdgcn_exp2f(ok ? (sc[r] * w.sl2 - lse) : -INFINITY);
         ds[jt2][r] = pv * (bwd_drop_t<DROP>(w, qi, kj) * dp[r] - dl) * w.scale;
       }
     }
@@ -430,13 +439,14 @@ SF_DEVICE void tile16_to_patch(char* patch, const f32x4_t (&t)[4], int lane) {
 #define SB_IMG (SB_ROWS * 128)
 #define SB_PATCH 2048
 
-template <bool DROP>
+template <bool DROP, int NTC = 0>
 __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
   const int L = a.L;
-  const int nt = (L + 15) >> 4, nb = (L + 31) >> 5;
+  constexpr int NB = (NTC + 1) / 2;
+  const int nt = NTC ? NTC : (L + 15) >> 4, nb = NTC ? NB : (L + 31) >> 5;
   const int rows_pad = nb * 32;
   char* iq = smem;
   char* ik = smem + SB_IMG;
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   bf16_t* dqkv = a.d_qkv + h * 64;
   for (int jt = wave; jt < nt && !(a.lab & 1); jt += SB_WAVES) {
     f32x4_t dk[4], dv[4];
-    phase_b_tile16<DROP>(w, jt, nb, dk, dv, lane);
+    phase_b_tile16<DROP, NB>(w, jt, nb, dk, dv, lane);
     if ((a.lab & 4) && dk[0][0] + dv[0][0] != 12345.f) continue;
     tile16_to_patch(patch, dk, lane);
     patch_to_global(patch, dqkv + a.D, a.ld_qkv, row_base, 1, jt * 16, L, 16, lane);
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   }
   for (int it = wave; it < nt && !(a.lab & 2); it += SB_WAVES) {
     f32x4_t dq[4];
-    phase_c_tile16<DROP>(w, it, nb, dq, lane);
+    phase_c_tile16<DROP, NB>(w, it, nb, dq, lane);
     if ((a.lab & 4) && dq[0][0] != 12345.f) continue;
     tile16_to_patch(patch, dq, lane);
     patch_to_global(patch, dqkv, a.ld_qkv, row_base, 1, it * 16, L, 16, lane);
@@ -493,11 +503,16 @@ hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s
   if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel<false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   static const int lab = SF_LAB_SWITCH("SF_ATTN_BWD_LAB");      // timing lab: phases off, results invalid (lab builds only)
+  static const bool ntc_off = getenv("SF_DISABLE_SPATIAL_NTC") != nullptr;      // A/B switch (same one as the forward kernel)
   SfAttnBwdArgs b = a;
   b.lab = lab;
+  const int nt = (a.L + 15) >> 4;
   if (b.drop.on) hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel<true>, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, b);
+  else if (nt == 13 && !a.causal && !ntc_off)      // 224^2 frames: 196 patches = 13 tiles, block loops unrolled
+    hipLaunchKernelGGL((sf_spatial_attn_bwd_kernel<false, 13>), dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, b);
   else hipLaunchKernelGGL(sf_spatial_attn_bwd_kernel<false>, dim3(a.nseq * a.heads), dim3(SB_THREADS), lds, s, b);
   return hipGetLastError();
 }
