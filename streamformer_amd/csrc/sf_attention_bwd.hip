@@ -334,6 +334,7 @@ SF_DEVICE void stage_do_delta(char* img, float* delta, const bf16_t* d_o, const 
 // forward kernel's NTC instance)
 template <bool DROP, int NB = 0>
 SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb_rt, f32x4_t (&dk)[4], f32x4_t (&dv)[4], int lane) {
+  constexpr int kUnroll = NB ? NB : 1;
   const int nb = NB ? NB : nb_rt;
   const bool causal = NB ? false : (w.causal != 0);
   const int l15 = lane & 15, g = lane >> 4;
@@ -347,7 +348,7 @@ SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb_rt, f32x4_t (&dk)
   for (int b = 0; b < 4; ++b) dk[b] = dv[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int kj = jt * 16 + l15;
   const int ib0 = causal ? (jt >> 1) : 0;
-#pragma unroll (NB ? NB : 1)
+#pragma unroll kUnroll
   for (int ib = ib0; ib < nb; ++ib) {
     f32x4_t p[2], ds[2];                   // [query tile]
 #pragma unroll
@@ -382,6 +383,7 @@ SF_DEVICE void phase_b_tile16(const BwdView& w, int jt, int nb_rt, f32x4_t (&dk)
 
 template <bool DROP, int NB = 0>
 SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb_rt, f32x4_t (&dq)[4], int lane) {
+  constexpr int kUnroll = NB ? NB : 1;
   const int nb = NB ? NB : nb_rt;
   const bool causal = NB ? false : (w.causal != 0);
   const int l15 = lane & 15, g = lane >> 4;
@@ -396,7 +398,7 @@ SF_DEVICE void phase_c_tile16(const BwdView& w, int it, int nb_rt, f32x4_t (&dq)
 #pragma unroll
   for (int b = 0; b < 4; ++b) dq[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int jb1 = causal ? (it >> 1) + 1 : nb;
-#pragma unroll (NB ? NB : 1)
+#pragma unroll kUnroll
   for (int jb = 0; jb < jb1; ++jb) {
     f32x4_t ds[2];                          // [key tile]
 #pragma unroll

@@ -36,6 +36,24 @@ SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
   return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
 }
 
+// SF_PANEL_TRACE (tools/panel_trace_lab.hip only): shader-clock stamps around the segments of the epilogue, summed over waves into
+// panel_trace[]; bit 1 of the value drops the residual loads, bit 2 the plane stores, bit 3 the row arithmetic (what is left is latency)
+#ifdef SF_PANEL_TRACE
+__device__ unsigned long long panel_trace[16];
+#define PT_DECL unsigned long long pt_[6] = {0, 0, 0, 0, 0, 0}, pt_t = 0, pt_0 = 0
+#define PT_START() do { pt_t = pt_0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define PT_MARK(i) do { const unsigned long long pt_n = __builtin_amdgcn_s_memtime(); pt_[i] += pt_n - pt_t; pt_t = pt_n; } while (0)
+#define PT_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&panel_trace[i_], pt_[i_]); \
+    atomicAdd(&panel_trace[6], __builtin_amdgcn_s_memtime() - pt_0); atomicAdd(&panel_trace[7], 1ull); } } while (0)
+#define PT_OFF(bit) ((SF_PANEL_TRACE) & (bit))
+#else
+#define PT_DECL
+#define PT_START()
+#define PT_MARK(i)
+#define PT_FLUSH()
+#define PT_OFF(bit) 0
+#endif
+
 template <int P_MT>
 __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,6 +104,8 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(dst + P_A_BYTES + 16384), 16, offW[2], kof, 0, 0);
   };
 
+  PT_DECL;
+  PT_START();
   f32x4_t acc[P_MT][P_NT];
 #pragma unroll
   for (int i = 0; i < P_MT; ++i)
@@ -156,7 +176,18 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     __builtin_amdgcn_s_barrier();
   }
 
+#ifdef SF_LAB      // lab library only (SF_PANEL_LAB_EPI): 1 = odd tiles, 3 = three of four tiles, 2 = all tiles leave without their epilogue —
+  // is the epilogue bound by the chip's HBM rate (time falls with the number of CUs in it) or per CU?  Results are invalid.
+  if (p.w_nt >= 78) {
+    const int lm = p.w_nt - 78;
+    if (lm == 2 || (lm == 1 && (blockIdx.x & 1)) || (lm == 3 && (blockIdx.x & 3))) {
+      if (acc[0][0][0] == 12345.678f) p.out_hi[0] = 0;
+      continue;
+    }
+  }
+#endif
   // ---- epilogue: stage 64-row groups in LDS as fp32 rows of 384, then whole-row 16-byte I/O --------
+  PT_MARK(0);                                      // [0] main loop
   int tid_e = threadIdx.x;
   asm volatile("" : "+v"(tid_e));
   const int el15 = tid_e & 15, eg = (tid_e >> 4) & 3;
@@ -181,7 +212,7 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
       const int m = m0 + grp * 64 + wave + 8 * j;
       if (p.resid_hi) {            // residual stream as hi + lo bf16 planes: lane e < 48 takes columns 8 e .. 8 e + 7 (16 bytes of each plane)
         u32x4_t h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
-        if (j < rows_w && m < m_end && elane < 48) {
+        if (j < rows_w && m < m_end && elane < 48 && !PT_OFF(2)) {
           const size_t ro = (size_t)m * (size_t)p.ldc + n0 + elane * 8;
           h = *reinterpret_cast<const u32x4_t*>(p.resid_hi + ro);
           l = *reinterpret_cast<const u32x4_t*>(p.resid_lo + ro);
@@ -209,7 +240,9 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
         }
       }
     }
+    PT_MARK(1);                                    // [1] residual loads issued + accumulators staged
     __syncthreads();
+    PT_MARK(2);                                    // [2] barrier
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
       const int r = wave + 8 * j;
@@ -236,8 +269,10 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
               s2 += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
             }
             const size_t o = (size_t)m * (size_t)p.ldc + n0 + elane * 8;
-            *reinterpret_cast<u32x4_t*>(p.out_hi + o) = ho;
-            *reinterpret_cast<u32x4_t*>(p.out_lo + o) = lo;
+            if (!PT_OFF(4) || s1 == 12345.678f) {
+              *reinterpret_cast<u32x4_t*>(p.out_hi + o) = ho;
+              *reinterpret_cast<u32x4_t*>(p.out_lo + o) = lo;
+            }
           }
         } else
 #pragma unroll
@@ -271,8 +306,11 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
         }
       }
     }
+    PT_MARK(3);                                    // [3] row loop
     __syncthreads();
+    PT_MARK(4);                                    // [4] closing barrier (its fence waits for the plane stores)
   }
+  PT_FLUSH();
   }   // tiles
 }
 
@@ -342,6 +380,7 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   // neutral on another; never slower in the sweeps (tools/stagger_sweep.py).  SF_PANEL_STAGGER_NS overrides.
   int stagger = (ntiles >= cus && pl.mt == 13) ? sf_wall_clock_ticks(3500) : 0;      // full-height tiles only: small tiles finish before a step elapses
   if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = sf_wall_clock_ticks(atoi(e));
+  if (const int lm = SF_LAB_SWITCH("SF_PANEL_LAB_EPI")) a.w_nt = 78 + lm;      // lab builds only
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
   switch (pl.mt) {
