@@ -172,7 +172,7 @@ hipError_t sf_launch_gelu_bwd(bf16_t* d, const bf16_t* pre, size_t n, hipStream_
 // LayerNorm backward: one wave per row (row in registers), waves walk rows with a grid stride and
 // keep per-lane column sums of dy*xhat / dy; one partial row pair per block, then a column reduce.
 // ------------------------------------------------------------------------------------------------
-#define LN_BWD_MAX_BLOCKS 512
+#define LN_BWD_MAX_BLOCKS 2048      // partial-sum rows the workspace holds; the launch uses ln_bwd_blocks() of them
 
 template <int MAXV, bool DYB>
 __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict__ x, const void* __restrict__ dy,
@@ -194,13 +194,15 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
     const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D);
     const f32x4_t* dr = reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(dy) + (size_t)row * D);
     const u32x2_t* db = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(dy) + (size_t)row * D);
-    f32x4_t v[MAXV], d[MAXV];
+    f32x4_t v[MAXV], d[MAXV], gi[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = i * 64 + lane;
+      gi[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       if (c < nv) {
         v[i] = xr[c];
+        if (g_in) gi[i] = reinterpret_cast<const f32x4_t*>(g_in + (size_t)row * D)[c];      // with the row's other loads, not behind its four reductions
         if (DYB) {
           const u32x2_t t = db[c];
           d[i] = (f32x4_t){bf2f(t[0] & 0xffffu), bf2f(t[0] >> 16), bf2f(t[1] & 0xffffu), bf2f(t[1] >> 16)};
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void sf_ln_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (d[i][j] - c1 - v[i][j] * c2);
         const size_t off = (size_t)row * D + (size_t)c * 4;
-        if (g_in) o += *reinterpret_cast<const f32x4_t*>(g_in + off);
+        o += gi[i];
         *reinterpret_cast<f32x4_t*>(g_out + off) = o;
         if (g_out_bf) *reinterpret_cast<u32x2_t*>(g_out_bf + off) = (u32x2_t){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
       }
@@ -321,7 +323,11 @@ hipError_t sf_launch_ln_bwd(const float* x, const void* dy, int dy_is_bf16, cons
                             hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > 64 * 4 * 8) return hipErrorInvalidValue;
+  // 512 workgroups = 8 waves per CU run at the HBM rate (fp32 dy, M = 25 088: 49 us = 6.2 TB/s; 1024 .. 2048 workgroups measure 50 .. 54 us
+  // and a slower finish kernel, profiles/r04_ln_bwd_lab.txt).  SF_LN_BWD_BLOCKS overrides (lab).
+  static const int cap = getenv("SF_LN_BWD_BLOCKS") ? atoi(getenv("SF_LN_BWD_BLOCKS")) : 512;
   int blocks = (rows + 3) / 4;
+  if (blocks > cap) blocks = cap;
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   const size_t lds = (size_t)3 * 2 * D * sizeof(float);
   const int nv = (D / 4 + 63) / 64;
