@@ -707,10 +707,23 @@ hipError_t sf_launch_adamw(const SfAdamWArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// 16-byte loads, four in flight per lane, four independent accumulators (round 4: the 4-byte, one-at-a-time loop of the first version ran
+// at 2.3 TB/s: 174 us for the 407 MB of gradients); fixed combination order, so the sum is reproducible for a given n
 __global__ __launch_bounds__(256) void sf_sumsq_kernel(const float* __restrict__ g, size_t n, float* partial) {
   __shared__ float red[4];
-  float t = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) t += g[i] * g[i];
+  const size_t n4 = ((reinterpret_cast<size_t>(g) & 15) == 0) ? n / 4 : 0;      // vector body only on a 16-byte aligned base
+  const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(g);
+  const size_t stride = (size_t)gridDim.x * 256;
+  f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4_t v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    a0 += v0 * v0; a1 += v1 * v1; a2 += v2 * v2; a3 += v3 * v3;
+  }
+  for (; i < n4; i += stride) { const f32x4_t v = g4[i]; a0 += v * v; }
+  const f32x4_t a = (a0 + a1) + (a2 + a3);
+  float t = (a[0] + a[1]) + (a[2] + a[3]);
+  for (size_t j = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) t += g[j] * g[j];      // tail (or everything, unaligned)
   t = wave_sum(t);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
