@@ -472,7 +472,12 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   const long row_base = (long)f * L;
   const bf16_t* qkv = a.qkv + h * 64;
   static_assert(SB_ROWS * 8 <= 2 * SB_THREADS, "two staging passes cover the padded image");
+  // the forward's saved row statistics ride with the staging pass (one memory round trip per workgroup, not two); padding queries get +big so that p = 0
+  static_assert(SB_ROWS <= SB_THREADS, "one statistics row per thread");
+  float lse_saved = -NEG_BIG;
+  if (a.lse2 && tid < L) lse_saved = a.lse2[((size_t)f * a.heads + h) * L + tid];
   stage_problem<2>(iq, ik, iv, ig, delta, qkv, a.D, a.d_o + h * 64, a.o + h * 64, a.ld_qkv, a.ld_o, row_base, 1, L, rows_pad, tid, SB_THREADS);
+  if (a.lse2 && tid < rows_pad) lse2[tid] = lse_saved;
   __syncthreads();
 
   BwdView w;
@@ -480,12 +485,10 @@ __global__ __launch_bounds__(SB_THREADS) void sf_spatial_attn_bwd_kernel(SfAttnB
   w.L = L; w.causal = a.causal; w.scale = a.scale; w.sl2 = a.scale * LOG2E;
   w.drop = a.drop; w.drop_base = (unsigned)(((size_t)f * a.heads + h) * (size_t)L * L);
 
-  if (a.lse2) {       // statistics saved by the forward kernel: padding queries get +big so that p = 0
-    for (int i = tid; i < rows_pad; i += SB_THREADS) lse2[i] = i < L ? a.lse2[((size_t)f * a.heads + h) * L + i] : -NEG_BIG;
-  } else {
+  if (!a.lse2) {      // no saved statistics (the op entry): phase A recomputes them
     for (int it = wave; it < 2 * nb; it += SB_WAVES) phase_a_tile<true>(w, it, nt, lane);
+    __syncthreads();
   }
-  __syncthreads();
 
   bf16_t* dqkv = a.d_qkv + h * 64;
   for (int jt = wave; jt < nt && !(a.lab & 1); jt += SB_WAVES) {
