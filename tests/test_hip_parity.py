@@ -177,6 +177,7 @@ def _attn_ref(qkv, heads, mask=None):
 
 
 @pytest.mark.parametrize("frames_,N,heads", [(3, 196, 12), (2, 9, 2), (1, 33, 1), (2, 224, 2), (4, 1, 2), (2, 16, 3),
+                                              (2, 193, 2), (1, 208, 3), (2, 192, 1), (1, 209, 2),       # both edges of the 13-tile (compile-time count) instance
                                               (2, 225, 2), (1, 576, 3), (1, 1024, 1), (2, 400, 2)])   # > 224: streaming-key kernel
 @pytest.mark.parametrize("mode", [0, 1])
 def test_op_spatial_attention(sa, frames_, N, heads, mode, monkeypatch):
@@ -189,6 +190,51 @@ def test_op_spatial_attention_accurate_fp32_inputs(sa, frames_, N, heads, monkey
     the DMA kernel on hi + lo planes that the plain call above takes."""
     monkeypatch.setenv("SF_DISABLE_SPATIAL_DMA_ACC", "1")
     _spatial_attention_case(sa, frames_, N, heads, 1)
+
+
+def _ntc_digest_child():
+    """Child of test_compile_time_tile_count_is_bit_identical: digests of the spatial attention forward (op entry, bf16 mode) and
+    backward at 196 and 200 tokens, printed for the parent (SF_DISABLE_SPATIAL_NTC is read once per process)."""
+    import hashlib
+    import streamformer_amd as sa_mod
+    nat = sa_mod._native
+    out = []
+    for N, heads, frames_ in ((196, 12, 3), (200, 2, 2)):
+        g = torch.Generator().manual_seed(N + heads)
+        qkv = torch.randn(frames_, N, 3 * heads * 64, generator=g) * 1.5
+        ctx = _attention(sa_mod, qkv.reshape(frames_ * N, -1), frames_, N, heads, False, False, 0, 0)
+        out.append(hashlib.sha256(ctx.numpy().tobytes()).hexdigest()[:16])
+        D = heads * 64
+        dev = torch.device("cuda", 0)
+        q16 = qkv.reshape(frames_ * N, -1).bfloat16().to(dev)
+        o16 = ctx.bfloat16().to(dev)
+        do16 = torch.randn(frames_ * N, D, generator=g).bfloat16().to(dev)
+        dq = torch.zeros_like(q16)
+        nat.check(nat.lib.sf_op_attention_bwd(q16.data_ptr(), o16.data_ptr(), do16.data_ptr(), dq.data_ptr(), 0, frames_, N, 1, heads, 0,
+                                              nat.current_stream_handle(dev)))
+        torch.cuda.synchronize()
+        out.append(hashlib.sha256(dq.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16])
+    print("NTC_DIGEST " + " ".join(out), flush=True)
+
+
+def test_compile_time_tile_count_is_bit_identical(sa):
+    """193 .. 208 tokens per frame take kernel instances whose tile / block count is a template constant (loops unrolled into one
+    schedulable region); they must return the bits of the run-time-count kernels, forward and backward."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for off in (False, True):
+        env = dict(os.environ)
+        env.pop("SF_DISABLE_SPATIAL_NTC", None)
+        if off:
+            env["SF_DISABLE_SPATIAL_NTC"] = "1"
+        r = subprocess.run([sys.executable, "-c", "import tests.test_hip_parity as t; t._ntc_digest_child()"], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("NTC_DIGEST")]
+        assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(lines[-1])
+    assert digests[0] == digests[1], digests
 
 
 def _spatial_attention_case(sa, frames_, N, heads, mode):

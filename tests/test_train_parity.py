@@ -86,7 +86,7 @@ def _attn_ref(qkv, d_o, nseq, L, heads, causal):
     return o.detach(), t.grad
 
 
-@pytest.mark.parametrize("nseq,L,heads", [(3, 196, 2), (2, 9, 2), (1, 224, 1), (5, 33, 3)])
+@pytest.mark.parametrize("nseq,L,heads", [(3, 196, 2), (2, 9, 2), (1, 224, 1), (5, 33, 3), (2, 193, 2), (1, 208, 1), (1, 192, 2), (2, 209, 1)])
 def test_spatial_attention_bwd_matches_autograd(nseq, L, heads):
     import streamformer_amd._native as nat
     dev = _dev()
