@@ -18,8 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamformer_hip.so")
 SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
-# lab library only (build.py --lab): the two epilogue-overlap experiments of round 4, measured slower than the panel kernel
-LAB_SOURCES = ["sf_gemm_pp.hip", "sf_gemm_pipe.hip"]
+# lab library only (build.py --lab): round-4 kernels that were built to parity and did not beat the product path on the wall clock —
+# the two epilogue-overlap variants of the panel kernel, and the qkv projection with the temporal attention as its epilogue
+LAB_SOURCES = ["sf_gemm_pp.hip", "sf_gemm_pipe.hip", "sf_gemm_qkv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

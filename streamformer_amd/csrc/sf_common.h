@@ -224,6 +224,20 @@ bool sf_gemm_tile_supported(const SfGemmArgs& a, bool split);                   
 hipError_t sf_launch_gemm_tile(const SfGemmArgs& a, hipStream_t s);
 int sf_tile_max_rows();
 int sf_infold_max_rows();                                                        // largest M of the in-kernel-statistics LayerNorm fold (skinny + tile kernels)
+// LayerNorm-folded qkv projection on the panel tile (sf_gemm_qkv.hip): plain = the [M, 3D] bf16 tensor (spatial attention's input),
+// fused = the temporal attention of a full 16-frame clip computed in the epilogue, ctx [M, D] written instead of qkv
+struct SfQkvArgs {
+  const bf16_t* a;                          // [M, K] bf16(x): the hi plane of the residual stream, rows in (clip, frame, patch) order
+  const bf16_t* w;                          // [3D, K] W' = W * gamma; fused: rows permuted so that 384-column tile j = [q | k | v] of heads 2j, 2j+1
+  const float* bias; const float* ln_s;     // [3D] b' = b + W beta and s_n = sum_k bf16(W')[n, k], permuted like w
+  const float* ln_stats; float ln_eps;      // [M][8] row sums of the producer (SfGemmArgs::ln_stats_wide layout)
+  int M, K, D;                              // D = heads * 64, N = 3 D
+  int B, T, NP;                             // fused: clips, frames per clip (16), patches per frame; M = B T NP
+  bf16_t* out;                              // plain: qkv [M, 3D]; fused: ctx [M, D]
+  float scale; int causal;                  // fused: softmax scale, causal mask over frames
+};
+bool sf_gemm_qkv_supported(const SfQkvArgs& a, bool fused);                        // sf_gemm_qkv.hip
+hipError_t sf_launch_gemm_qkv(const SfQkvArgs& a, bool fused, hipStream_t s);
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip
 hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 bool sf_gemm_pp_supported(const SfGemmArgs& a, bool split);                      // sf_gemm_pp.hip: two workgroups per CU, epilogue beside main loop

@@ -63,6 +63,7 @@ struct DevLayer {
   DevLN ln_t, ln_b, ln_a;
   DevLinear t_qkv, t_out, t_dense, t_fused, s_qkv, s_out, up, down;
   DevLinear t_qkv_f, s_qkv_f, up_f;   // the preceding LayerNorm folded in (W' = W*gamma, b' = b + W beta; hi + lo planes in the accurate mode)
+  DevLinear t_qkv_fp;                 // t_qkv_f with its rows permuted for sf_gemm_qkv.hip's fused tile: [q | k | v] of two heads per 384 rows (bf16 mode)
   float gate_tanh = 0.f;
 };
 
@@ -401,6 +402,21 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     TRY(upload_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"), 3 * D, D, &l.t_qkv));
     TRY(upload_folded_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"),
                              H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_f));
+#ifdef SF_LAB      // lab library only: the permuted copy for sf_gemm_qkv.hip's fused tile (profiles/r04_qkv_fused_ab.txt)
+    if (e->compute == SF_COMPUTE_BF16 && D % 128 == 0 && SF_LAB_SWITCH("SF_QKV_FUSED")) {
+      // row 384 j + 64 i + c of the permuted matrix = row (i / 2) D + (2 j + (i & 1)) 64 + c of the original (i = 0..5: q0 q1 k0 k1 v0 v1)
+      const std::vector<float>& w0 = H(p + "temporal_attention.attention.qkv.weight");
+      const std::vector<float>* b0 = Hopt(p + "temporal_attention.attention.qkv.bias");
+      std::vector<float> wp(w0.size()), bp(3 * (size_t)D, 0.f);
+      for (int r = 0; r < 3 * D; ++r) {
+        const int j = r / 384, i = (r % 384) / 64, cc = r % 64;
+        const int src = (i >> 1) * D + (2 * j + (i & 1)) * 64 + cc;
+        std::copy(w0.begin() + (size_t)src * D, w0.begin() + (size_t)(src + 1) * D, wp.begin() + (size_t)r * D);
+        if (b0) bp[r] = (*b0)[src];
+      }
+      TRY(upload_folded_linear(e, wp, b0 ? &bp : nullptr, H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_fp));
+    }
+#endif
     if (e->fused_temporal) {
       // temporal_dense(output.dense(x)) = (W2 W1) x + (W2 b1 + b2)      (modeling:947-954)
       const std::vector<float>& w1 = H(p + "temporal_attention.output.dense.weight");
@@ -778,10 +794,26 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     // accurate mode, whole short clip (no cache): hi + lo bf16 planes for the DMA kernel, like the spatial attention below
     const bool tplanes = acc && !layer_tqkv && cap == T && t_past == 0 && sf_temporal_planes_ok(T, T);
     const size_t tsz = tplanes ? 2 : esz;
+    // lab library, SF_QKV_FUSED=1 (bf16 mode, whole 16-frame clips, no cache): qkv projection + temporal attention in ONE launch
+    // (sf_gemm_qkv.hip; bit-identical, -0.27 ms of kernel time per forward under rocprof, +0.07 ms on the wall clock: DESIGN.md section 4)
+    bool t_fused_attn = false;
+#ifdef SF_LAB
+    if (fold && !acc && !layer_tqkv && cap == T && t_past == 0 && tk == T && !sp && l.t_qkv_fp.w_hi) {
+      SfQkvArgs q;
+      memset(&q, 0, sizeof(q));
+      q.a = ln_in; q.w = l.t_qkv_fp.w_hi; q.bias = l.t_qkv_fp.bias; q.ln_s = l.t_qkv_fp.ln_s; q.ln_stats = fold_st; q.ln_eps = c.layer_norm_eps;
+      q.M = M; q.K = D; q.D = D; q.B = B; q.T = T; q.NP = N; q.out = ws.ctx_hi; q.scale = scale; q.causal = c.enable_causal_temporal;
+      if (sf_gemm_qkv_supported(q, true)) {
+        HIP_TRY(prof_span(e, 3, s, [&]() { return sf_launch_gemm_qkv(q, true, s); }));
+        t_fused_attn = true;
+      }
+    }
+#endif
+    if (!t_fused_attn)
     HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, tplanes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)tq, (bf16_t*)tq,
                        tplanes ? (bf16_t*)tq + (size_t)M * 3 * D : nullptr, nullptr, 1.f,
                        3 * D, T * N, cap * N, sp ? 0 : slot * N, fold_st, nullptr, sfold, sp ? &sp->slot : nullptr, N));
-    {
+    if (!t_fused_attn) {
       SfAttnArgs a;
       memset(&a, 0, sizeof(a));
       a.q = tq; a.k = (char*)tq + (size_t)D * tsz; a.v = (char*)tq + (size_t)2 * D * tsz;
@@ -808,6 +840,22 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     // kernel can take them; fp32 otherwise (probabilities requested, more than 224 tokens per frame)
     const bool planes = acc && sf_spatial_planes_ok(N, attentions != nullptr);
     const size_t sesz = planes ? 2 : esz;
+    // lab library, SF_SQKV_PANEL=1: the folded spatial qkv projection on the panel tile (768 tiles of 196 x 384 = three whole rounds)
+    bool s_qkv_panel = false;
+#ifdef SF_LAB
+    static const bool s_panel_on = SF_LAB_SWITCH("SF_SQKV_PANEL") != 0;
+    if (s_panel_on && fold && !acc && qkv_epi == SF_EPI_BF16 && l.s_qkv_f.ln_s) {
+      SfQkvArgs q;
+      memset(&q, 0, sizeof(q));
+      q.a = ln_in; q.w = l.s_qkv_f.w_hi; q.bias = l.s_qkv_f.bias; q.ln_s = l.s_qkv_f.ln_s; q.ln_stats = fold_st; q.ln_eps = c.layer_norm_eps;
+      q.M = M; q.K = D; q.D = D; q.out = (bf16_t*)ws.qkv;
+      if (sf_gemm_qkv_supported(q, false)) {
+        HIP_TRY(sf_launch_gemm_qkv(q, false, s));
+        s_qkv_panel = true;
+      }
+    }
+#endif
+    if (!s_qkv_panel)
     HIP_TRY(run_linear(e, anyfold ? l.s_qkv_f : l.s_qkv, ln_in, ws.xn_lo, M, planes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv,
                        planes ? (bf16_t*)ws.qkv + (size_t)M * 3 * D : nullptr, nullptr, 1.f, 0, 0, 0, 0, fold_st, nullptr, sfold));
     {
