@@ -124,6 +124,49 @@ def timed_steps(model, x, steps, warmup, dist, world, nstreams=1):
     return max_over_ranks(dt, dist)
 
 
+def power_under_load(model, x, seconds=2.5):
+    """Package power (W) and shader clock (MHz) from rocm-smi while the forward runs back to back: the forward is bound by the
+    power envelope, this is the evidence on the line itself.  None if rocm-smi is absent / unreadable."""
+    import json as _json, shutil, subprocess, threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    samples = []
+    def poll():
+        time.sleep(0.8 * seconds / 2.5)
+        for _ in range(3):
+            try:
+                r = subprocess.run([exe, "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10)
+                d = _json.loads(r.stdout)
+                card = d[sorted(d.keys())[0]]
+                w = [float(v) for k, v in card.items() if "Power (W)" in k and "Max" not in k]
+                cap = [float(v) for k, v in card.items() if "Max Graphics Package Power" in k]
+                sclk = [v for k, v in card.items() if k.startswith("sclk")]
+                mhz = float("".join(ch for ch in str(sclk[0]) if ch.isdigit() or ch == ".")) if sclk else None
+                if w:
+                    samples.append((w[0], mhz, cap[0] if cap else None))
+            except Exception:
+                pass
+            time.sleep(0.3)
+    th = threading.Thread(target=poll)
+    th.start()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while th.is_alive() or time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                model(x)
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 > 20:
+                break
+    th.join()
+    if not samples:
+        return None
+    return {"package_W": round(sum(s[0] for s in samples) / len(samples), 1), "cap_W": samples[0][2],
+            "sclk_MHz": round(sum(s[1] for s in samples if s[1]) / max(1, sum(1 for s in samples if s[1])), 0) if any(s[1] for s in samples) else None,
+            "samples": len(samples), "source": "rocm-smi --showpower --showclocks, polled under the back-to-back forward (rank 0)"}
+
+
+
 def max_over_ranks(dt, dist):
     """MAX all-reduce of the elapsed time (on the GPU for RCCL, on the host for gloo)."""
     if dist is None:
@@ -569,6 +612,8 @@ def main():
                                          "these MFMA loops at 1.88 GHz on random data (power budget; the same binary runs 12 % faster on all-zero "
                                          "operands), i.e. 1024 SIMDs x 16384 FLOP / 17.6 cycles x 1.88 GHz = 1790 TFLOP/s issue-bound (DESIGN.md 4.1c)",
                            "frac_of_issue_bound_at_measured_clock": round(panel_tflops / 1790.0, 4)}
+        if world == 1 and not args.profile:
+            out["power_under_load"] = power_under_load(model, x)
         by = nat.C.c_double()
         att = {}
         for which, name in ((0, "spatial"), (1, "temporal")):

@@ -55,7 +55,7 @@ __device__ unsigned long long panel_trace[16];
 #endif
 
 template <int P_MT>
-__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks) {
+__global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, int rows_per_tile, int ntiles, int stagger_ticks, int pad_clamp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -87,9 +87,10 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
     const int c = i * P_THREADS + tid;
     const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
     if (i < 2) {
-      int ar = m0 + row;
-      ar = ar < m_end ? ar : m_end - 1;
-      offA[i] = ((unsigned)ar * (unsigned)K + kc * 8) * 2u;
+      // rows past the tile: an offset beyond the buffer's num_records — the DMA returns zeros without touching memory, and the MFMAs of the
+      // padding rows (12 of 208 at 196-row panels) run on zero operands (SF_PANEL_PAD_CLAMP=1: round 1-3 behaviour, re-reads of the last row)
+      const int ar = m0 + row;
+      offA[i] = (ar < m_end || pad_clamp) ? ((unsigned)(ar < m_end ? ar : m_end - 1) * (unsigned)K + kc * 8) * 2u : 0xffff0000u;
     }
     offW[i] = ((unsigned)(n0 + row) * (unsigned)K + kc * 8) * 2u;
   }
@@ -381,13 +382,14 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   int stagger = (ntiles >= cus && pl.mt == 13) ? sf_wall_clock_ticks(3500) : 0;      // full-height tiles only: small tiles finish before a step elapses
   if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = sf_wall_clock_ticks(atoi(e));
   if (const int lm = SF_LAB_SWITCH("SF_PANEL_LAB_EPI")) a.w_nt = 78 + lm;      // lab builds only
+  static const int pad_clamp = getenv("SF_PANEL_PAD_CLAMP") ? 1 : 0;      // A/B switch
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
   switch (pl.mt) {
-    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
-    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
-    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
-    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger); break;
+    case 2: hipLaunchKernelGGL(sf_gemm_panel_kernel<2>, grid, block, lds, s, a, pl.rows, ntiles, stagger, pad_clamp); break;
+    case 4: hipLaunchKernelGGL(sf_gemm_panel_kernel<4>, grid, block, lds, s, a, pl.rows, ntiles, stagger, pad_clamp); break;
+    case 7: hipLaunchKernelGGL(sf_gemm_panel_kernel<7>, grid, block, lds, s, a, pl.rows, ntiles, stagger, pad_clamp); break;
+    default: hipLaunchKernelGGL(sf_gemm_panel_kernel<13>, grid, block, lds, s, a, pl.rows, ntiles, stagger, pad_clamp); break;
   }
   return hipGetLastError();
 }
