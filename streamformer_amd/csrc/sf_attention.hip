@@ -1125,7 +1125,14 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (accurate && !a.in_is_f32) {       // hi + lo bf16 planes (sf_spatial_planes_ok): the DMA kernel with three products
     if (a.probs || a.lo_plane_off <= 0 || (a.row_pitch_kv % 8) || (a.lo_plane_off % 8)) return hipErrorInvalidValue;
     const size_t lds2 = (size_t)nkp * 512 + SP_WAVES * 4096;
-    // (the compile-time tile count of the bf16 instance does not pay here: the accurate forward measured 20.6 against 18.7 ms with it)
+    static const bool ntc_acc_off = getenv("SF_DISABLE_SPATIAL_NTC") != nullptr;      // A/B switch (shared with the bf16 instance)
+    if (!ntc_acc_off && ((a.N + 15) >> 4) == 13) {       // compile-time tile count: 129.9 -> 118.2 us per launch, bit-identical (profiles/r04_spatial_ntc_acc_ab.txt)
+      static SfPerDeviceOnce attr6;
+      if (attr6.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14, true, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, true, false, 13>), grid, block, lds2, s, a, qsplit);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, true>), grid, block, lds2, s, a, qsplit);
     return hipGetLastError();
   }
