@@ -222,7 +222,10 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
 // ------------------------------------------------------------------------------------------------
 #define SKG_STAGES 4
 
-template <bool SPLIT, int EPI, int KG, bool LNF = false>
+// PG > 0: K-tiles per group as a compile-time constant (every group owns exactly PG <= SKG_STAGES tiles: K = 64 KG PG) — the issue and
+// compute loops of the one-step path unroll into straight-line code (all fragment reads of the slice in flight before the first MFMA)
+// instead of one [ds_read -> wait -> MFMA] block per tile behind a run-time trip count (round 4, same finding as the attention kernels)
+template <bool SPLIT, int EPI, int KG, bool LNF = false, int PG = 0>
 __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGemmArgs p) {
   constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);
   constexpr int RING = SKG_STAGES * STAGE;
@@ -234,9 +237,9 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   const int l15 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
   const int nkt = p.K / SK_BK;
-  const int per_grp = (nkt + KG - 1) / KG;              // K-tiles of a group (the last group may own fewer)
+  const int per_grp = PG ? PG : (nkt + KG - 1) / KG;    // K-tiles of a group (the last group may own fewer)
   const int kt_base = kgrp * per_grp;
-  const int mine = max(0, min(per_grp, nkt - kt_base));
+  const int mine = PG ? PG : max(0, min(per_grp, nkt - kt_base));
 
   const bf16_t* src_hi[LOADS];
   const bf16_t* src_lo[LOADS];
@@ -305,7 +308,15 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
   // every group runs the same number of steps (one barrier domain); a step is a serial wait -> barrier -> LDS read -> MFMA
   // chain of a few hundred cycles.  (Two tiles per step on the 4-stage ring measured slower at K = 3072: it gives up the
   // prefetch distance.)
-  if (per_grp <= SKG_STAGES) {                           // the whole slice fits the ring (K = 768: 3 tiles): ONE step
+  if (PG) {
+#pragma unroll
+    for (int j = 0; j < PG; ++j) issue(j);
+    prefetch_epilogue();
+    sk_wait<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < PG; ++j) compute(j);
+  } else if (per_grp <= SKG_STAGES) {                    // the whole slice fits the ring (K = 768: 3 tiles): ONE step
     for (int j = 0; j < mine; ++j) issue(j);
     prefetch_epilogue();
     sk_wait<0>();
@@ -548,6 +559,16 @@ static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
 #define SKG_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<SPLIT, E, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SKG_ATTR(SF_EPI_F32) SKG_ATTR(SF_EPI_BF16) SKG_ATTR(SF_EPI_ACT_BF16) SKG_ATTR(SF_EPI_RESID_F32)
 #undef SKG_ATTR
+  }
+  if constexpr (!SPLIT && KG == 4) {        // the streamed K = 768 residual projections (24 of a frame's 108 launches): three K-tiles per group, unrolled
+    static const bool pg_off = getenv("SF_DISABLE_SKG_UNROLL") != nullptr;      // A/B switch
+    if (!pg_off && a.epi == SF_EPI_RESID_F32 && a.K == 64 * KG * 3) {
+      static SfPerDeviceOnce attr_pg;
+      if (attr_pg.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kg_kernel<false, SF_EPI_RESID_F32, 4, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((sf_gemm_skinny_kg_kernel<false, SF_EPI_RESID_F32, 4, false, 3>), grid, dim3(SK_THREADS * KG), lds, s, a);
+      return hipGetLastError();
+    }
   }
 #define SKG_CASE(E)                                                                                              \
   case E:                                                                                                        \
