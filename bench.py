@@ -191,6 +191,46 @@ def ranks_seen(dist, rank, dev):
 TRAIN_GFLOP_PER_FRAME = (3 * 790.48 - 12 * (11.098 + 3.699)) / 16
 
 
+def dp_consistency_check(tr, task, x, ti, dist, world):
+    """BASELINE configs[3] invariants, checked on the job itself (every rank calls this; collectives inside):
+    (1) after the timed optimizer steps every rank holds bit-identical parameters (DDP's contract,
+    run_finetuning_multi_task.py:421-423); (2) the gradient buffer the bucketed all-reduce leaves equals the SUM of the
+    ranks' local gradients (the optimizer kernel divides by world), compared on a strided ~1M-element sample that
+    crosses every bucket: the local gradients come from a backward with the collectives off, are all-gathered
+    independently of the bucket path, and summed in float64."""
+    from streamformer_amd.parallel import all_gather_rows
+    dev = tr.device
+    bits = tr.params.view(torch.int32).to(torch.int64)
+    w = (torch.arange(bits.numel(), device=dev, dtype=torch.int64) % 65521) + 1
+    mine = (int(bits.sum().item()), int((bits * w).sum().item()))          # order-free + position-weighted checksum of the raw bits
+    del bits, w
+    sums = [None] * world
+    dist.all_gather_object(sums, mine)
+    idx = torch.arange(0, tr.n_train, max(1, tr.n_train // (1 << 20)), device=dev)
+
+    def one_backward(reduce):
+        tr.zero_grad()
+        _, pooler = tr.forward(x)
+        _, gp, _ = tr.loss_and_grad(task, pooler, ti)
+        tr.backward(gp, reduce=reduce)
+        g = tr.grads[idx].clone()
+        tr.zero_grad()
+        return g
+
+    local = one_backward(False)
+    reduced = one_backward(True)
+    want = all_gather_rows(local[None].contiguous(), group=tr.group, at_world_1=True).double().sum(0)
+    scale = float(want.abs().max())
+    err = float((reduced.double() - want).abs().max()) / max(scale, 1e-30)
+    # which buckets the sample touched
+    touched = sorted({b for b, (_, off, n) in enumerate(tr.buckets) if bool(((idx >= off) & (idx < off + n)).any())})
+    return {"params_identical_on_all_ranks": all(s == sums[0] for s in sums), "param_checksums_distinct": len(set(sums)),
+            "reduced_equals_sum_of_local_rel_err": err, "sampled_elements": int(idx.numel()), "buckets_sampled": len(touched),
+            "buckets": len(tr.buckets), "ways": world, "local_grad_absmax": float(local.abs().max()), "task": task,
+            "how": "params: int64 checksums of the raw fp32 bits, all_gather_object; gradients: bucketed all-reduce result vs float64 sum "
+                   "of the all-gathered local gradients on a strided sample"}
+
+
 def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
     """Time `steps` training micro-steps (update_freq = 1) of the LoRA recipe: SigLIP-base, add_lora_spatial,
     spatial base weights frozen, tasks alternating retrieval / localization, AdamW, gradients all-reduced."""
@@ -248,6 +288,11 @@ def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
            "recipe": "SigLIP-base + LoRA r=32 on spatial attention, spatial base frozen, retrieval/localization alternating, "
                      "AdamW (fp32 master weights, bf16 MFMA operands), update_freq 1"}
     if dist is not None:
+        # data-parallel invariants of the job itself, BEFORE the no-collective timing below lets the ranks' parameters drift apart
+        try:
+            res["dp_check"] = dp_consistency_check(tr, "localization", x, tasks[1][1], dist, world)
+        except Exception as e:          # symmetric on all ranks (no rank-dependent branch inside), so no rank is left in a collective
+            res["dp_check"] = {"error": repr(e)}
         # How much of the gradient all-reduce is exposed: the same K steps with the collectives switched off (every rank
         # steps on its local gradients), and the bucket all-reduces alone on an idle GPU, HIP-event timed.
         n2 = max(2, min(steps, 6))
@@ -516,6 +561,28 @@ def main():
         out["two_steps_in_flight"] = {"value": round(frames / dt2, 1), "ms_per_step": round(1e3 * dt2 / args.steps, 3),
                                       "note": "consecutive steps alternate over two HIP streams; throughput only"}
 
+    # BASELINE configs[3] on the driver's standard command: at N > 1 every rank also runs a short training leg (6 micro-steps of the
+    # multitask step with the bucketed RCCL gradient all-reduce + the caption all-gather) right behind the headline forward timing,
+    # while all ranks are still in lock step; the forward `value` above is untouched.  north_star scopes the xGMI traffic to exactly
+    # this collective, and the forward alone would show an embarrassingly parallel curve.
+    train_leg = None
+    if world > 1 and not args.no_train and not args.profile:
+        del model
+        torch.cuda.empty_cache()
+        try:
+            train_leg = train_bench(args, dev, dist, world, rank, 6, 2, with_cpu=False)
+            train_leg["config"] = (f"BASELINE configs[3]: data-parallel multitask pre-training step, {args.batch} clips per GPU x {world} GPUs = "
+                                   f"{args.batch * world} clips global, gradient all-reduce in {train_leg.get('allreduce_buckets')} buckets + caption all-gather")
+            train_leg["ranks_seen"] = seen
+        except Exception as e:
+            train_leg = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        if rank == 0:                       # rank 0's roofline / accuracy legs below use it
+            model = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
+            model.load_state_dict(sd)
+            model.to(dev).eval()
+            model(x)                        # weights are uploaded / finalised by the first forward
+            torch.cuda.synchronize()
     if args.profile and rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -740,6 +807,8 @@ def main():
                 out["train_step"] = train_bench(args, dev, dist, world, rank, 6, 2, with_cpu=not args.no_cpu_baseline)
             except Exception as e:      # never lose the headline line to the extra measurement
                 out["train_step"] = {"error": repr(e)}
+        elif train_leg is not None:
+            out["train_step"] = train_leg
         print(json.dumps(out), flush=True)
     if dist is not None and dist.is_initialized():
         dist.barrier()
