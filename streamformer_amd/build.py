@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamformer_hip.so")
-SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_loss.hip", "sf_encoder.hip",
+SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_pool_head.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
 # lab library only (build.py --lab): round-4 kernels that were built to parity and did not beat the product path on the wall clock —
 # the two epilogue-overlap variants of the panel kernel, and the qkv projection with the temporal attention as its epilogue
@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
     flags = FLAGS + (["-DSF_LAB"] if lab else [])
     sources = SOURCES + (LAB_SOURCES if lab else [])
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "sf_train.h"), os.path.join(CSRC, "sf_internal.h"),
+    headers = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "sf_train.h"), os.path.join(CSRC, "sf_internal.h"), os.path.join(CSRC, "sf_pool_head.h"),
                os.path.join(os.path.dirname(HERE), "include", "streamformer_hip.h")]
 
     def compile_one(src: str) -> str:

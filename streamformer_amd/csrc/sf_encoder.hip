@@ -3,6 +3,7 @@
 // streaming copy vqa_enc:1316-1392).  See include/streamformer_hip.h for the contract.
 #include "sf_internal.h"
 #include "sf_common.h"
+#include "sf_pool_head.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -83,9 +84,12 @@ struct sf_encoder {
   float* time_tab = nullptr;  // [num_frames,D]
   std::vector<DevLayer> layers;
   DevLN post_ln, head_ln;
-  DevLinear head_kv, head_out, head_fc1, head_fc2;
-  float* head_q = nullptr;    // [D] probe query, projected and scaled
-  bf16_t* head_q_bf = nullptr; // the same rounded to bf16 (storage type of the bf16-mode k / v it meets in the decode kernel)
+  DevLinear head_out, head_fc1, head_fc2;
+  // pooling head with the k / v projections of the tokens folded away (sf_pool_head.hip): U_h = Wk_h^T q_h as hi + lo bf16
+  // planes [16, D] (q = the projected, scaled probe), the value projection and its bias in fp32
+  bf16_t* head_u_hi = nullptr; bf16_t* head_u_lo = nullptr;
+  float* head_wv = nullptr;   // [D, D]
+  float* head_bv = nullptr;   // [D]
   size_t weight_bytes = 0;
   uint64_t generation = 0;    // process-unique id of this handle's current weight packing (bumped by every finalize)
   SfPixelNorm pixel_norm = {{1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f, 1.0f / 127.5f}, {-1.f, -1.f, -1.f, -1.f}};
@@ -197,6 +201,8 @@ extern "C" int sf_create(const sf_config* cfg, int device, sf_encoder** out) {
   if (c.hidden_size / c.num_attention_heads != 64)
     return set_err(SF_ERR_INVALID, "head_dim %d unsupported: the gfx950 attention kernels are built for head_dim 64",
                    c.hidden_size / c.num_attention_heads);
+  if (c.num_attention_heads > 16)
+    return set_err(SF_ERR_INVALID, "%d attention heads unsupported: the pooling-head kernels hold at most 16 heads per MFMA tile", c.num_attention_heads);
   if (c.hidden_size % 64 || c.intermediate_size % 64)
     return set_err(SF_ERR_INVALID, "hidden_size and intermediate_size must be multiples of 64");
   if (c.patch_size % 8 || (c.num_channels * c.patch_size * c.patch_size) % 64)
@@ -465,20 +471,32 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     const std::vector<float>& w = H("head.attention.in_proj_weight");
     const std::vector<float>& b = H("head.attention.in_proj_bias");
     const std::vector<float>& probe = H("head.probe");
-    std::vector<float> q(D);
+    std::vector<double> q(D);
     const double sc = 1.0 / std::sqrt(64.0);
     for (int o = 0; o < D; ++o) {
       double acc = b[o];
       for (int k = 0; k < D; ++k) acc += (double)w[(size_t)o * D + k] * probe[k];
-      q[o] = (float)(acc * sc);
+      q[o] = acc * sc;
     }
-    TRY(dev_upload<float>(e, q, &e->head_q));
-    std::vector<uint16_t> qb(D);
-    for (int o = 0; o < D; ++o) qb[o] = h_f2bf(q[o]);
-    TRY(dev_upload<uint16_t>(e, qb, &e->head_q_bf));
-    std::vector<float> wkv(w.begin() + (size_t)D * D, w.end());
-    std::vector<float> bkv(b.begin() + D, b.end());
-    TRY(upload_linear(e, wkv, &bkv, 2 * D, D, &e->head_kv));
+    // The keys only ever meet this one query, so the key projection folds into it: score_hn = (Wk_h^T q_h) . x_n + q_h . bk_h, and
+    // the second term is constant over n — the softmax drops it.  U_h = Wk_h^T q_h, in double; the values need no projection of
+    // the tokens either: ctx_h = Wv_h (sum_n p_hn x_n) + bv_h.
+    const int heads = e->cfg.num_attention_heads;
+    std::vector<uint16_t> uh((size_t)16 * D, 0), ul((size_t)16 * D, 0);
+    for (int h = 0; h < heads; ++h)
+      for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        for (int j = 0; j < 64; ++j) acc += (double)w[((size_t)D + h * 64 + j) * D + d] * q[h * 64 + j];
+        const float v = (float)acc;
+        uh[(size_t)h * D + d] = h_f2bf(v);
+        ul[(size_t)h * D + d] = h_f2bf(v - h_bf2f(uh[(size_t)h * D + d]));
+      }
+    TRY(dev_upload<uint16_t>(e, uh, &e->head_u_hi));
+    TRY(dev_upload<uint16_t>(e, ul, &e->head_u_lo));
+    std::vector<float> wv(w.begin() + (size_t)2 * D * D, w.end());
+    std::vector<float> bv(b.begin() + 2 * D, b.end());
+    TRY(dev_upload<float>(e, wv, &e->head_wv));
+    TRY(dev_upload<float>(e, bv, &e->head_bv));
   }
   TRY(upload_linear(e, H("head.attention.out_proj.weight"), Hopt("head.attention.out_proj.bias"), D, D, &e->head_out, true));
   TRY(upload_linear(e, H("head.mlp.fc1.weight"), Hopt("head.mlp.fc1.bias"), I, D, &e->head_fc1, true));
@@ -510,9 +528,10 @@ struct Workspace {
   float* embed_tab; bf16_t* patch_buf;  // pos + time table [T*N, D]; patch matrix [M, Kp] when the embedding GEMM runs on the
                                         // panel kernel (its bf16 output goes to xn_hi, so the A operand needs its own buffer)
   bf16_t *xn_hi, *xn_lo, *ctx_hi, *ctx_lo, *tmp_hi, *tmp_lo, *mid_hi, *mid_lo;
-  void* qkv;          // spatial qkv / head kv; fast: bf16 [M,3D], accurate: fp32 [M,3D]
+  void* qkv;          // spatial qkv; fast: bf16 [M,3D], accurate: fp32 [M,3D]
   void* tqkv;         // temporal qkv of the current layer when no cache is used
   float* attn_out;    // head: [F, D]
+  float *pool_z, *pool_ml;         // head: weighted token sums [F, S, heads, D] and {max, sum} [F, S, heads, 2] per token split
   bf16_t *pc_hi, *pc_lo, *hn_hi, *hn_lo, *hm_hi, *hm_lo;
   float *lhs_stage, *pool_stage;   // streaming only: graph-owned outputs, copied to the caller's tensors after the replay
   bf16_t* res_bf;                  // small-M LayerNorm fold: bf16 copy of the residual stream (A operand of the folded Linears)
@@ -548,6 +567,8 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.qkv = c.take<char>(M * 3 * D * (acc ? 4 : 2));
   w.tqkv = need_tqkv ? (void*)c.take<char>(M * 3 * D * (acc ? 4 : 2)) : nullptr;
   w.attn_out = c.take<float>(F * D);
+  w.pool_z = c.take<float>(sf_pool_z_floats((int)F, N, e->cfg.num_attention_heads, (int)D));
+  w.pool_ml = c.take<float>(sf_pool_ml_floats((int)F, N, e->cfg.num_attention_heads));
   w.pc_hi = c.take<bf16_t>(F * D);          // the pooling head's one-row-per-frame tensors keep hi + lo planes in both modes
   w.pc_lo = c.take<bf16_t>(F * D);
   w.hn_hi = c.take<bf16_t>(F * D);
@@ -883,30 +904,27 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     HIP_TRY(hipMemcpyAsync(hidden_states + (size_t)e->L * hs_stride, ws.resid, hs_stride * 4, hipMemcpyDeviceToDevice, s));
   if (!(stages & 12)) return SF_OK;
   // ---- post LayerNorm + pooling head (modeling:1330-1340, 1141-1154) -------------------------------
+  // (the head reads the fp32 tokens: no bf16 copy of the normalised rows is written any more)
   if (stages & 4)       // pm: the rows arrive as the two planes of the residual stream
-    HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s,
+    HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, nullptr, nullptr, M, D, c.layer_norm_eps, s,
                                 rplanes ? ws.xn_hi : nullptr, plo, plo2));
-  else      // stage 8: the head alone on tokens the caller has already normalised (model.head(x))
-    HIP_TRY(sf_launch_split(ws.resid, ws.xn_hi, acc ? ws.xn_lo : nullptr, (size_t)M * D, s));
+  // stage 8: the head alone on tokens the caller has already normalised (model.head(x)): they sit in ws.resid
   if (pooler) {
-    static const bool head_acc_off = getenv("SF_DISABLE_HEAD_ACC") != nullptr;       // A/B switch
-    bool hacc = !acc && !head_acc_off;
-    HIP_TRY(run_linear(e, e->head_kv, ws.xn_hi, ws.xn_lo, M, qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv, nullptr));
-    static const bool pool_decode_off = getenv("SF_DISABLE_POOL_DECODE") != nullptr;
-    if (N <= 256 && !pool_decode_off) {
-      // one learned query against the N tokens of a frame = the single-query attention of the streaming step with
-      // (stream, patch) -> (frame, -) and the cache -> the frame's tokens: same matrix-vector kernel (sf_temporal_decode_kernel)
-      SfAttnArgs a;
-      memset(&a, 0, sizeof(a));
-      a.q = acc ? (const void*)e->head_q : (const void*)e->head_q_bf;      // pre-projected, pre-scaled: scale = 1
-      a.k = ws.qkv; a.v = (char*)ws.qkv + (size_t)D * esz;
-      a.in_is_f32 = acc; a.row_pitch_q = 0; a.row_pitch_kv = 2 * D; a.heads = heads; a.scale = 1.0f;
-      a.N = 1; a.B = F; a.Tq = 1; a.Tk = N; a.Tcap = N; a.t_past = N; a.causal = 0; a.Tq_cap = 0; a.q_t0 = 0;
-      a.ctx_hi = ws.pc_hi; a.ctx_lo = (acc || hacc) ? ws.pc_lo : nullptr; a.D = D;
-      HIP_TRY(sf_launch_temporal_attention(a, acc, s));
-    } else {
-      hacc = false;            // sf_pool_attn_kernel writes the lo plane in the accurate mode only
-      HIP_TRY(sf_launch_pool_attention(e->head_q, ws.qkv, acc, 2 * D, ws.pc_hi, ws.pc_lo, F, N, heads, D, s));
+    // The probe attention without projecting the tokens (sf_pool_head.hip): scores = x . U, z_h = sum_n p_hn x_n on the fp32
+    // tokens, ctx_h = Wv_h z_h + bv_h — bf16x3 / fp32 arithmetic in BOTH modes (the [M, 2D] k / v tensor and its 59 GFLOP are gone).
+    const bool hacc = !acc;          // the head's one-row-per-frame tensors keep hi + lo planes in both modes (force_split in bf16 mode)
+    {
+      const float* tok = (stages & 4) ? last_hidden : ws.resid;
+      SfPoolArgs pa;
+      memset(&pa, 0, sizeof(pa));
+      pa.x = tok; pa.u_hi = e->head_u_hi; pa.u_lo = e->head_u_lo; pa.zpart = ws.pool_z; pa.ml = ws.pool_ml;
+      pa.F = F; pa.N = N; pa.heads = heads; pa.D = D; pa.S = sf_pool_splits(F, N, heads); pa.normalize = pa.S == 1;
+      HIP_TRY(sf_launch_pool_probe(pa, s));
+      SfPoolCtxArgs ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.zpart = ws.pool_z; ca.ml = ws.pool_ml; ca.wv = e->head_wv; ca.ldw = D; ca.bv = e->head_bv;
+      ca.ctx_hi = ws.pc_hi; ca.ctx_lo = ws.pc_lo; ca.F = F; ca.heads = heads; ca.D = D; ca.S = pa.S;
+      HIP_TRY(sf_launch_pool_ctx(ca, s));
     }
     // one row per frame from here on (F rows: 0.03 % of the forward's FLOPs): three bf16 products per operand pair in BOTH modes —
     // pooler_output is the product both loss heads and the feature dumps consume, and the bf16 mode's own head added 1.5e-2 of

@@ -1,0 +1,48 @@
+// Attention-pooling head without the key / value projections of the tokens (sf_pool_head.hip; modeling:1141-1154).
+#pragma once
+#include "sf_common.h"
+
+// U_h = Wk_h^T q_h: fp32 [16, D] and hi / lo bf16 planes [16, D] (rows >= heads zero).  wk = in_proj_weight rows [D, 2D),
+// q = the projected, scaled probe [D]
+hipError_t sf_launch_pool_u(const float* wk, const float* q, float* u, bf16_t* u_hi, bf16_t* u_lo, int heads, int D, hipStream_t s);
+
+struct SfPoolArgs {
+  const float* x;                          // [F * N, D] fp32: the normalised tokens (post_layernorm output)
+  const bf16_t* u_hi; const bf16_t* u_lo;  // [16, D]
+  float* zpart;                            // [F, S, heads, D] weighted token sums of each split (normalised when S == 1)
+  float* ml;                               // [F, S, heads, 2] {max score, sum of exp} per split (needed when S > 1)
+  float* probs;                            // optional (S == 1): softmax probabilities [F, heads, N] fp32, kept for the backward
+  int F, N, heads, D, S, normalize;
+};
+int sf_pool_splits(int F, int N, int heads);                       // token splits per frame the launcher wants for this shape
+size_t sf_pool_z_floats(int F, int N, int heads, int D);
+size_t sf_pool_ml_floats(int F, int N, int heads);
+hipError_t sf_launch_pool_probe(const SfPoolArgs& a, hipStream_t s);
+
+struct SfPoolCtxArgs {
+  const float* zpart; const float* ml;     // as written by sf_launch_pool_probe
+  const float* wv; int ldw;                // value projection rows [D][ldw] fp32 (in_proj_weight rows [2D, 3D))
+  const float* bv;                         // [D]
+  float* z_out;                            // optional, S > 1: combined normalised sums [F, heads, D]
+  float* ctx_f32; bf16_t* ctx_hi; bf16_t* ctx_lo;      // [F, D] outputs (any subset)
+  int F, heads, D, S;
+};
+hipError_t sf_launch_pool_ctx(const SfPoolCtxArgs& a, hipStream_t s);
+
+// backward of ctx = Wv z + bv: dz [F, heads, D]; dwv / dbv accumulate (+=), either may be null.  wT = transposed bf16 working copy
+// [D][ldt] whose value columns start at col0
+hipError_t sf_launch_pool_ctx_bwd(const float* dctx, const bf16_t* wT, int ldt, int col0, const float* z, float* dz, float* dwv, int ldw,
+                                  float* dbv, int F, int heads, int D, hipStream_t s);
+struct SfPoolBwdArgs {
+  const bf16_t* x_bf;                      // [F * N, D] bf16 normalised tokens
+  const float* probs;                      // [F, heads, N]
+  const float* z; const float* dz;         // [F, heads, D]
+  const float* u;                          // [16, D] fp32
+  const float* d_lhs;                      // optional [F * N, D]: gradient arriving through last_hidden_state, added to dx
+  float* dx;                               // [F * N, D] fp32 gradient wrt the normalised tokens (written)
+  bf16_t* ds_bf;                           // [F * N, 32] bf16: score gradients, the dY operand of dU = ds^T x (columns >= heads zero)
+  int F, N, heads, D;
+};
+hipError_t sf_launch_pool_probe_bwd(const SfPoolBwdArgs& a, hipStream_t s);
+// dWk += q dU^T (null: skipped), dq = Wk dU;  du [>= heads, D] fp32
+hipError_t sf_launch_pool_u_bwd(const float* du, const float* wk, const float* q, float* dwk, float* dq, int D, hipStream_t s);

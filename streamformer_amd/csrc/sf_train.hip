@@ -6,6 +6,7 @@
 #include "sf_internal.h"
 #include "sf_common.h"
 #include "sf_train.h"
+#include "sf_pool_head.h"
 
 #include <cmath>
 #include <cstdio>
@@ -62,6 +63,8 @@ struct sf_trainer {
   bf16_t* arena = nullptr;
   float* farena = nullptr;          // scaled biases, head query, reduction scratch
   float* head_q = nullptr;
+  float* head_u = nullptr;          // pooling head: U_h = Wk_h^T q_h, fp32 [16, D] (+ hi / lo bf16 planes), refreshed with the weights
+  bf16_t* head_u_hi = nullptr; bf16_t* head_u_lo = nullptr;
   float* red_partial = nullptr;
   SfPrepJob* prep_jobs = nullptr;   // device table for sf_trainer_sync_weights
   int n_prep_jobs = 0, prep_tiles = 0;
@@ -248,7 +251,8 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
       if (x->pla >= 0) nb += (((size_t)kRank * x->K + 127) & ~(size_t)127) + (((size_t)kRank * x->N + 127) & ~(size_t)127);
       if (x->pgate >= 0) nf += ((size_t)x->N + 63) & ~(size_t)63;
     }
-    nf += (size_t)D + 64 + 2048;          // head query + reduction scratch
+    nf += (size_t)D + 64 + 2048 + (size_t)16 * D;          // head query + reduction scratch + the head's folded key projection
+    nb += (size_t)2 * 16 * D;
     if (hipMalloc(&t->arena, nb * sizeof(bf16_t)) != hipSuccess || hipMalloc(&t->farena, nf * sizeof(float)) != hipSuccess) {
       free_trainer_device(t); delete t;
       return sf_set_err(SF_ERR_HIP, "hipMalloc failed (working weights, %zu bytes)", nb * 2);
@@ -266,6 +270,9 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
       if (x->pgate >= 0) { x->bias_scaled = fp; fp += ((size_t)x->N + 63) & ~(size_t)63; }
     }
     t->head_q = fp; fp += (size_t)D + 64;
+    t->head_u = fp; fp += (size_t)16 * D;
+    t->head_u_hi = bp; bp += (size_t)16 * D;
+    t->head_u_lo = bp; bp += (size_t)16 * D;
     t->red_partial = fp;
     // one-launch weight refresh: job table with offsets into the flat parameter buffer
     std::vector<SfPrepJob> jobs;
@@ -364,6 +371,8 @@ extern "C" int sf_trainer_sync_weights(sf_trainer* t, const float* params_dev, s
   // nn.MultiheadAttention scales q by head_dim^-0.5 after the in-projection (modeling:1145-1149)
   HIP_TRY(sf_launch_head_query(PP(t, params_dev, t->p_probe), PP(t, params_dev, t->p_inw), PP(t, params_dev, t->p_inb), 0.125f,
                                t->head_q, t->D, s));
+  // the keys of the pooling head only meet that one query: U_h = Wk_h^T q_h (sf_pool_head.hip)
+  HIP_TRY(sf_launch_pool_u(PP(t, params_dev, t->p_inw, (size_t)t->D * t->D), t->head_q, t->head_u, t->head_u_hi, t->head_u_lo, t->heads, t->D, s));
   return SF_OK;
 }
 
@@ -393,14 +402,16 @@ struct TWs {
   bf16_t* patches; float* te_rows;
   std::vector<float*> h;               // L+1 residual snapshots
   std::vector<TSavedLayer> sl;
-  bf16_t *xn, *kv, *pc, *hn, *hm_pre, *hm;
+  bf16_t *xn, *pc, *hn, *hm_pre, *hm;
   float* attn_out;
+  float *pz, *pprobs;                  // pooling head: z_h = sum_n p_hn x_n [F, heads, D] and the probabilities [F, heads, N]
   // backward scratch
   bf16_t* d_ln_bf;
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
   bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
   bf16_t *g_bf1, *g_bf2, *d_wide_s, *d_wide_t;       // a layer's weight-gradient operands stay intact until its grouped launch
-  float *gh, *d_hn, *d_pc, *dq_frames, *dq_total;
+  float *gh, *d_hn, *d_pc, *dq_total, *pdz, *pdu;
+  bf16_t* pds;                         // pooling head: score gradients [M, 32] (the dY operand of dU = ds^T x)
   bf16_t *gh_bf, *d_hm;
   size_t bytes;
 };
@@ -426,7 +437,8 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
     s.ln_a = c.take<bf16_t>(M * D); s.pre = c.take<bf16_t>(M * I); s.act = c.take<bf16_t>(M * I);
     s.lse_s = c.take<float>(F * (size_t)t->heads * N);
   }
-  w.xn = c.take<bf16_t>(M * D); w.kv = c.take<bf16_t>(M * 2 * D); w.pc = c.take<bf16_t>(F * D);
+  w.xn = c.take<bf16_t>(M * D); w.pc = c.take<bf16_t>(F * D);
+  w.pz = c.take<float>(F * (size_t)t->heads * D); w.pprobs = c.take<float>(F * (size_t)t->heads * N);
   w.attn_out = c.take<float>(F * D); w.hn = c.take<bf16_t>(F * D);
   w.hm_pre = c.take<bf16_t>(F * I); w.hm = c.take<bf16_t>(F * I);
   // scratch
@@ -460,7 +472,8 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   w.cs_partial = c.take<float>(sf_colsum_partial_floats((int)max_sz(I, 3 * D)));
   w.s_tn = c.take<float>((size_t)T * N * D);
   w.gh = c.take<float>(F * D); w.d_hn = c.take<float>(F * D); w.d_pc = c.take<float>(F * D);
-  w.dq_frames = c.take<float>(F * D); w.dq_total = c.take<float>(D);
+  w.dq_total = c.take<float>(D);
+  w.pdz = c.take<float>(F * (size_t)t->heads * D); w.pdu = c.take<float>((size_t)32 * D); w.pds = c.take<bf16_t>(M * 32);
   w.gh_bf = c.take<bf16_t>(F * D); w.d_hm = c.take<bf16_t>(F * I);
   w.bytes = (c.off + 255) & ~(size_t)255;
   return w;
@@ -640,9 +653,23 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
     }
   }
   // post LayerNorm + pooling head (modeling:1330-1340, 1141-1154)
-  HIP_TRY(sf_launch_layernorm(ws.h[t->L], PP(t, P0, t->post_g), PP(t, P0, t->post_b), last_hidden, ws.xn, nullptr, M, D, eps, s));
-  HIP_TRY(lin_fwd(t, t->head_kv, ws.xn, M, SF_EPI_BF16, s, nullptr, ws.kv));
-  HIP_TRY(sf_launch_pool_attention(t->head_q, ws.kv, 0, 2 * D, ws.pc, nullptr, F, N, heads, D, s));
+  // The probe attention reads the fp32 tokens and never projects them to k / v (sf_pool_head.hip): scores = x . U, z_h = sum_n p_hn x_n,
+  // ctx_h = Wv_h z_h + bv_h.  The caller's last_hidden_state (or, without one, the backward's scratch) holds the fp32 rows; the
+  // backward itself works from the bf16 copy ws.xn, so the caller may do with its tensor what it likes.
+  float* xf = last_hidden ? last_hidden : ws.g;
+  HIP_TRY(sf_launch_layernorm(ws.h[t->L], PP(t, P0, t->post_g), PP(t, P0, t->post_b), xf, ws.xn, nullptr, M, D, eps, s));
+  {
+    SfPoolArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.x = xf; pa.u_hi = t->head_u_hi; pa.u_lo = t->head_u_lo; pa.zpart = ws.pz; pa.probs = ws.pprobs;
+    pa.F = F; pa.N = N; pa.heads = heads; pa.D = D; pa.S = 1; pa.normalize = 1;
+    HIP_TRY(sf_launch_pool_probe(pa, s));
+    SfPoolCtxArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.zpart = ws.pz; ca.wv = PP(t, P0, t->p_inw, (size_t)2 * D * D); ca.ldw = D; ca.bv = PP(t, P0, t->p_inb, (size_t)2 * D);
+    ca.ctx_hi = ws.pc; ca.F = F; ca.heads = heads; ca.D = D; ca.S = 1;
+    HIP_TRY(sf_launch_pool_ctx(ca, s));
+  }
   HIP_TRY(lin_fwd(t, t->head_out, ws.pc, F, SF_EPI_F32, s, ws.attn_out, nullptr));
   HIP_TRY(sf_launch_layernorm(ws.attn_out, PP(t, P0, t->hln_g), PP(t, P0, t->hln_b), nullptr, ws.hn, nullptr, F, D, eps, s));
   HIP_TRY(lin_fwd(t, t->fc1, ws.hn, F, SF_EPI_BF16, s, nullptr, ws.hm_pre));
@@ -717,14 +744,28 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   HIP_TRY(lin_dgrad(t->head_out, ws.gh_bf, F, s, ws.d_pc, nullptr));
   HIP_TRY(lin_wgrad(c, t->head_out, ws.gh_bf, ws.pc, F));
   // probe attention over the N tokens of every frame
-  bf16_t* d_kv = ws.d_wide;
-  HIP_TRY(sf_launch_pool_attention_bwd(t->head_q, ws.kv, ws.d_pc, d_kv, ws.dq_frames, F, N, t->heads, D, s));
-  HIP_TRY(sf_launch_sum_rows(ws.dq_frames, ws.dq_total, 1, 1, 0, 0, F, 1, D, 0, s));
+  // ctx_h = Wv_h z_h + bv_h: dz, dWv, dbv (the value rows are in_proj rows [2D, 3D))
+  HIP_TRY(sf_launch_pool_ctx_bwd(ws.d_pc, t->head_kv.wT, 2 * D, D, ws.pz, ws.pdz, GG(t, c.grads, t->p_inw, (size_t)2 * D * D), D,
+                                 GG(t, c.grads, t->p_inb, (size_t)2 * D), F, t->heads, D, s));
+  // p = softmax(x . U), z = p x: dx (+ the gradient that arrives through last_hidden_state) and the score gradients ds
+  {
+    SfPoolBwdArgs pb;
+    memset(&pb, 0, sizeof(pb));
+    pb.x_bf = ws.xn; pb.probs = ws.pprobs; pb.z = ws.pz; pb.dz = ws.pdz; pb.u = t->head_u; pb.d_lhs = d_lhs; pb.dx = ws.d_ln; pb.ds_bf = ws.pds;
+    pb.F = F; pb.N = N; pb.heads = t->heads; pb.D = D;
+    HIP_TRY(sf_launch_pool_probe_bwd(pb, s));
+  }
+  {   // dU = ds^T x over all token rows ([32, D], rows >= heads zero), then U_h = Wk_h^T q_h: dWk_h += q_h dU_h^T, dq_h = Wk_h dU_h.
+      // The key bias gets no gradient: its term q_h . bk_h is constant over the keys and cancels in the softmax.
+    SfWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = ws.pds; a.ldy = 32; a.x = ws.xn; a.ldx = D; a.M = M; a.N1 = 32; a.N2 = D; a.out = ws.pdu; a.ldo = D; a.alpha = 1.f;
+    a.partial = ws.wg_partial;
+    HIP_TRY(sf_launch_wgrad(a, s));
+    HIP_TRY(sf_launch_pool_u_bwd(ws.pdu, PP(t, P0, t->p_inw, (size_t)D * D), t->head_q, GG(t, c.grads, t->p_inw, (size_t)D * D), ws.dq_total, D, s));
+  }
   HIP_TRY(sf_launch_head_query_bwd(ws.dq_total, PP(t, P0, t->p_probe), PP(t, P0, t->p_inw), 0.125f, GG(t, c.grads, t->p_inw),
                                    GG(t, c.grads, t->p_inb), GG(t, c.grads, t->p_probe), D, s));
-  HIP_TRY(lin_wgrad(c, t->head_kv, d_kv, ws.xn, M));
-  HIP_TRY(lin_dgrad(t->head_kv, d_kv, M, s, ws.d_ln, nullptr));
-  if (d_lhs) HIP_TRY(sf_launch_sum_rows(d_lhs, ws.d_ln, M, M, 1, 0, 1, 0, D, 1, s));
   // post_layernorm: g = dLN(h_L)
   HIP_TRY(sf_launch_ln_bwd(ws.h[t->L], ws.d_ln, 0, PP(t, P0, t->post_g), nullptr, ws.g, ws.g_bf, GG(t, c.grads, t->post_g), GG(t, c.grads, t->post_b),
                            ws.ln_partial, M, D, eps, s));
