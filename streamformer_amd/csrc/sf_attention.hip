@@ -1666,75 +1666,3 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
 #undef SF_TL
   return hipGetLastError();
 }
-
-// ================================================================================================
-// pooling-head attention: one pre-projected, pre-scaled query per head against the N tokens of a
-// frame.  One wave per (frame, head); scores via per-lane 64-long dots, output with lane = d.
-// kv rows: [frames*N, row_pitch] with K in columns [0,D) and V in [D,2D).
-// ================================================================================================
-template <bool F32>
-__global__ __launch_bounds__(256) void sf_pool_attn_kernel(const float* __restrict__ q, const void* __restrict__ kv,
-                                                           int row_pitch, bf16_t* __restrict__ ctx_hi,
-                                                           bf16_t* __restrict__ ctx_lo, int frames, int N,
-                                                           int heads, int D) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= frames * heads) return;
-  const int frame = item / heads, h = item % heads;
-  float* sc = reinterpret_cast<float*>(smem) + (size_t)wave * ((N + 63) & ~63);
-  float qv[HD];
-#pragma unroll
-  for (int j = 0; j < HD; ++j) qv[j] = q[h * HD + j];
-  const size_t row0 = (size_t)frame * N;
-  float mx = -INFINITY;
-  for (int key = lane; key < N; key += 64) {
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float kk[8];
-      load8<F32>(kv, (row0 + key) * row_pitch + h * HD + c * 8, kk);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc = fmaf(qv[c * 8 + j], kk[j], acc);
-    }
-    sc[key] = acc;
-    mx = fmaxf(mx, acc);
-  }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int key = lane; key < N; key += 64) {
-    const float e = expf(sc[key] - mx);
-    sc[key] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float acc = 0.f;
-  for (int key = 0; key < N; ++key) {
-    float vv;
-    const size_t off = (row0 + key) * row_pitch + D + h * HD + lane;
-    if (F32) vv = reinterpret_cast<const float*>(kv)[off];
-    else vv = bf2f(reinterpret_cast<const bf16_t*>(kv)[off]);
-    acc = fmaf(sc[key], vv, acc);
-  }
-  acc /= sum;
-  unsigned int hi, lo;
-  split_bf(acc, hi, lo);
-  const size_t o = (size_t)frame * D + h * HD + lane;
-  ctx_hi[o] = (bf16_t)hi;
-  if (ctx_lo) ctx_lo[o] = (bf16_t)lo;
-}
-
-hipError_t sf_launch_pool_attention(const float* q, const void* kv, int kv_is_f32, int row_pitch,
-                                    bf16_t* ctx_hi, bf16_t* ctx_lo, int frames, int N, int heads,
-                                    int D, hipStream_t s) {
-  if (D != heads * HD) return hipErrorInvalidValue;
-  const int items = frames * heads;
-  const size_t lds = (size_t)4 * ((N + 63) & ~63) * sizeof(float);
-  const dim3 grid((items + 3) / 4), block(256);
-  if (kv_is_f32) hipLaunchKernelGGL(sf_pool_attn_kernel<true>, grid, block, lds, s, q, kv, row_pitch, ctx_hi, ctx_lo, frames, N, heads, D);
-  else hipLaunchKernelGGL(sf_pool_attn_kernel<false>, grid, block, lds, s, q, kv, row_pitch, ctx_hi, ctx_lo, frames, N, heads, D);
-  return hipGetLastError();
-}

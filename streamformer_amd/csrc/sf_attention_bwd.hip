@@ -609,100 +609,3 @@ hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t 
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// pooling head: one query per (frame, head); one wave per problem, lanes over keys
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sf_pool_attn_bwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                               const float* __restrict__ d_ctx, bf16_t* __restrict__ d_kv,
-                                                               float* __restrict__ dq_frames, int frames, int N, int heads,
-                                                               int D) {
-  __shared__ float sq[4][64], sg[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int prob = blockIdx.x * 4 + wave;
-  if (prob >= frames * heads) return;
-  const int f = prob / heads, h = prob % heads;
-  sq[wave][lane] = q[h * 64 + lane];
-  sg[wave][lane] = d_ctx[(size_t)f * D + h * 64 + lane];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int ld = 2 * D;
-  const int per = (N + 63) / 64;             // keys per lane (<= 4 for N <= 256)
-  float s[4], dp[4];
-  float m = NEG_BIG;
-  for (int i = 0; i < 4; ++i) {
-    s[i] = NEG_BIG; dp[i] = 0.f;
-    const int n = i * 64 + lane;
-    if (i < per && n < N) {
-      const bf16_t* kr = kv + ((size_t)f * N + n) * ld + h * 64;
-      const bf16_t* vr = kr + D;
-      float a = 0.f, b = 0.f;
-      for (int c = 0; c < 8; ++c) {
-        const u32x4_t kk = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
-        const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vr + c * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          a += bf2f(kk[j] & 0xffffu) * sq[wave][c * 8 + 2 * j] + bf2f(kk[j] >> 16) * sq[wave][c * 8 + 2 * j + 1];
-          b += bf2f(vv[j] & 0xffffu) * sg[wave][c * 8 + 2 * j] + bf2f(vv[j] >> 16) * sg[wave][c * 8 + 2 * j + 1];
-        }
-      }
-      s[i] = a; dp[i] = b;
-      m = fmaxf(m, a);
-    }
-  }
-  m = wave_max(m);
-  float l = 0.f;
-  for (int i = 0; i < 4; ++i) {
-    s[i] = s[i] > 0.5f * NEG_BIG ? __expf(s[i] - m) : 0.f;
-    l += s[i];
-  }
-  l = wave_sum(l);
-  const float inv = 1.0f / l;
-  float pd = 0.f;
-  for (int i = 0; i < 4; ++i) {
-    s[i] *= inv;                              // p
-    pd += s[i] * dp[i];
-  }
-  pd = wave_sum(pd);
-  float dq[64];
-#pragma unroll
-  for (int e = 0; e < 64; ++e) dq[e] = 0.f;
-  for (int i = 0; i < 4; ++i) {
-    const int n = i * 64 + lane;
-    if (i < per && n < N) {
-      const float p = s[i];
-      const float ds = p * (dp[i] - pd);
-      const size_t row = ((size_t)f * N + n) * ld + h * 64;
-      const bf16_t* kr = kv + row;
-      for (int c = 0; c < 8; ++c) {
-        const u32x4_t kk = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
-        u32x4_t ok, ov;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int e = c * 8 + 2 * j;
-          dq[e] += ds * bf2f(kk[j] & 0xffffu);
-          dq[e + 1] += ds * bf2f(kk[j] >> 16);
-          ok[j] = pack_bf2(ds * sq[wave][e], ds * sq[wave][e + 1]);
-          ov[j] = pack_bf2(p * sg[wave][e], p * sg[wave][e + 1]);
-        }
-        *reinterpret_cast<u32x4_t*>(d_kv + row + c * 8) = ok;
-        *reinterpret_cast<u32x4_t*>(d_kv + row + D + c * 8) = ov;
-      }
-    }
-  }
-  float mine = 0.f;
-#pragma unroll
-  for (int e = 0; e < 64; ++e) {
-    const float t = wave_sum(dq[e]);
-    if (lane == e) mine = t;
-  }
-  dq_frames[(size_t)f * D + h * 64 + lane] = mine;
-}
-
-hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const float* d_ctx, bf16_t* d_kv,
-                                        float* dq_frames, int frames, int N, int heads, int D, hipStream_t s) {
-  if (N <= 0 || N > 256 || D != heads * 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_pool_attn_bwd_kernel, dim3((frames * heads + 3) / 4), dim3(256), 0, s, q, kv, d_ctx, d_kv, dq_frames,
-                     frames, N, heads, D);
-  return hipGetLastError();
-}

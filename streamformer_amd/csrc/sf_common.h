@@ -339,10 +339,6 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
 bool sf_spatial_planes_ok(int N, bool probs);
 bool sf_temporal_planes_ok(int Tq, int Tk);
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
-// pooling head: one query (probe, pre-projected & pre-scaled, fp32 [D]) vs N keys per frame
-hipError_t sf_launch_pool_attention(const float* q, const void* kv, int kv_is_f32, int row_pitch,
-                                    bf16_t* ctx_hi, bf16_t* ctx_lo, int frames, int N, int heads,
-                                    int D, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // loss heads

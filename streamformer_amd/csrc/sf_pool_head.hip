@@ -72,226 +72,362 @@ hipError_t sf_launch_pool_u(const float* wk, const float* q, float* u, bf16_t* u
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward 1: scores -> softmax (within the workgroup's token split) -> weighted token sums
-// grid (F * S, heads / HP); block = 64 * ceil(D / 256) threads (a thread owns 4 columns of the weighted sum)
+// forward 1: one pass over the tokens of a (frame, token split) — chunks of 16 tokens staged in LDS (the next chunk's global
+// loads in flight under the current chunk's arithmetic), scores by MFMA with the K range split over the four waves, online
+// softmax (running max / sum per head, rescaled accumulators), weighted token sums in fp32 from the LDS image.
+// grid F * S; 256 threads; a thread owns 4 columns x all heads of the weighted sums
 // ------------------------------------------------------------------------------------------------
-template <int HP>
+#define PCH 16                         // tokens per chunk
+// all-reduce over the 16 lanes of a DPP row by rotations (row_ror:8 / 4 / 2 / 1): every lane ends with the row's result
+template <int ROT>
+SF_DEVICE float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROT, 0xf, 0xf, false));
+}
+SF_DEVICE float row16_max(float v) {
+  v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); return fmaxf(v, row_ror<1>(v));
+}
+SF_DEVICE float row16_sum(float v) {
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); return v + row_ror<1>(v);
+}
+// NH: heads rounded up to 4 / 8 / 12 / 16 (U rows past `heads` are zero); KI: k-steps per wave, ceil(D / 128) — a compile-time
+// count keeps the score loop one straight-line region (run-time trip counts split it into load -> wait -> use blocks)
+template <int NH, int KI>
 __global__ __launch_bounds__(256) void sf_pool_probe_kernel(SfPoolArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float sc[];      // [16][pitch] scores -> exp weights
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int f = blockIdx.x / p.S, sp = blockIdx.x % p.S, hg = blockIdx.y;
+  const int D = p.D, XP = D + 4, UP = D + 8;        // LDS row pitches (fp32 tokens, bf16 U rows): 4 banks of skew per row
+  float* xs = smem_f;                               // [PCH][XP] the current chunk's tokens (MFMA operand image)
+  float* red = xs + PCH * XP;                       // [4 waves][64 lanes][4] K-split partial scores
+  float* wts = red + 4 * 64 * 4;                    // [16 heads][PCH] exp weights of the current chunk
+  float* st = wts + 16 * PCH;                       // [2][48]: running max [16], running sum [16], this chunk's rescale factor [16]
+  bf16_t* us_hi = reinterpret_cast<bf16_t*>(st + 96);   // [16][UP]
+  bf16_t* us_lo = us_hi + 16 * UP;
+  const int f = blockIdx.x / p.S, sp = blockIdx.x % p.S;
   const int per = (((p.N + p.S - 1) / p.S) + 15) & ~15;
-  const int pitch = per + 4;
   const int n0 = sp * per;
   const int n1 = n0 + per < p.N ? n0 + per : p.N;
   const int nt = n1 > n0 ? n1 - n0 : 0;
-  const int tiles = (nt + 15) >> 4;
-  const float* xf = p.x + (size_t)f * p.N * p.D;
-  const int D = p.D;
+  const int nch = (nt + PCH - 1) / PCH;
+  const bool own = tid * 4 < D;                     // this thread owns columns 4 tid .. 4 tid + 3 of every token row
+  const float* xcol = p.x + ((size_t)f * p.N + n0) * D + (own ? tid * 4 : 0);
 
-  // ---- scores S[head][token] = U[head] . x[token], three bf16 products per operand pair ----------------------------
-  for (int t = wave; t < tiles; t += nw) {
-    const int tok = n0 + t * 16 + l15;
-    const int tokc = tok < p.N ? tok : p.N - 1;
-    const float* xr = xf + (size_t)tokc * D + g * 8;
-    const bf16_t* uh = p.u_hi + (size_t)l15 * D + g * 8;
-    const bf16_t* ul = p.u_lo + (size_t)l15 * D + g * 8;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < D; k += 64) {          // D = heads * 64: two k-steps per trip, all eight loads in front of the arithmetic
-      const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(xr + k), x1 = *reinterpret_cast<const f32x4_t*>(xr + k + 4);
-      const f32x4_t x2 = *reinterpret_cast<const f32x4_t*>(xr + k + 32), x3 = *reinterpret_cast<const f32x4_t*>(xr + k + 36);
-      const bf16x8_t ah0 = *reinterpret_cast<const bf16x8_t*>(uh + k), al0 = *reinterpret_cast<const bf16x8_t*>(ul + k);
-      const bf16x8_t ah1 = *reinterpret_cast<const bf16x8_t*>(uh + k + 32), al1 = *reinterpret_cast<const bf16x8_t*>(ul + k + 32);
-      bf16x8_t xh, xl;
-      split8(x0, x1, xh, xl);
-      acc = pmfma(al0, xh, acc);
-      acc = pmfma(ah0, xl, acc);
-      acc = pmfma(ah0, xh, acc);
-      split8(x2, x3, xh, xl);
-      acc = pmfma(al1, xh, acc);
-      acc = pmfma(ah1, xl, acc);
-      acc = pmfma(ah1, xh, acc);
+  if (tid < 96) st[tid] = (tid % 48) < 16 ? -INFINITY : 0.f;
+  {   // U planes -> LDS, 16 bytes per access; all loads first (a fixed trip count; an index past the end repeats the last element)
+    const int c8n = D >> 3, tot = 16 * c8n;
+    u32x4_t th[KI], tl[KI];
+    int dst[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int e = i * 256 + tid < tot ? i * 256 + tid : tot - 1;
+      const int r = e / c8n, c8 = e - r * c8n;
+      th[i] = *reinterpret_cast<const u32x4_t*>(p.u_hi + (size_t)r * D + c8 * 8);
+      tl[i] = *reinterpret_cast<const u32x4_t*>(p.u_lo + (size_t)r * D + c8 * 8);
+      dst[i] = r * UP + c8 * 8;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sc[(4 * g + j) * pitch + t * 16 + l15] = tok < n1 ? acc[j] : -INFINITY;
-  }
-  __syncthreads();
-  // ---- softmax over this split's tokens, heads of this workgroup ---------------------------------------------------
-  const int h0 = hg * HP;
-  for (int hh = wave; hh < HP; hh += nw) {
-    const int h = h0 + hh;
-    float* row = sc + h * pitch;
-    float m = -INFINITY;
-    for (int n = lane; n < nt; n += 64) m = fmaxf(m, row[n]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int n = lane; n < tiles * 16; n += 64) {
-      const float e = n < nt ? __builtin_amdgcn_exp2f((row[n] - m) * LOG2E) : 0.f;
-      row[n] = e;
-      l += e;
-    }
-    l = wave_sum(l);
-    if (p.normalize) {
-      const float inv = nt > 0 ? 1.0f / l : 0.f;
-      for (int n = lane; n < tiles * 16; n += 64) {
-        const float pr = row[n] * inv;
-        row[n] = pr;
-        if (p.probs && n < nt) p.probs[((size_t)f * p.heads + h) * p.N + n0 + n] = pr;
-      }
-    }
-    if (lane == 0 && p.ml) {
-      float* o = p.ml + (((size_t)f * p.S + sp) * p.heads + h) * 2;
-      o[0] = nt > 0 ? m : -INFINITY;
-      o[1] = nt > 0 ? l : 0.f;
+    for (int i = 0; i < KI; ++i) {
+      *reinterpret_cast<u32x4_t*>(us_hi + dst[i]) = th[i];
+      *reinterpret_cast<u32x4_t*>(us_lo + dst[i]) = tl[i];
     }
   }
-  __syncthreads();
-  // ---- z[h][d] = sum_n w[h][n] x[n][d]  (fp32; a thread owns 4 columns, HP heads) ----------------------------------
-  for (int c4 = tid; c4 * 4 < D; c4 += blockDim.x) {
-    f32x4_t acc[HP];
+  f32x4_t acc[NH];
 #pragma unroll
-    for (int i = 0; i < HP; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const float* xc = xf + (size_t)n0 * D + c4 * 4;
-    const int nt4 = tiles * 16;          // weights of the padding tokens are zero; their rows are clamped, finite reads
-    for (int n = 0; n < nt4; n += 4) {
-      f32x4_t xv[4];
+  for (int i = 0; i < NH; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // A thread reads its own 4 columns of the chunk's 16 tokens: exactly the operands of ITS weighted sums, which therefore stay in
+  // registers; the LDS image only feeds the score MFMAs.  The next chunk's 16 loads fly under the current chunk's arithmetic.
+  f32x4_t cx[PCH], nx[PCH];
+  auto issue = [&](int c) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int tk = n0 + n + i < p.N ? n + i : p.N - 1 - n0;
-        xv[i] = *reinterpret_cast<const f32x4_t*>(xc + (size_t)tk * D);
+    for (int t = 0; t < PCH; ++t) {
+      const int tok = c * PCH + t < nt ? c * PCH + t : nt - 1;          // rows past the split: a valid row, weight zero
+      nx[t] = *reinterpret_cast<const f32x4_t*>(xcol + (size_t)tok * D);
+    }
+  };
+  if (nch > 0 && own) issue(0);
+  const int nks = D >> 5;
+  for (int c = 0; c < nch; ++c) {
+    const float* sto = st + (c & 1) * 48;
+    float* stn = st + ((c + 1) & 1) * 48;
+    if (own) {
+#pragma unroll
+      for (int t = 0; t < PCH; ++t) {
+        cx[t] = nx[t];
+        *reinterpret_cast<f32x4_t*>(xs + t * XP + tid * 4) = cx[t];
+      }
+      if (c + 1 < nch) issue(c + 1);
+    }
+    __syncthreads();
+    // ---- scores of the chunk: S[head][token] = U[head] . x[token]; wave w takes k-steps w, w + 4, ... ------------------
+    {
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+      const float* xr = xs + l15 * XP + g * 8;
+      const bf16_t* uh = us_hi + l15 * UP + g * 8;
+      const bf16_t* ul = us_lo + l15 * UP + g * 8;
+      f32x4_t xa[KI], xb4[KI];
+      bf16x8_t ah[KI], al[KI];
+#pragma unroll
+      for (int i = 0; i < KI; ++i) {                 // a k-step past the end (ragged D): a valid address, operand zeroed below
+        const int ks = wave + 4 * i;
+        const int kc = ks < nks ? ks : nks - 1;
+        xa[i] = *reinterpret_cast<const f32x4_t*>(xr + kc * 32);
+        xb4[i] = *reinterpret_cast<const f32x4_t*>(xr + kc * 32 + 4);
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(uh + kc * 32);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(ul + kc * 32);
       }
 #pragma unroll
-      for (int i = 0; i < HP; ++i) {
-        const f32x4_t w = *reinterpret_cast<const f32x4_t*>(sc + (h0 + i) * pitch + n);
-        acc[i] += w[0] * xv[0];
-        acc[i] += w[1] * xv[1];
-        acc[i] += w[2] * xv[2];
-        acc[i] += w[3] * xv[3];
+      for (int i = 0; i < KI; ++i) {
+        const float keep = wave + 4 * i < nks ? 1.f : 0.f;
+        bf16x8_t xh, xl;
+        split8(xa[i] * keep, xb4[i] * keep, xh, xl);
+        a = pmfma(al[i], xh, a);
+        a = pmfma(ah[i], xl, a);
+        a = pmfma(ah[i], xh, a);
+      }
+      *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = a;
+    }
+    __syncthreads();
+    {   // thread (h = tid / 16, tok = tid % 16): the score, then the online-softmax update of head h over the 16 lanes of its DPP row
+      const int h = tid >> 4, tk = tid & 15;
+      const int src = ((h >> 2) * 16 + tk) * 4 + (h & 3);
+      const float sraw = (red[src] + red[256 + src]) + (red[512 + src] + red[768 + src]);
+      const bool ok = c * PCH + tk < nt;
+      if (p.probs && ok && h < p.heads) p.probs[((size_t)f * p.heads + h) * p.N + n0 + c * PCH + tk] = sraw;      // raw scores, finished below
+      const float sv = ok ? sraw : -INFINITY;
+      const float cm = row16_max(sv);
+      const float m_old = sto[h], l_old = sto[16 + h];
+      const float m_new = fmaxf(m_old, cm);
+      const float e = ok ? __builtin_amdgcn_exp2f((sv - m_new) * LOG2E) : 0.f;
+      const float cl = row16_sum(e);
+      const float alpha = m_old == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m_old - m_new) * LOG2E);
+      wts[h * PCH + tk] = e;
+      if (tk == 0) { stn[h] = m_new; stn[16 + h] = l_old * alpha + cl; stn[32 + h] = alpha; }
+    }
+    __syncthreads();
+    // ---- z[h][d] = alpha_h z[h][d] + sum_tok w[h][tok] x[tok][d], x from this thread's registers ----------------------
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        acc[i] *= stn[32 + i];
+#pragma unroll
+        for (int t4 = 0; t4 < PCH; t4 += 4) {
+          const f32x4_t w = *reinterpret_cast<const f32x4_t*>(wts + i * PCH + t4);
+          acc[i] += w[0] * cx[t4];
+          acc[i] += w[1] * cx[t4 + 1];
+          acc[i] += w[2] * cx[t4 + 2];
+          acc[i] += w[3] * cx[t4 + 3];
+        }
       }
     }
+    // no barrier here: the next trip's first LDS writes go to xs (last read before the barrier above), and red / wts / st
+    // are only rewritten behind the next trip's barriers
+  }
+  __syncthreads();
+  const float* stf = st + (nch & 1) * 48;
+  // ---- results: the weighted sums (normalised when this workgroup saw the whole frame), {max, sum} per head, probabilities ----
+  if (own) {
 #pragma unroll
-    for (int i = 0; i < HP; ++i)
-      *reinterpret_cast<f32x4_t*>(p.zpart + (((size_t)f * p.S + sp) * p.heads + h0 + i) * D + c4 * 4) = acc[i];
+    for (int i = 0; i < NH; ++i)
+      if (i < p.heads) {
+        const float l = stf[16 + i];
+        const float sc = p.normalize ? (l > 0.f ? 1.0f / l : 0.f) : 1.0f;
+        *reinterpret_cast<f32x4_t*>(p.zpart + (((size_t)f * p.S + sp) * p.heads + i) * D + tid * 4) = acc[i] * sc;
+      }
+  }
+  if (p.ml && tid < p.heads) {
+    float* o = p.ml + (((size_t)f * p.S + sp) * p.heads + tid) * 2;
+    o[0] = stf[tid];
+    o[1] = stf[16 + tid];
+  }
+  if (p.probs) {      // raw scores (written by this workgroup above; S == 1) -> probabilities
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < p.heads * nt; i += 256) {
+      const int h = i / nt, n = i - h * nt;
+      float* o = p.probs + ((size_t)f * p.heads + h) * p.N + n0 + n;
+      *o = __builtin_amdgcn_exp2f((*o - stf[h]) * LOG2E) / stf[16 + h];
+    }
   }
 }
 
-static int pool_hp(int heads) {
-  if (heads <= 8) return heads;
-  for (int hp = 6; hp >= 2; --hp)
-    if (heads % hp == 0) return hp;
-  return 1;
-}
 int sf_pool_splits(int F, int N, int heads) {
-  const int hg = heads / pool_hp(heads);
+  (void)heads;
   int S = 1;
-  while (S < 8 && F * hg * S < 256 && (N + 2 * S - 1) / (2 * S) >= 16) S *= 2;
+  while (S < 8 && F * S < 256 && (N + 2 * S - 1) / (2 * S) >= 16) S *= 2;
   return S;
 }
 size_t sf_pool_z_floats(int F, int N, int heads, int D) { return (size_t)F * sf_pool_splits(F, N, heads) * heads * D; }
 size_t sf_pool_ml_floats(int F, int N, int heads) { return (size_t)F * sf_pool_splits(F, N, heads) * heads * 2; }
 
 hipError_t sf_launch_pool_probe(const SfPoolArgs& a, hipStream_t s) {
-  if (a.heads > 16 || a.D != a.heads * 64 || a.F <= 0 || a.N <= 0 || a.S < 1) return hipErrorInvalidValue;
-  if (a.normalize && a.S != 1) return hipErrorInvalidValue;
-  const int per = (((a.N + a.S - 1) / a.S) + 15) & ~15;
-  const size_t lds = (size_t)16 * (per + 4) * sizeof(float);
-  if (lds > 150 * 1024) return hipErrorInvalidValue;
-  const int hp = pool_hp(a.heads);
-  const int threads = 64 * ((a.D / 4 + 63) / 64) > 256 ? 256 : 64 * ((a.D / 4 + 63) / 64);
-  const dim3 grid(a.F * a.S, a.heads / hp);
-#define SF_POOL_CASE(HP)                                                                                              \
-  case HP: {                                                                                                          \
+  if (a.heads > 16 || a.D != a.heads * 64 || a.D > 1024 || a.F <= 0 || a.N <= 0 || a.S < 1) return hipErrorInvalidValue;
+  if ((a.normalize || a.probs) && a.S != 1) return hipErrorInvalidValue;
+  if (a.S > 1 && !a.ml) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)PCH * (a.D + 4) + 4 * 64 * 4 + 16 * PCH + 96) * sizeof(float) + (size_t)2 * 16 * (a.D + 8) * sizeof(bf16_t);
+  const dim3 grid(a.F * a.S);
+#define SF_POOL_CASE(NH, KI)                                                                                          \
+  {                                                                                                                   \
     static SfPerDeviceOnce once;                                                                                      \
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_probe_kernel<HP>),             \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);              \
-    hipLaunchKernelGGL(sf_pool_probe_kernel<HP>, grid, dim3(threads), lds, s, a);                                     \
-    break;                                                                                                            \
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_probe_kernel<NH, KI>),         \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+    hipLaunchKernelGGL((sf_pool_probe_kernel<NH, KI>), grid, dim3(256), lds, s, a);                                   \
   }
-  switch (hp) {
-    SF_POOL_CASE(1) SF_POOL_CASE(2) SF_POOL_CASE(3) SF_POOL_CASE(4) SF_POOL_CASE(5) SF_POOL_CASE(6) SF_POOL_CASE(7) SF_POOL_CASE(8)
-    default: return hipErrorInvalidValue;
-  }
+  // D = 64 heads: k-steps per wave = ceil(2 heads / 4)
+  if (a.heads <= 2) SF_POOL_CASE(4, 1)
+  else if (a.heads <= 4) SF_POOL_CASE(4, 2)
+  else if (a.heads <= 6) SF_POOL_CASE(8, 3)
+  else if (a.heads <= 8) SF_POOL_CASE(8, 4)
+  else if (a.heads <= 12) SF_POOL_CASE(12, 6)
+  else SF_POOL_CASE(16, 8)
 #undef SF_POOL_CASE
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward 2: combine the token splits, ctx[f][h*64 + c] = Wv[h*64 + c] . z[f][h] + bv   (MFMA, bf16x3)
-// grid (ceil(F / 16), heads); 4 waves = the four 16-column tiles of the head
+// grid (ceil(F / 16), heads * 4): one 16-frame x 16-column tile per workgroup, its K range split over the four waves
+// (every load of a wave issued in front of its arithmetic: the tile is one memory round trip deep)
 // ------------------------------------------------------------------------------------------------
+template <int CTX_KI>                  // k-steps per wave, ceil(D / 128): compile-time, so that every load of a wave is issued before its first use
 __global__ __launch_bounds__(256) void sf_pool_ctx_kernel(SfPoolCtxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int f = blockIdx.x * 16 + l15, h = blockIdx.y;
-  const bool fv = f < p.F;
-  const int fc = fv ? f : p.F - 1;
-  const int D = p.D, S = p.S;
-  float wgt[8];
+  const int f0 = blockIdx.x * 16, h = blockIdx.y >> 2, ct = blockIdx.y & 3;
+  const int D = p.D, S = p.S, ZP = D + 4;
+  float* red = smem_f;                               // [4][64][4]
+  float* zs = red + 4 * 64 * 4;                      // S > 1: combined z tile [16][ZP]
+  const int nf = p.F - f0 < 16 ? p.F - f0 : 16;
+  const bool fv = l15 < nf;
+  const int nks = D >> 5;
+  // this wave's weight fragments (k-steps wave, wave + 4, ...): issued first, they fly under the combine below
+  const float* wr = p.wv + (size_t)(h * 64 + ct * 16 + l15) * p.ldw + g * 8;
+  f32x4_t wa[CTX_KI], wb[CTX_KI];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) wgt[i] = 0.f;
+  for (int i = 0; i < CTX_KI; ++i) {
+    const int ks = wave + 4 * i;
+    const int kc = ks < nks ? ks : nks - 1;          // ragged D: a valid address, the z fragment is zeroed below
+    wa[i] = *reinterpret_cast<const f32x4_t*>(wr + kc * 32);
+    wb[i] = *reinterpret_cast<const f32x4_t*>(wr + kc * 32 + 4);
+  }
   if (S > 1) {
-    float m = -INFINITY;
-    for (int sidx = 0; sidx < S; ++sidx) m = fmaxf(m, p.ml[(((size_t)fc * S + sidx) * p.heads + h) * 2]);
-    float L = 0.f;
+    // combine the splits of the valid frames, flash-decoding style: z = sum_s exp(m_s - m) z_s / sum_s exp(m_s - m) l_s
+    float* wl = zs + 16 * ZP;                        // [16 frames][8 splits] weights
+    const int nv4 = D >> 2;
+    // the partial sums of this thread's elements first (independent of the weights), then the weights, then the combination
+    f32x4_t part[8];
+    const int e0 = tid;                              // one valid frame of <= 1024 columns (the streamed case); more frames loop below
+    const bool one = nf == 1 && nv4 <= 256;
+    if (one && e0 < nf * nv4) {
+      const float* zr0 = p.zpart + (((size_t)f0 * S) * p.heads + h) * D + e0 * 4;
 #pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx)
-      if (sidx < S) {
-        const float* o = p.ml + (((size_t)fc * S + sidx) * p.heads + h) * 2;
-        const float w = o[1] > 0.f ? __builtin_amdgcn_exp2f((o[0] - m) * LOG2E) : 0.f;
-        wgt[sidx] = w;
-        L += w * o[1];
+      for (int sidx = 0; sidx < 8; ++sidx)          // branch-free: a split past S reads split 0, its weight below is zero
+        part[sidx] = *reinterpret_cast<const f32x4_t*>(zr0 + (size_t)(sidx < S ? sidx : 0) * p.heads * D);
+    }
+    if (tid < 16) {
+      float w[8], mm[8], ll[8];
+      const int fr = tid < nf ? f0 + tid : f0;
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx) {
+        const float* o = p.ml + (((size_t)fr * S + (sidx < S ? sidx : 0)) * p.heads + h) * 2;
+        const float a0 = o[0], a1 = o[1];
+        mm[sidx] = sidx < S ? a0 : -INFINITY;
+        ll[sidx] = sidx < S ? a1 : 0.f;
       }
-    const float inv = 1.0f / L;
+      float m = -INFINITY, L = 0.f;
 #pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) wgt[sidx] *= inv;
+      for (int sidx = 0; sidx < 8; ++sidx) m = fmaxf(m, mm[sidx]);
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx) {
+        w[sidx] = ll[sidx] > 0.f ? __builtin_amdgcn_exp2f((mm[sidx] - m) * LOG2E) : 0.f;
+        L += w[sidx] * ll[sidx];
+      }
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx) wl[tid * 8 + sidx] = w[sidx] * inv;
+    }
+    __syncthreads();
+    if (one) {
+      if (e0 < nf * nv4) {
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) v += (sidx < S ? wl[sidx] : 0.f) * part[sidx];
+        *reinterpret_cast<f32x4_t*>(zs + e0 * 4) = v;
+        if (p.z_out && ct == 0) *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)f0 * p.heads + h) * D + e0 * 4) = v;
+      }
+    } else {
+      for (int e = tid; e < nf * nv4; e += 256) {
+        const int fr = e / nv4, c4 = e - fr * nv4;
+        const float* zr = p.zpart + (((size_t)(f0 + fr) * S) * p.heads + h) * D + c4 * 4;
+        f32x4_t pv[8];
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) pv[sidx] = *reinterpret_cast<const f32x4_t*>(zr + (size_t)(sidx < S ? sidx : 0) * p.heads * D);
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) v += (sidx < S ? wl[fr * 8 + sidx] : 0.f) * pv[sidx];
+        *reinterpret_cast<f32x4_t*>(zs + fr * ZP + c4 * 4) = v;
+        if (p.z_out && ct == 0) *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)(f0 + fr) * p.heads + h) * D + c4 * 4) = v;
+      }
+    }
+    __syncthreads();
   }
-  const float* wr = p.wv + (size_t)(h * 64 + wave * 16 + l15) * p.ldw + g * 8;
-  const float* zr = p.zpart + (((size_t)fc * S) * p.heads + h) * D + g * 8;
-  const size_t zs = (size_t)p.heads * D;         // split stride
+  const float* zr = S > 1 ? zs + (fv ? l15 : 0) * ZP + g * 8 : p.zpart + ((size_t)(f0 + (fv ? l15 : 0)) * p.heads + h) * D + g * 8;
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < D; k += 32) {
-    f32x4_t za = {0.f, 0.f, 0.f, 0.f}, zb = {0.f, 0.f, 0.f, 0.f};
-    if (fv) {
-      if (S == 1) {
-        za = *reinterpret_cast<const f32x4_t*>(zr + k);
-        zb = *reinterpret_cast<const f32x4_t*>(zr + k + 4);
-      } else {
+  {
+    f32x4_t za[CTX_KI], zb[CTX_KI];
 #pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx)
-          if (sidx < S) {
-            za += wgt[sidx] * *reinterpret_cast<const f32x4_t*>(zr + sidx * zs + k);
-            zb += wgt[sidx] * *reinterpret_cast<const f32x4_t*>(zr + sidx * zs + k + 4);
-          }
-      }
+    for (int i = 0; i < CTX_KI; ++i) {
+      const int ks = wave + 4 * i;
+      const int kc = ks < nks ? ks : nks - 1;
+      za[i] = *reinterpret_cast<const f32x4_t*>(zr + kc * 32);
+      zb[i] = *reinterpret_cast<const f32x4_t*>(zr + kc * 32 + 4);
     }
-    bf16x8_t zh, zl, wh, wl;
-    split8(za, zb, zh, zl);
-    split8p(wr + k, wh, wl);
-    acc = pmfma(wl, zh, acc);
-    acc = pmfma(wh, zl, acc);
-    acc = pmfma(wh, zh, acc);
-    if (p.z_out && S > 1 && wave == 0 && fv) {       // the combined, normalised sums (kept for inspection / a later backward)
-      *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)f * p.heads + h) * D + g * 8 + k) = za;
-      *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)f * p.heads + h) * D + g * 8 + k + 4) = zb;
+#pragma unroll
+    for (int i = 0; i < CTX_KI; ++i) {
+      const float keep = wave + 4 * i < nks ? 1.f : 0.f;
+      bf16x8_t zh, zl, wh, wl2;
+      split8(za[i] * keep, zb[i] * keep, zh, zl);
+      split8(wa[i], wb[i], wh, wl2);
+      acc = pmfma(wl2, zh, acc);
+      acc = pmfma(wh, zl, acc);
+      acc = pmfma(wh, zh, acc);
     }
   }
-  // lane: ctx[frame l15][column h*64 + wave*16 + 4g + j]
-  if (!fv) return;
-  const int c = h * 64 + wave * 16 + 4 * g;
-  const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bv + c);
-  acc += b;
+  *reinterpret_cast<f32x4_t*>(red + (wave * 64 + lane) * 4) = acc;
+  __syncthreads();
+  if (wave != 0 || !fv) return;
+  // lane: ctx[frame f0 + l15][column h*64 + ct*16 + 4g + j]
+  const float* r0 = red + lane * 4;
+  acc = (*reinterpret_cast<const f32x4_t*>(r0) + *reinterpret_cast<const f32x4_t*>(r0 + 256)) +
+        (*reinterpret_cast<const f32x4_t*>(r0 + 512) + *reinterpret_cast<const f32x4_t*>(r0 + 768));
+  const int c = h * 64 + ct * 16 + 4 * g;
+  acc += *reinterpret_cast<const f32x4_t*>(p.bv + c);
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) split_bf(acc[j], hi[j], lo[j]);
-  const size_t o = (size_t)f * D + c;
+  const size_t o = (size_t)(f0 + l15) * D + c;
   if (p.ctx_f32) *reinterpret_cast<f32x4_t*>(p.ctx_f32 + o) = acc;
   if (p.ctx_hi) *reinterpret_cast<u32x2_t*>(p.ctx_hi + o) = (u32x2_t){hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
   if (p.ctx_lo) *reinterpret_cast<u32x2_t*>(p.ctx_lo + o) = (u32x2_t){lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
 }
 hipError_t sf_launch_pool_ctx(const SfPoolCtxArgs& a, hipStream_t s) {
-  if (a.heads > 16 || a.D != a.heads * 64 || a.F <= 0 || a.S < 1 || a.S > 8 || (a.S > 1 && !a.ml)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_pool_ctx_kernel, dim3((a.F + 15) / 16, a.heads), dim3(256), 0, s, a);
+  if (a.heads > 16 || a.D != a.heads * 64 || a.D > 1024 || a.F <= 0 || a.S < 1 || a.S > 8 || (a.S > 1 && !a.ml)) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)4 * 64 * 4 + (a.S > 1 ? (size_t)16 * (a.D + 4) + 16 * 8 : 0)) * sizeof(float);
+  const dim3 grid((a.F + 15) / 16, a.heads * 4);
+#define SF_CTX_CASE(KI)                                                                                               \
+  {                                                                                                                   \
+    static SfPerDeviceOnce once;                                                                                      \
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_ctx_kernel<KI>),               \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);               \
+    hipLaunchKernelGGL(sf_pool_ctx_kernel<KI>, grid, dim3(256), lds, s, a);                                           \
+  }
+  if (a.heads <= 2) SF_CTX_CASE(1)
+  else if (a.heads <= 4) SF_CTX_CASE(2)
+  else if (a.heads <= 6) SF_CTX_CASE(3)
+  else if (a.heads <= 8) SF_CTX_CASE(4)
+  else if (a.heads <= 12) SF_CTX_CASE(6)
+  else SF_CTX_CASE(8)
+#undef SF_CTX_CASE
   return hipGetLastError();
 }
 

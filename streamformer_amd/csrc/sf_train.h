@@ -67,10 +67,7 @@ struct SfAttnBwdArgs {
 };
 hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);    // L <= 224
 hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s);   // L <= 32
-// pooling head: q fp32 [D] (projected, scaled), kv bf16 [F*N, 2D], d_ctx fp32 [F, D]
-//   -> d_kv bf16 [F*N, 2D], dq_frames fp32 [F, D] (gradient wrt the scaled q, per frame)
-hipError_t sf_launch_pool_attention_bwd(const float* q, const bf16_t* kv, const float* d_ctx, bf16_t* d_kv,
-                                        float* dq_frames, int frames, int N, int heads, int D, hipStream_t s);
+// (pooling head backward: sf_pool_head.h)
 
 // ------------------------------------------------------------------------------------------------
 // row-wise / elementwise

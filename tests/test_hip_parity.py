@@ -26,8 +26,10 @@ ACC_CEIL = 5e-4
 # bf16 mode.  pooler_output: 3e-2 until round 3 (measured 2.7e-2).  Round 4 runs the pooling head's per-frame tail in bf16x3 in both modes: the
 # head's own contribution fell from 1.5e-2 to 6.7e-3 and the SigLIP-base clip of bench.py measures 1.93e-2, of which 1.86e-2 is what the
 # encoder's bf16 tokens carry through an EXACT head (tools/pool_err.py) — the operand floor, not the head.  SURVEY's 2e-2 holds for the
-# SigLIP-base fixtures; the 128-wide two-layer fixture F7 (T = 32) measures 2.06e-2, hence 2.2e-2.
-BF16_LHS, BF16_POOL = 4e-2, 2.2e-2
+# SigLIP-base fixtures; the 128-wide two-layer fixture F7 (T = 32) measured 2.06e-2, hence 2.2e-2 in round 4.  Round 5: the head no longer
+# projects the tokens to k / v at all (sf_pool_head.hip: scores and weighted sums on the fp32 tokens, bf16x3 / fp32 arithmetic in both
+# modes), so what is left is exactly what the encoder's tokens carry: back to SURVEY's 2e-2 for every fixture.
+BF16_LHS, BF16_POOL = 4e-2, 2e-2
 
 
 @pytest.fixture(scope="module")
