@@ -82,6 +82,12 @@ struct sf_trainer {
   int* guard_flag = nullptr;          // non-finite guard (sf_trainer_set_nonfinite_guard): device int32[2], caller-owned
   const float* guard_loss = nullptr;  // optional device loss scalar checked next to the gradient's sum of squares
   float* guard_sumsq = nullptr;       // library-owned scalar the guard's own sum-of-squares pass writes
+  // The rank-32 LoRA gradients of a layer (two projections, two small weight-gradient GEMMs + reductions per adapted Linear:
+  // ~1.8 ms per step at 8 clips, all bandwidth- / latency-bound launches that depend on nothing downstream) run on a library-owned
+  // side stream, forked from and joined into the caller's stream inside every layer: they fill the gaps of the MFMA-bound chain.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_state = 0;                 // 0 = not tried, 1 = available, -1 = unavailable (creation failed / SF_TRAIN_SIDE_STREAM=0)
 };
 
 static int add_param(sf_trainer* t, const std::string& name, std::initializer_list<int64_t> shape, bool trainable) {
@@ -309,6 +315,9 @@ extern "C" void sf_trainer_destroy(sf_trainer* t) {
   (void)hipSetDevice(t->device);
   free_trainer_device(t);
   if (t->guard_sumsq) (void)hipFree(t->guard_sumsq);
+  if (t->side) (void)hipStreamDestroy(t->side);
+  if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+  if (t->ev_join) (void)hipEventDestroy(t->ev_join);
   delete t;
 }
 
@@ -409,6 +418,8 @@ struct TWs {
   bf16_t* d_ln_bf;
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
   bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
+  float *wg_partial_side, *cs_partial_side;          // the side stream's own scratch (LoRA gradients, see sf_trainer::side)
+  bf16_t *lora_u_side, *lora_v_side;
   bf16_t *g_bf1, *g_bf2, *d_wide_s, *d_wide_t;       // a layer's weight-gradient operands stay intact until its grouped launch
   float *gh, *d_hn, *d_pc, *dq_total, *pdz, *pdu;
   bf16_t* pds;                         // pooling head: score gradients [M, 32] (the dY operand of dU = ds^T x)
@@ -450,6 +461,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   w.g_bf1 = c.take<bf16_t>(M * D); w.g_bf2 = c.take<bf16_t>(M * D);
   w.d_wide_s = c.take<bf16_t>(M * 3 * D); w.d_wide_t = c.take<bf16_t>(M * 3 * D);
   w.lora_u = c.take<bf16_t>(M * kRank); w.lora_v = c.take<bf16_t>(M * kRank);
+  w.lora_u_side = c.take<bf16_t>(M * kRank); w.lora_v_side = c.take<bf16_t>(M * kRank);
   size_t wp = 0;
   const int Mi = (int)M, Fi = (int)F, Di = t->D, Ii = t->I;
   wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Di, Ii)); wp = max_sz(wp, sf_wgrad_partial_floats(Mi, Ii, Di));
@@ -466,10 +478,17 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
     for (int n = 1; n <= tiles; ++n) wp = max_sz(wp, sf_wgrad_group_partial_floats(Mi, n, n1));
   }
   w.wg_partial = c.take<float>(wp);
+  {
+    size_t ws2 = 0;
+    ws2 = max_sz(ws2, sf_wgrad_partial_floats(Mi, 3 * Di, kRank)); ws2 = max_sz(ws2, sf_wgrad_partial_floats(Mi, kRank, Di));
+    ws2 = max_sz(ws2, sf_wgrad_partial_floats(Mi, Di, kRank));
+    w.wg_partial_side = c.take<float>(ws2);
+  }
   w.dw_scratch = c.take<float>((size_t)3 * D * D);
   w.cs = c.take<float>(max_sz(I, 3 * D));
   w.ln_partial = c.take<float>(sf_ln_bwd_partial_floats(t->D));
   w.cs_partial = c.take<float>(sf_colsum_partial_floats((int)max_sz(I, 3 * D)));
+  w.cs_partial_side = c.take<float>(sf_colsum_partial_floats((int)max_sz(I, 3 * D)));
   w.s_tn = c.take<float>((size_t)T * N * D);
   w.gh = c.take<float>(F * D); w.d_hn = c.take<float>(F * D); w.d_pc = c.take<float>(F * D);
   w.dq_total = c.take<float>(D);
@@ -688,6 +707,11 @@ struct BwdCtx {
   const TWs* ws;
   float* grads;
   hipStream_t s;
+  bool on_side = false;               // this context launches on the side stream and uses the side scratch
+  bf16_t* lora_u() const { return on_side ? ws->lora_u_side : ws->lora_u; }
+  bf16_t* lora_v() const { return on_side ? ws->lora_v_side : ws->lora_v; }
+  float* wg_partial() const { return on_side ? ws->wg_partial_side : ws->wg_partial; }
+  float* cs_partial() const { return on_side ? ws->cs_partial_side : ws->cs_partial; }
 };
 
 // weight + bias gradients of one Linear: dW (+)= dy^T x, db += colsum(dy); LoRA factors from dW_eff
@@ -698,27 +722,27 @@ static hipError_t lin_wgrad(const BwdCtx& c, const TLin& l, const bf16_t* dy, co
   SfWgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.ldy = l.N; a.x = x; a.ldx = l.K; a.M = M; a.N1 = l.N; a.N2 = l.K; a.ldo = l.K; a.alpha = 1.f;
-  a.partial = c.ws->wg_partial;
+  a.partial = c.wg_partial();
   hipError_t e = hipSuccess;
   if (l.pla >= 0) {
     // W_eff = W + B A (modeling:541-545):  dB = dy^T (x A^T),  dA = (dy B)^T x  — two rank-32 projections
     // and two skinny weight-gradient GEMMs instead of the full [N,K] one (the base weight is frozen)
-    if ((e = tgemm(x, l.la_bf, nullptr, M, kRank, l.K, SF_EPI_BF16, c.s, nullptr, c.ws->lora_u)) != hipSuccess) return e;
-    if ((e = tgemm(dy, l.lbT_bf, nullptr, M, kRank, l.N, SF_EPI_BF16, c.s, nullptr, c.ws->lora_v)) != hipSuccess) return e;
+    if ((e = tgemm(x, l.la_bf, nullptr, M, kRank, l.K, SF_EPI_BF16, c.s, nullptr, c.lora_u())) != hipSuccess) return e;
+    if ((e = tgemm(dy, l.lbT_bf, nullptr, M, kRank, l.N, SF_EPI_BF16, c.s, nullptr, c.lora_v())) != hipSuccess) return e;
     SfWgradArgs b = a;
-    b.dy = dy; b.ldy = l.N; b.x = c.ws->lora_u; b.ldx = kRank; b.N1 = l.N; b.N2 = kRank; b.ldo = kRank;
+    b.dy = dy; b.ldy = l.N; b.x = c.lora_u(); b.ldx = kRank; b.N1 = l.N; b.N2 = kRank; b.ldo = kRank;
     b.out = GG(t, c.grads, l.plb); b.accumulate = 1;
     if (b.out && (e = sf_launch_wgrad(b, c.s)) != hipSuccess) return e;
-    b.dy = c.ws->lora_v; b.ldy = kRank; b.x = x; b.ldx = l.K; b.N1 = kRank; b.N2 = l.K; b.ldo = l.K;
+    b.dy = c.lora_v(); b.ldy = kRank; b.x = x; b.ldx = l.K; b.N1 = kRank; b.N2 = l.K; b.ldo = l.K;
     b.out = GG(t, c.grads, l.pla);
     if (b.out && (e = sf_launch_wgrad(b, c.s)) != hipSuccess) return e;
   }
   if (gw) {
     a.out = gw; a.accumulate = 1;
-    a.dbias = gb; a.dbias_scratch = c.ws->cs_partial;      // bias gradient rides on the same launch
+    a.dbias = gb; a.dbias_scratch = c.cs_partial();      // bias gradient rides on the same launch
     e = sf_launch_wgrad(a, c.s);
   } else if (gb) {
-    e = sf_launch_colsum_bf16(dy, M, l.N, l.N, 1.f, gb, 1, c.ws->cs_partial, c.s);
+    e = sf_launch_colsum_bf16(dy, M, l.N, l.N, 1.f, gb, 1, c.cs_partial(), c.s);
   }
   return e;
 }
@@ -788,6 +812,37 @@ static hipError_t lin_wgrad_queued(const BwdCtx& c, LayerWgrads& q, const TLin& 
   return hipSuccess;
 }
 
+// the side stream of the LoRA gradients: created on first use; SF_TRAIN_SIDE_STREAM=0 keeps everything on the caller's stream (A/B)
+static bool side_stream_ready(sf_trainer* t) {
+  if (t->side_state == 0) {
+    const char* e = getenv("SF_TRAIN_SIDE_STREAM");
+    t->side_state = -1;
+    if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) == hipSuccess)
+      t->side_state = 1;
+  }
+  return t->side_state == 1;
+}
+// weight gradients of a LoRA-adapted Linear, forked onto the side stream behind everything the caller's stream has enqueued so
+// far (its operands are complete there); the caller joins at the end of the layer (side_join)
+static hipError_t lin_wgrad_side(const BwdCtx& c, const TLin& l, const bf16_t* dy, const bf16_t* x, int M, bool* forked) {
+  sf_trainer* t = const_cast<sf_trainer*>(c.t);
+  if (l.pla < 0 || !side_stream_ready(t)) return lin_wgrad(c, l, dy, x, M);
+  hipError_t e;
+  if ((e = hipEventRecord(t->ev_fork, c.s)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(t->side, t->ev_fork, 0)) != hipSuccess) return e;
+  BwdCtx cs = c;
+  cs.s = t->side; cs.on_side = true;
+  *forked = true;
+  return lin_wgrad(cs, l, dy, x, M);
+}
+static hipError_t side_join(const BwdCtx& c) {
+  sf_trainer* t = const_cast<sf_trainer*>(c.t);
+  hipError_t e = hipEventRecord(t->ev_join, t->side);
+  return e != hipSuccess ? e : hipStreamWaitEvent(c.s, t->ev_join, 0);
+}
+
 static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   const sf_trainer* t = c.t;
   const TWs& ws = *c.ws;
@@ -809,6 +864,8 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   const int I = t->I;
   auto site = [&](int k) { return sf_drop_make(t->f_drop_hidden, t->f_drop_seed, (unsigned)(li * 8 + k)); };
   q.on = !dp && !hd && !ungrouped;  // the drop_path / dropout copies reuse d_ctx / d_tout inside the layer: immediate launches there
+  const bool side_ok = q.on;        // same condition: the side stream's operands must stay untouched until the end of the layer
+  bool forked = false;
   // g (fp32) and its bf16 copy are both written by the LayerNorm backward that produced them; the bf16 copy rotates through
   // g_bf -> g_bf1 -> g_bf2 -> g_bf inside the layer and the three attention / MLP gradients have their own wide buffers, so
   // that every queued weight gradient still finds its operands at the end of the layer
@@ -826,7 +883,8 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   gy = ws.g_bf1;
   if (dp || hd) { HIP_TRY(sf_launch_rowscale_bf16(ws.g_bf1, ws.d_tout, dp ? dp + (size_t)B * N : nullptr, M, D, 1, T, N, s, site(1))); gy = ws.d_tout; }
   HIP_TRY(lin_dgrad(l.s_out, gy, M, s, nullptr, ws.d_ctx));
-  HIP_TRY(lin_wgrad_queued(c, q, l.s_out, gy, sv.ctx_s, M));
+  if (side_ok && l.s_out.pla >= 0) HIP_TRY(lin_wgrad_side(c, l.s_out, gy, sv.ctx_s, M, &forked));
+  else HIP_TRY(lin_wgrad_queued(c, q, l.s_out, gy, sv.ctx_s, M));
   {
     SfAttnBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -836,7 +894,8 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     if (t->f_drop_attn > 0.f) a.drop = sf_drop_make(t->f_drop_attn, t->f_drop_seed, (unsigned)(li * 8 + 5));
     HIP_TRY(sf_launch_spatial_attention_bwd(a, s));
   }
-  HIP_TRY(lin_wgrad_queued(c, q, l.s_qkv, ws.d_wide_s, sv.ln_b, M));
+  if (side_ok && l.s_qkv.pla >= 0) HIP_TRY(lin_wgrad_side(c, l.s_qkv, ws.d_wide_s, sv.ln_b, M, &forked));
+  else HIP_TRY(lin_wgrad_queued(c, q, l.s_qkv, ws.d_wide_s, sv.ln_b, M));
   HIP_TRY(lin_dgrad(l.s_qkv, ws.d_wide_s, M, s, nullptr, ws.d_ln_bf));
   HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln_bf, 1, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf2, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
                            ws.ln_partial, M, D, eps, s));
@@ -880,6 +939,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
                                 GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln_bf, 1, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
                            ws.ln_partial, M, D, eps, s));
+  if (forked) HIP_TRY(side_join(c));   // the layer's gradient slice is complete in the caller's stream order from here on
   return SF_OK;
 }
 

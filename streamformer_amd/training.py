@@ -114,6 +114,13 @@ class StreamformerTrainer:
         self.attention_dropout = float(getattr(config, "attention_probs_dropout_prob", 0.0) or 0.0)
         if not (0.0 <= self.hidden_dropout < 1.0 and 0.0 <= self.attention_dropout < 1.0):
             raise ValueError("dropout probabilities must be in [0, 1)")
+        if self.attention_dropout > 0.0:
+            # the masked variants exist for the DMA-staged attention kernels only (sf_train.hip: T <= 16, N <= 224 patches per frame);
+            # say so here, not as SF_ERR_INVALID at the first forward
+            n_patches = (config.image_size // config.patch_size) ** 2
+            if n_patches > 224 or config.num_frames > 16:
+                raise NotImplementedError(f"attention_probs_dropout_prob > 0 needs <= 224 patches per frame and <= 16 frames "
+                                          f"(this config: {n_patches} patches, {config.num_frames} frames)")
         self.dropout = True                         # False: forwards without dropout (evaluation through the trainer)
         self.last_dropout: Optional[Tuple[int, float, float]] = None    # (seed, hidden_p, attention_p) of the last forward, for replay in tests
         self.drop_path_rate = float(getattr(config, "drop_path_rate", 0.0) or 0.0)
@@ -188,6 +195,11 @@ class StreamformerTrainer:
         # kernel — {sticky flag, skipped steps}; the host looks at it only in check_finite() / at checkpoints
         self._guard = torch.zeros(2, dtype=torch.int32, device=dev) if nonfinite_guard else None
         self._last_loss: Optional[torch.Tensor] = None
+        # sum of the losses of the current accumulation window (update_freq > 1) — a non-finite micro-step loss stays visible to the
+        # guard of the optimizer step that closes the window; with world > 1 it is all-reduced next to the gradients so that every
+        # rank takes the same skip / step decision
+        self._loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._loss_acc_used = False
         self._wire: Optional[torch.Tensor] = None       # bf16 wire format of the gradient all-reduce (grad_reduce_dtype="bf16")
         self.step_count = 0
         self.micro = 0
@@ -385,10 +397,21 @@ class StreamformerTrainer:
                 return False
         return True
 
-    def checkpoint(self, epoch: int = 0, args=None) -> dict:
+    def _gather_stochastic_states(self) -> list:
+        """Every rank's generator state, in rank order (a collective when world > 1: call it on ALL ranks)."""
+        mine = self._dp_gen.get_state()
+        if self.world > 1 and torch.distributed.is_initialized():
+            states = [None] * self.world
+            torch.distributed.all_gather_object(states, mine, group=self.group)
+            return states
+        return [mine]
+
+    def checkpoint(self, epoch: int = 0, args=None, stochastic_states: Optional[list] = None) -> dict:
         """The dict the reference's ``save_model`` writes on rank 0: wrapper-keyed weights (``timesformer.*``,
-        ``task_heads.*``), optimizer state, epoch.  ``scaler`` is empty: bf16 operands need no loss scaling."""
-        self.check_finite()
+        ``task_heads.*``), optimizer state, epoch.  ``scaler`` is empty: bf16 operands need no loss scaling.
+        With world > 1 call :meth:`save_checkpoint` (every rank) rather than this method on rank 0 alone: the finite check and the
+        per-rank generator states are collectives."""
+        self.check_finite(collective=False)
         model = OrderedDict()
         model["logit_scale"] = torch.tensor(math.log(10.0))        # the wrapper's own pair (modeling:1363-1364): never trained,
         model["logit_bias"] = torch.tensor(-2.0)                   # kept so that the reference's load_state_dict finds its keys
@@ -396,13 +419,20 @@ class StreamformerTrainer:
             model[k if k.startswith("task_heads.") else "timesformer." + k] = v.detach().cpu()
         # "stochastic_state": this rank's generator of drop_path factors and dropout seeds, so that a resumed run continues the
         # sequence of masks instead of replaying it from the start; an extra key the reference's loader ignores
+        # per-rank states: the ranks draw from generators seeded seed * 1000003 + rank; a resume must hand every rank
+        # ITS state back, not rank 0's
+        states = stochastic_states if stochastic_states is not None else ([self._dp_gen.get_state()] if self.world == 1 else None)
         return {"model": model, "optimizer": self.optimizer_state_dict(), "epoch": int(epoch), "scaler": {}, "args": args,
-                "stochastic_state": self._dp_gen.get_state()}
+                "stochastic_state": states}
 
     def save_checkpoint(self, path: str, epoch: int = 0, args=None) -> None:
+        """Call on EVERY rank: the non-finite check raises on all of them together (a rank-0-only raise would leave the others
+        hanging in their next collective), the generator states are gathered, rank 0 writes."""
+        self.check_finite()
+        states = self._gather_stochastic_states()
         if self.rank == 0:
             tmp = path + ".tmp"
-            torch.save(self.checkpoint(epoch, args), tmp)
+            torch.save(self.checkpoint(epoch, args, stochastic_states=states), tmp)
             os.replace(tmp, path)
 
     def load_checkpoint(self, path_or_dict) -> int:
@@ -413,8 +443,13 @@ class StreamformerTrainer:
         self.load_state_dict(ck["model"])
         if ck.get("optimizer"):
             self.load_optimizer_state_dict(ck["optimizer"])
-        if ck.get("stochastic_state") is not None:
-            self._dp_gen.set_state(ck["stochastic_state"])
+        st = ck.get("stochastic_state")
+        if isinstance(st, (list, tuple)):
+            if len(st) == self.world:
+                self._dp_gen.set_state(st[self.rank])         # this rank's own sequence continues
+            # a file written at another world size: keep the generator this trainer was constructed with (seed * 1000003 + rank)
+        elif st is not None and self.world == 1:
+            self._dp_gen.set_state(st)                         # round-4 file: one state, meaningful for a one-rank run only
         self.micro = 0
         self.grads.zero_()
         self.sync_weights()
@@ -437,13 +472,31 @@ class StreamformerTrainer:
         """Optimizer steps the device-side guard has skipped so far (reads the flag: synchronises with the GPU)."""
         return 0 if self._guard is None else int(self._guard[1].item())
 
-    def check_finite(self) -> None:
-        """The reference stops the run when a loss is not finite (``tools/finetune_tools.py:533-541``: ``sys.exit(1)``) and its
+    def reset_nonfinite(self) -> int:
+        """Acknowledge skipped steps and continue: clears the sticky flag and takes the skipped steps back out of the host-side step
+        counts (the device skipped the update, the host had already counted it).  Returns the number of steps that had been skipped."""
+        n = self.nonfinite_steps()
+        if n:
+            self.step_count = max(0, self.step_count - n)
+            for t in self.head_steps:
+                self.head_steps[t] = max(0, self.head_steps[t] - n)
+            self._guard.zero_()
+        return n
+
+    def check_finite(self, collective: bool = True) -> None:
+        """With world > 1 every rank must call this at the same point (the flag is all-reduced first, so that all ranks raise together).
+        The reference stops the run when a loss is not finite (``tools/finetune_tools.py:533-541``: ``sys.exit(1)``) and its
         GradScaler skips a step with inf gradients (``utils.py:515-551``).  Here the optimizer kernel makes both checks on the
         device (the step is sync-free) and skips the update; this host-side read — call it wherever the loop already touches
         the host (logging, checkpoints; ``checkpoint()`` does) — raises once that has happened.  Weights and moments are
         those of the last finite step."""
         n = self.nonfinite_steps()
+        if collective and self._guard is not None and self._collectives and self.world > 1:
+            flag = torch.tensor([float(n)], dtype=torch.float32, device=self.device)
+            if torch.distributed.get_backend(self.group) != "nccl":
+                flag = flag.cpu()
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            n = int(flag.item())
         if n:
             raise FloatingPointError(f"loss or gradients were not finite in {n} optimizer step(s): those updates were skipped on the "
                                      "device; stopping as the reference does (tools/finetune_tools.py:533-541)")
@@ -542,9 +595,13 @@ class StreamformerTrainer:
                         works.append((torch.distributed.all_reduce(half, group=self.group, async_op=True), sl, half))
                     else:
                         works.append((torch.distributed.all_reduce(sl, group=self.group, async_op=True), None, None))
+            if reduce and self._loss_acc_used and self.world > 1:
+                # the window's loss sum rides along: every rank's guard sees the same (possibly non-finite) value
+                la = self._loss_acc if torch.distributed.get_backend(self.group) == "nccl" else self._loss_acc.cpu()
+                works.append((torch.distributed.all_reduce(la, group=self.group, async_op=True), self._loss_acc if la is not self._loss_acc else None, la))
         for w, sl, half in works:
             w.wait()
-            if half is not None:
+            if half is not None and sl is not None:
                 sl.copy_(half)
 
     def time_bucket_allreduce(self, iters: int = 3) -> float:
@@ -603,6 +660,9 @@ class StreamformerTrainer:
                             [gs[0], gs[1]], alpha=inv)
         self._touched.add(task)
         self._last_loss = loss
+        if update_freq > 1 or (self._collectives and self.world > 1):
+            torch.add(self._loss_acc, loss.reshape(1), out=self._loss_acc)       # inf / NaN survive the sum
+            self._loss_acc_used = True
         self.micro += 1
         last = self.micro % update_freq == 0
         self.backward(gp if update_freq == 1 else gp.mul_(inv), reduce=last)
@@ -637,7 +697,7 @@ class StreamformerTrainer:
             self._touched = set()
         with torch.cuda.device(self.device):
             if self._guard is not None:
-                ll = self._last_loss
+                ll = self._loss_acc if self._loss_acc_used else self._last_loss
                 nat.check(nat.lib.sf_trainer_set_nonfinite_guard(
                     self._h, self._guard.data_ptr(), ll.data_ptr() if (ll is not None and ll.dtype == torch.float32 and ll.is_cuda) else None))
             if clip_grad is not None:
@@ -648,9 +708,16 @@ class StreamformerTrainer:
                 self.step_count, self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
                 self.weight_decay if weight_decay is None else weight_decay, scale, sumsq,
                 float(clip_grad) if clip_grad is not None else 0.0, 1, self._stream()))
+        # the guard has read its loss: a later optimizer_step() without a micro_step() must not re-check a stale one
+        self._last_loss = None
+        if self._loss_acc_used:
+            self._loss_acc.zero_()
+            self._loss_acc_used = False
         self.sync_weights()
 
     def zero_grad(self) -> None:
         self.grads.zero_()
         self.micro = 0
         self._touched = set()
+        self._loss_acc.zero_()
+        self._loss_acc_used = False

@@ -797,6 +797,10 @@ def test_trainer_rejects_what_it_cannot_do():
     sd2.pop("head.probe")
     with pytest.raises(KeyError):
         StreamformerTrainer(cfg, sd2, ["retrieval"], device=dev)
+    # attention-probability dropout exists for <= 224 patches per frame and <= 16 frames: refused at construction
+    big = small_cfg(add_lora_spatial=True, image_size=256, attention_probs_dropout_prob=0.1)       # 16 x 16 = 256 patches
+    with pytest.raises(NotImplementedError):
+        StreamformerTrainer(big, make_state_dict(big, seed=8, lora=True), ["retrieval"], device=dev)
     # state_dict round trip keeps the reference key names and the head scalars
     out = tr.state_dict()
     assert {k for k in sd if not k.endswith(".mask")} <= set(out) and "task_heads.retrieval.logit_scale" in out   # masks: unused buffers
@@ -829,6 +833,21 @@ def test_nonfinite_step_is_skipped_on_the_device_and_reported():
         tr.check_finite()
     with pytest.raises(FloatingPointError):
         tr.checkpoint()
+    # acknowledging the skipped step takes it back out of the host-side counts, and an optimizer_step() with no
+    # micro_step() in between does not re-check the stale NaN loss
+    before, hb = tr.step_count, dict(tr.head_steps)
+    assert tr.reset_nonfinite() == 1 and tr.step_count == before - 1 and tr.nonfinite_steps() == 0
+    assert all(tr.head_steps[k] == max(0, hb[k] - 1) for k in hb)
+    tr.check_finite()
+    tr.optimizer_step()
+    assert tr.nonfinite_steps() == 0 and tr._last_loss is None
+    # a poisoned FIRST micro-step of an accumulation window is still seen by the step that closes the window
+    tr.zero_grad()
+    tr.micro_step(task, bad.to(dev), _to_dev(ti, dev), update_freq=2)
+    tr.grads.zero_()                                           # finite gradients, non-finite loss sum
+    tr.micro_step(task, x.to(dev), _to_dev(ti, dev), update_freq=2)
+    assert tr.nonfinite_steps() == 1
+    tr.reset_nonfinite()
     # inf gradients with a finite loss (the GradScaler case): poison the gradient buffer directly
     tr2, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True)
     tr2.forward(x.to(dev))
