@@ -375,6 +375,16 @@ def streaming_bench(dev):
                      "frac_of_hbm_peak": round(by / ms.value / 1e6 / PEAK_HBM_GBS, 4)}
     del ws
     del cache
+    # what a chain of dependent launches costs on this box when the kernels do nothing: the same number of EMPTY 256-workgroup
+    # kernels in one hipGraph: the floor a ~100-launch frame sits on, next to its 64 us of bytes at the HBM peak
+    floor = None
+    try:
+        us = nat.C.c_float()
+        nat.check(nat.lib.sf_bench_launch_floor(int(dev.index or 0), 104, 50, nat.current_stream_handle(dev), nat.C.byref(us)))
+        floor = {"us_per_launch": round(us.value, 3), "launches_per_frame": 104, "ms_per_frame_of_empty_launches": round(104 * us.value / 1e3, 4),
+                 "how": "104 dependent empty kernels (256 x 256 threads) in one hipGraph, 50 replays, HIP events (sf_bench_launch_floor)"}
+    except Exception as e:
+        floor = {"error": repr(e)}
     # the serving shape of the vision tower (vqa_enc:1494-1500: one cache per stream): 8 streams advance one frame per call
     S = 8
     xs = x.expand(S, -1, -1, -1, -1).contiguous()
@@ -400,7 +410,8 @@ def streaming_bench(dev):
                            "note": "fresh cache: frame 0 runs eagerly (lazy per-kernel set-up), frame 1 captures the one "
                                    "position-free hipGraph of the cache, every later frame replays it"},
             "config": "SigLIP-base, num_frames=64, B=1, one 224^2 frame per call, bf16 mode, KV-cache of 64 frames",
-            "roofline_streaming": {"bound": "hbm", "kernel": "sf_gemm_skinny_kg_kernel (N = 768 residual projections, 37 of 108 launches "
+            "launch_floor": floor,
+            "roofline_streaming": {"bound": "hbm", "kernel": "sf_gemm_skinny_kg_kernel (N = 768 residual projections, 36 of 104 launches "
                                    "per frame, ~32 % of its kernel time)", "launches": dom, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "whole_frame": {"achieved": round(gb / mean, 1), "frac": round(gb / mean / PEAK_HBM_GBS, 4)},
                                    "note": "a streamed frame is ~100 dependent launches of 4-10 us: latency-bound, not bandwidth-bound "

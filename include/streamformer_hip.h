@@ -324,6 +324,11 @@ int sf_bench_attention(sf_encoder* enc, int B, int T, int which, int iters, void
                        size_t workspace_bytes, sf_stream stream, float* mean_ms_out, double* bytes_out,
                        double* flops_out);
 
+/* Launch floor of this device: `launches` dependent EMPTY kernels (256 workgroups of 256 threads) captured into one hipGraph and
+ * replayed `iters` times; mean microseconds per launch.  What a chain of dependent launches costs when the kernels do nothing —
+ * the yardstick next to the streamed frame's ~100-launch graph (bench.py `streaming.launch_floor`).                              */
+int sf_bench_launch_floor(int device, int launches, int iters, sf_stream stream, float* us_per_launch_out);
+
 #ifdef __cplusplus
 }
 #endif

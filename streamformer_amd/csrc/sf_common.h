@@ -178,6 +178,8 @@ struct SfGemmArgs {
   const bf16_t* resid_lo2; bf16_t* out_lo2;
   const float* pos; const float* time_rows; // SF_EPI_EMBED_F32: [Np,N], [Tn,N]
   int Np, Tn;
+  const int* time_base_dev;                 // skinny kernel only: time row = (row / Np) % Tn + *time_base_dev, i.e. time_rows is the whole
+                                            // time-embedding table and the streamed frame's row comes from device memory (no gather launch)
   float* out_f32;                           // [*,ldc]
   bf16_t* out_hi; bf16_t* out_lo;           // [*,ldc]
   int ldc;                                  // output row pitch in elements
@@ -252,7 +254,8 @@ int sf_gemm_pipe_failed();                                                      
 // LayerNorm over D: x fp32 [rows,D] -> any of {y_f32, y_hi, y_lo} (nullptr = skip)
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
                                bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s, const bf16_t* xp_hi = nullptr,
-                               const bf16_t* xp_lo = nullptr, const bf16_t* xp_lo2 = nullptr);
+                               const bf16_t* xp_lo = nullptr, const bf16_t* xp_lo2 = nullptr, float* const* y_f32_ind = nullptr);
+                               // y_f32_ind: the fp32 destination is read from device memory (the streamed frame's caller tensor)
 // pixels [F,C,H,W] -> patch matrix [F*N, C*P*P] bf16 (+lo), columns (c,ph,pw).
 // pixel_kind 0 fp32, 1 bf16, 2 uint8 raw frames normalised on the fly: y = x * scale[c] + shift[c]
 struct SfPixelNorm { float scale[4]; float shift[4]; };
@@ -266,7 +269,10 @@ struct SfStreamParams { const void* pixels; float* lhs; float* pooler; int t_row
 hipError_t sf_launch_stream_params(SfStreamParams* dst, const SfStreamParams& v, hipStream_t s);
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
                               int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr,
-                              const SfStreamParams* sp = nullptr);     // sp != nullptr: pixels = sp->pixels (device read)
+                              const SfStreamParams* sp = nullptr,      // sp != nullptr: pixels = sp->pixels (device read)
+                              SfStreamParams* sp_write = nullptr, const SfStreamParams* sp_value = nullptr);
+                              // sp_write: the launch also stores *sp_value there (the streamed frame's parameter block rides on the
+                              // patch extraction instead of a launch of its own)
 // fp32 [n] -> bf16 hi (+lo)
 hipError_t sf_launch_split(const float* x, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s);
 // two fp32 copies in one launch (b may be null): the streaming path's hand-over of graph-owned outputs to the caller's tensors

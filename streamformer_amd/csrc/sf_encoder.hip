@@ -531,6 +531,7 @@ struct Workspace {
   void* qkv;          // spatial qkv; fast: bf16 [M,3D], accurate: fp32 [M,3D]
   void* tqkv;         // temporal qkv of the current layer when no cache is used
   float* attn_out;    // head: [F, D]
+  float *head_ctx, *head_mid;      // head tail on one to four rows (streamed frames): fp32 context [F, D] and MLP activation [F, I]
   float *pool_z, *pool_ml;         // head: weighted token sums [F, S, heads, D] and {max, sum} [F, S, heads, 2] per token split
   bf16_t *pc_hi, *pc_lo, *hn_hi, *hn_lo, *hm_hi, *hm_lo;
   float *lhs_stage, *pool_stage;   // streaming only: graph-owned outputs, copied to the caller's tensors after the replay
@@ -567,6 +568,8 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.qkv = c.take<char>(M * 3 * D * (acc ? 4 : 2));
   w.tqkv = need_tqkv ? (void*)c.take<char>(M * 3 * D * (acc ? 4 : 2)) : nullptr;
   w.attn_out = c.take<float>(F * D);
+  w.head_ctx = c.take<float>(F * D);
+  w.head_mid = c.take<float>(F * I);
   w.pool_z = c.take<float>(sf_pool_z_floats((int)F, N, e->cfg.num_attention_heads, (int)D));
   w.pool_ml = c.take<float>(sf_pool_ml_floats((int)F, N, e->cfg.num_attention_heads));
   w.pc_hi = c.take<bf16_t>(F * D);          // the pooling head's one-row-per-frame tensors keep hi + lo planes in both modes
@@ -681,6 +684,12 @@ static bool ln_fold_small_ok(const sf_encoder* e, int M) {
   return takes(g);                                            // ... and K = I
 }
 
+// the head's per-frame tail on one to four rows runs as row-vector launches (sf_launch_rowlin)
+static bool sf_head_rows_ok(const sf_encoder* e, int F) {
+  return e->head_out.w_lo && e->head_fc1.w_lo && e->head_fc2.w_lo && sf_rowlin_supported(F, e->D, e->D) && sf_rowlin_supported(F, e->I, e->D) &&
+         sf_rowlin_supported(F, e->D, e->I);
+}
+
 static int time_rows(const sf_encoder* e, int t_past, int T, bool streaming, SfRowIndex* idx) {
   const int nf = e->cfg.num_frames;
   if (T > 256) return set_err(SF_ERR_INVALID, "at most 256 frames per call (got %d)", T);
@@ -745,7 +754,17 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   int rc = time_rows(e, t_row, T, streaming, &idx);
   if (rc) return rc;
   if (sp) { for (int t = 0; t < T; ++t) idx.idx[t] = t; }
-  HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s, sp ? &sp->t_row : nullptr));
+  // streamed frame inside the position-free graph: the embedding GEMM reads its time-embedding row straight from the table
+  // (row index from the device block) when the skinny kernel takes the shape — no gather launch
+  bool time_folded = false;
+  if (sp && T == 1) {
+    SfGemmArgs gt;
+    memset(&gt, 0, sizeof(gt));
+    gt.a_hi = ws.xn_hi; gt.a_lo = acc ? ws.xn_lo : nullptr; gt.w_hi = e->patch.w_hi; gt.w_lo = acc ? e->patch.w_lo : nullptr;
+    gt.M = M; gt.N = D; gt.K = e->Kp; gt.ldc = D; gt.epi = SF_EPI_EMBED_F32; gt.out_f32 = ws.resid;
+    time_folded = sf_gemm_skinny_supported(gt, acc) && !ln_fold_ok(e, M);
+  }
+  if (!time_folded) HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s, sp ? &sp->t_row : nullptr));
   // LN folding (decided here because the folded path lets the embedding GEMM emit bf16(x) + row statistics itself:
   // panel kernel, out = table[m % (T N)] + patches W^T + b with table = pos + time rows)
   bool embed_panel = false;
@@ -779,6 +798,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     } else {
       g.epi = SF_EPI_EMBED_F32;
       g.pos = pos_dev ? pos_dev : e->pos; g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
+      if (time_folded) { g.time_rows = e->time_tab; g.time_base_dev = &sp->t_row; }
       if (ws.res_bf && ln_fold_small_ok(e, M) && (stages & 2)) g.out_hi = ws.res_bf;   // layer 0's folded qkv reads bf16(x)
       HIP_TRY(sf_launch_gemm(g, acc, s));
     }
@@ -907,7 +927,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // (the head reads the fp32 tokens: no bf16 copy of the normalised rows is written any more)
   if (stages & 4)       // pm: the rows arrive as the two planes of the residual stream
     HIP_TRY(sf_launch_layernorm(ws.resid, e->post_ln.g, e->post_ln.b, last_hidden, nullptr, nullptr, M, D, c.layer_norm_eps, s,
-                                rplanes ? ws.xn_hi : nullptr, plo, plo2));
+                                rplanes ? ws.xn_hi : nullptr, plo, plo2, sp ? &sp->lhs : nullptr));   // sp: straight into the caller's tensor
   // stage 8: the head alone on tokens the caller has already normalised (model.head(x)): they sit in ws.resid
   if (pooler) {
     // The probe attention without projecting the tokens (sf_pool_head.hip): scores = x . U, z_h = sum_n p_hn x_n on the fp32
@@ -917,14 +937,35 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       const float* tok = (stages & 4) ? last_hidden : ws.resid;
       SfPoolArgs pa;
       memset(&pa, 0, sizeof(pa));
-      pa.x = tok; pa.u_hi = e->head_u_hi; pa.u_lo = e->head_u_lo; pa.zpart = ws.pool_z; pa.ml = ws.pool_ml;
+      pa.x = tok; pa.x_ind = (sp && (stages & 4)) ? reinterpret_cast<const float* const*>(&sp->lhs) : nullptr;
+      pa.u_hi = e->head_u_hi; pa.u_lo = e->head_u_lo; pa.zpart = ws.pool_z; pa.ml = ws.pool_ml;
       pa.F = F; pa.N = N; pa.heads = heads; pa.D = D; pa.S = sf_pool_splits(F, N, heads); pa.normalize = pa.S == 1;
       HIP_TRY(sf_launch_pool_probe(pa, s));
       SfPoolCtxArgs ca;
       memset(&ca, 0, sizeof(ca));
       ca.zpart = ws.pool_z; ca.ml = ws.pool_ml; ca.wv = e->head_wv; ca.ldw = D; ca.bv = e->head_bv;
       ca.ctx_hi = ws.pc_hi; ca.ctx_lo = ws.pc_lo; ca.F = F; ca.heads = heads; ca.D = D; ca.S = pa.S;
+      const bool rows = sf_head_rows_ok(e, F);
+      if (rows) { ca.ctx_hi = ca.ctx_lo = nullptr; ca.ctx_f32 = ws.head_ctx; }
       HIP_TRY(sf_launch_pool_ctx(ca, s));
+      if (rows) {
+        // One to four rows (streamed frames): the per-frame tail as three row-vector launches with fp32 activations — out_proj,
+        // LayerNorm + fc1 + GELU, fc2 + residual (written straight into the caller's pooler_output inside the position-free graph)
+        SfRowLinArgs r;
+        memset(&r, 0, sizeof(r));
+        r.F = F; r.act = -1;
+        r.x = ws.head_ctx; r.ldx = D; r.K = D; r.N = D; r.w_hi = e->head_out.w_hi; r.w_lo = e->head_out.w_lo; r.bias = e->head_out.bias;
+        r.out = ws.attn_out; r.ldo = D;
+        HIP_TRY(sf_launch_rowlin(r, s));
+        r.x = ws.attn_out; r.ln_g = e->head_ln.g; r.ln_b = e->head_ln.b; r.ln_eps = c.layer_norm_eps; r.N = e->I; r.act = c.hidden_act;
+        r.w_hi = e->head_fc1.w_hi; r.w_lo = e->head_fc1.w_lo; r.bias = e->head_fc1.bias; r.out = ws.head_mid; r.ldo = e->I;
+        HIP_TRY(sf_launch_rowlin(r, s));
+        r.x = ws.head_mid; r.ldx = e->I; r.K = e->I; r.N = D; r.ln_g = r.ln_b = nullptr; r.act = -1;
+        r.w_hi = e->head_fc2.w_hi; r.w_lo = e->head_fc2.w_lo; r.bias = e->head_fc2.bias; r.resid = ws.attn_out; r.ldr = D;
+        r.out = pooler; r.ldo = D; r.out_ind = sp ? &sp->pooler : nullptr;
+        HIP_TRY(sf_launch_rowlin(r, s));
+        return SF_OK;
+      }
     }
     // one row per frame from here on (F rows: 0.03 % of the forward's FLOPs): three bf16 products per operand pair in BOTH modes —
     // pooler_output is the product both loss heads and the feature dumps consume, and the bf16 mode's own head added 1.5e-2 of
@@ -1205,7 +1246,8 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
     if (!g.exec) c->graphs.erase(key);
     return rc;
   }
-  // patch extraction reads the caller's frames: outside the per-position graphs, inside the position-free one (indirect pointer)
+  // patch extraction reads the caller's frames: outside the graphs.  For the position-free graph the same launch stores the call's
+  // parameter block {pixels, outputs, position} that the graph's kernels read (it used to be a launch of its own)
   if (!posfree)
     HIP_TRY(sf_launch_patchify(pixels, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm));
   if (!g.exec) {
@@ -1214,19 +1256,18 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
     HIP_TRY(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
     hipError_t pe = hipSuccess;
     if (posfree) {
-      // representative position of the class: selects the 64-key pass count; the kernels read the live one from dparams
+      // representative position of the class: selects the 64-key pass count; the kernels read the live one from dparams.
+      // The patch extraction stays OUTSIDE the graph (it also delivers the parameter block, below); last_hidden_state is written
+      // straight into the caller's tensor through the block, pooler_output too when the head's row-vector tail runs (<= 4 streams):
+      // no staging copy at the end of the graph.
       int rep_tk = kcls * 64;
       if (rep_tk > c->cap) rep_tk = c->cap;
       if (c->policy != 1 && rep_tk > nf) rep_tk = nf;
       const int rep3[3] = {0, 0, rep_tk};
-      pe = sf_launch_patchify(nullptr, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, c->cap_stream,
-                              &e->pixel_norm, c->dparams);
-      rc = pe != hipSuccess ? SF_ERR_HIP :
-           run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
+      rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
                        ws, c->qkv.data(), c->cap, 0, true, c->cap_stream, nullptr, 7, 0, -1, 1, c->dparams, rep3);
-      if (rc == SF_OK)
-        pe = sf_launch_copy2(ws.lhs_stage, nullptr, (size_t)M * e->D, pooler ? ws.pool_stage : nullptr, nullptr, (size_t)F * e->D,
-                             c->cap_stream, c->dparams);
+      if (rc == SF_OK && pooler && !sf_head_rows_ok(e, F))
+        pe = sf_launch_copy2(nullptr, nullptr, 0, ws.pool_stage, nullptr, (size_t)F * e->D, c->cap_stream, c->dparams);
     } else {
       rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, ws.lhs_stage, pooler ? ws.pool_stage : nullptr, nullptr, pos_dev,
                        ws, c->qkv.data(), c->cap, c->len, true, c->cap_stream, nullptr, 7, 0, -1, 1);
@@ -1249,7 +1290,8 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
   if (posfree) {
     SfStreamParams v;
     v.pixels = pixels; v.lhs = last_hidden; v.pooler = pooler; v.t_row = pos3[0]; v.slot = pos3[1]; v.tk = pos3[2];
-    HIP_TRY(sf_launch_stream_params(c->dparams, v, s));
+    HIP_TRY(sf_launch_patchify(pixels, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm, nullptr,
+                               c->dparams, &v));
     HIP_TRY(hipGraphLaunch(g.exec, s));
   } else {
     // (Launching the embedding + first layers eagerly to cover the replay's host-side submit time measured no gain: 0.78 vs 0.77 ms.)
@@ -1505,5 +1547,46 @@ extern "C" int sf_bench_attention(sf_encoder* e, int B, int T, int which, int it
     const double seqs = which == 0 ? (double)B * T : (double)B * N;
     *flops_out = seqs * heads * 2.0 * (2.0 * L * L * 64.0);
   }
+  return SF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch floor (bench hook): a graph of dependent empty kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sf_null_kernel(int* sink) {
+  if (sink && threadIdx.x == 1024) *sink = 0;     // never true: the kernel has no memory traffic
+}
+extern "C" int sf_bench_launch_floor(int device, int launches, int iters, sf_stream stream, float* us_per_launch_out) {
+  if (launches <= 0 || iters <= 0 || !us_per_launch_out) return set_err(SF_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  hipStream_t cap = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipError_t err = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (err == hipSuccess) {
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(sf_null_kernel, dim3(256), dim3(256), 0, cap, (int*)nullptr);
+    err = hipStreamEndCapture(cap, &graph);
+  }
+  if (err == hipSuccess) err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  float ms = 0.f;
+  if (err == hipSuccess) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipGraphLaunch(exec, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) (void)hipGraphLaunch(exec, s);
+    (void)hipEventRecord(e1, s);
+    err = hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipStreamDestroy(cap);
+  if (err != hipSuccess) return set_err(SF_ERR_HIP, "sf_bench_launch_floor: %s", hipGetErrorString(err));
+  *us_per_launch_out = 1e3f * ms / ((float)iters * (float)launches);
   return SF_OK;
 }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       if (!SPLIT && p.out_hi)    // small-M LayerNorm fold producer: bf16 copy of the new residual rows
         *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     } else if (EPI == SF_EPI_EMBED_F32) {
-      const int pn = m % p.Np, tt = (m / p.Np) % p.Tn;
+      const int pn = m % p.Np, tt = (m / p.Np) % p.Tn + (p.time_base_dev ? *p.time_base_dev : 0);
       const f32x4_t pe = *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)pn * p.N + n);
       const f32x4_t te = *reinterpret_cast<const f32x4_t*>(p.time_rows + (size_t)tt * p.N + n);
       v = v + pe + te;

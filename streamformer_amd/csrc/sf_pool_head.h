@@ -8,6 +8,7 @@ hipError_t sf_launch_pool_u(const float* wk, const float* q, float* u, bf16_t* u
 
 struct SfPoolArgs {
   const float* x;                          // [F * N, D] fp32: the normalised tokens (post_layernorm output)
+  const float* const* x_ind;               // optional: x is read from device memory (the streamed frame's caller tensor)
   const bf16_t* u_hi; const bf16_t* u_lo;  // [16, D]
   float* zpart;                            // [F, S, heads, D] weighted token sums of each split (normalised when S == 1)
   float* ml;                               // [F, S, heads, 2] {max score, sum of exp} per split (needed when S > 1)
@@ -28,6 +29,21 @@ struct SfPoolCtxArgs {
   int F, heads, D, S;
 };
 hipError_t sf_launch_pool_ctx(const SfPoolCtxArgs& a, hipStream_t s);
+
+// One-to-four-row Linear of the head's per-frame tail (a streamed frame: F = streams <= 4): y = act(LN?(x) W^T + b) (+ resid) with fp32
+// activations and hi + lo bf16 weights multiplied out in fp32 FMAs; one wave per output column, the whole K range in flight.
+struct SfRowLinArgs {
+  const float* x; int ldx;                 // [F, K] fp32
+  const float* ln_g; const float* ln_b; float ln_eps;      // optional: LayerNorm of the rows first
+  const bf16_t* w_hi; const bf16_t* w_lo;  // [N, K]
+  const float* bias;                       // [N] or null
+  const float* resid; int ldr;             // optional [F, N]
+  float* out; int ldo;                     // [F, N] fp32
+  float* const* out_ind;                   // optional: the destination is read from device memory (replaces out)
+  int F, N, K, act;                        // act: -1 none, else the hidden_act code (0 erf-gelu, 1 tanh-gelu, 2 relu)
+};
+bool sf_rowlin_supported(int F, int N, int K);
+hipError_t sf_launch_rowlin(const SfRowLinArgs& a, hipStream_t s);
 
 // backward of ctx = Wv z + bv: dz [F, heads, D]; dwv / dbv accumulate (+=), either may be null.  wT = transposed bf16 working copy
 // [D][ldt] whose value columns start at col0

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void sf_pool_probe_kernel(SfPoolArgs p) {
   const int nt = n1 > n0 ? n1 - n0 : 0;
   const int nch = (nt + PCH - 1) / PCH;
   const bool own = tid * 4 < D;                     // this thread owns columns 4 tid .. 4 tid + 3 of every token row
-  const float* xcol = p.x + ((size_t)f * p.N + n0) * D + (own ? tid * 4 : 0);
+  const float* xcol = (p.x_ind ? *p.x_ind : p.x) + ((size_t)f * p.N + n0) * D + (own ? tid * 4 : 0);
 
   if (tid < 96) st[tid] = (tid % 48) < 16 ? -INFINITY : 0.f;
   {   // U planes -> LDS, 16 bytes per access; all loads first (a fixed trip count; an index past the end repeats the last element)
@@ -428,6 +428,110 @@ hipError_t sf_launch_pool_ctx(const SfPoolCtxArgs& a, hipStream_t s) {
   else if (a.heads <= 12) SF_CTX_CASE(6)
   else SF_CTX_CASE(8)
 #undef SF_CTX_CASE
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// head tail for one to four rows (the streamed frame): y[f][n] = act(sum_k LN?(x)[f][k] (w_hi + w_lo)[n][k] + b[n]) (+ resid[f][n])
+// 4 waves per workgroup, a wave per output column at a time; a lane holds 8 consecutive k per 512-wide pass, KI passes (all
+// loads of a column issued before its arithmetic); rows of x in LDS as fp32.
+// ------------------------------------------------------------------------------------------------
+template <int KI, int FR>
+__global__ __launch_bounds__(256) void sf_rowlin_kernel(SfRowLinArgs p, int cpw) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];          // [FR][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K;
+  for (int i = tid; i < FR * (K >> 2); i += 256) {
+    const int f = i / (K >> 2), c4 = i - f * (K >> 2);
+    const int fr = f < p.F ? f : p.F - 1;
+    *reinterpret_cast<f32x4_t*>(xs + f * K + c4 * 4) = *reinterpret_cast<const f32x4_t*>(p.x + (size_t)fr * p.ldx + c4 * 4);
+  }
+  __syncthreads();
+  if (p.ln_g) {                      // LayerNorm of the rows, in place (wave f normalises row f; two-pass statistics)
+    if (wave < FR) {
+      float* r = xs + wave * K;
+      float s1 = 0.f;
+      for (int k = lane; k < K; k += 64) s1 += r[k];
+      const float mean = wave_sum_dpp(s1) / (float)K;
+      float s2 = 0.f;
+      for (int k = lane; k < K; k += 64) { const float d = r[k] - mean; s2 += d * d; }
+      const float rstd = rsqrtf(wave_sum_dpp(s2) / (float)K + p.ln_eps);
+      for (int k = lane; k < K; k += 64) r[k] = (r[k] - mean) * rstd * p.ln_g[k] + p.ln_b[k];
+    }
+    __syncthreads();
+  }
+  const int n_base = (blockIdx.x * 4 + wave) * cpw;
+  for (int ci = 0; ci < cpw; ++ci) {
+    const int n = n_base + ci;
+    if (n >= p.N) break;
+    u32x4_t wh[KI], wl[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k = i * 512 + lane * 8;
+      const int kc = k + 8 <= K ? k : K - 8;            // past the end: a valid address, the products are masked below
+      wh[i] = *reinterpret_cast<const u32x4_t*>(p.w_hi + (size_t)n * K + kc);
+      wl[i] = *reinterpret_cast<const u32x4_t*>(p.w_lo + (size_t)n * K + kc);
+    }
+    float acc[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k = i * 512 + lane * 8;
+      const bool ok = k + 8 <= K;
+      const int kc = ok ? k : K - 8;
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = ok ? 1.f : 0.f;
+        w[2 * j] = (bf2f(wh[i][j] & 0xffffu) + bf2f(wl[i][j] & 0xffffu)) * m;
+        w[2 * j + 1] = (bf2f(wh[i][j] >> 16) + bf2f(wl[i][j] >> 16)) * m;
+      }
+#pragma unroll
+      for (int f = 0; f < FR; ++f) {
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(xs + f * K + kc), x1 = *reinterpret_cast<const f32x4_t*>(xs + f * K + kc + 4);
+        acc[f] = fmaf(w[0], x0[0], acc[f]); acc[f] = fmaf(w[1], x0[1], acc[f]); acc[f] = fmaf(w[2], x0[2], acc[f]); acc[f] = fmaf(w[3], x0[3], acc[f]);
+        acc[f] = fmaf(w[4], x1[0], acc[f]); acc[f] = fmaf(w[5], x1[1], acc[f]); acc[f] = fmaf(w[6], x1[2], acc[f]); acc[f] = fmaf(w[7], x1[3], acc[f]);
+      }
+    }
+    float* out = p.out_ind ? *p.out_ind : p.out;
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      float v = wave_sum_dpp(acc[f]);
+      if (lane == 0 && f < p.F) {
+        if (p.bias) v += p.bias[n];
+        if (p.act >= 0) v = apply_act(v, p.act);
+        if (p.resid) v += p.resid[(size_t)f * p.ldr + n];
+        out[(size_t)f * p.ldo + n] = v;
+      }
+    }
+  }
+}
+bool sf_rowlin_supported(int F, int N, int K) {
+  return F >= 1 && F <= 4 && N >= 1 && K >= 8 && K % 8 == 0 && K <= 4096 && (size_t)4 * K * sizeof(float) <= 64 * 1024;
+}
+hipError_t sf_launch_rowlin(const SfRowLinArgs& a, hipStream_t s) {
+  if (!sf_rowlin_supported(a.F, a.N, a.K) || (a.ldx % 4) || !a.w_lo) return hipErrorInvalidValue;
+  const int ki = (a.K + 511) / 512;
+  const int fr = a.F <= 1 ? 1 : (a.F <= 2 ? 2 : 4);
+  int cpw = (a.N + 1023) / 1024;                      // ~256 workgroups of four columns at a time
+  const dim3 grid((a.N + 4 * cpw - 1) / (4 * cpw));
+  const size_t lds = (size_t)fr * a.K * sizeof(float);
+#define SF_RL(KI, FR)                                                                                                         \
+  {                                                                                                                           \
+    static SfPerDeviceOnce once;                                                                                              \
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_rowlin_kernel<KI, FR>),                     \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);                       \
+    hipLaunchKernelGGL((sf_rowlin_kernel<KI, FR>), grid, dim3(256), lds, s, a, cpw);                                          \
+  }
+#define SF_RL_F(KI) { if (fr == 1) SF_RL(KI, 1) else if (fr == 2) SF_RL(KI, 2) else SF_RL(KI, 4) }
+  if (ki <= 1) SF_RL_F(1)
+  else if (ki <= 2) SF_RL_F(2)
+  else if (ki <= 4) SF_RL_F(4)
+  else if (ki <= 6) SF_RL_F(6)
+  else SF_RL_F(8)
+#undef SF_RL_F
+#undef SF_RL
   return hipGetLastError();
 }
 

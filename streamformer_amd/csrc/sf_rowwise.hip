@@ -14,10 +14,12 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
                                                            float* __restrict__ y_f32,
                                                            bf16_t* __restrict__ y_hi,
                                                            bf16_t* __restrict__ y_lo, int rows, int D,
-                                                           float eps, const bf16_t* xp_hi, const bf16_t* xp_lo, const bf16_t* xp_lo2) {
+                                                           float eps, const bf16_t* xp_hi, const bf16_t* xp_lo, const bf16_t* xp_lo2,
+                                                           float* const* __restrict__ y_f32_ind) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (y_f32_ind) y_f32 = *y_f32_ind;
   const int nv = D >> 2;                       // float4 per row
   const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + (size_t)row * D);
   // xp_hi / xp_lo: the row arrives as hi + lo bf16 planes (residual stream of the BASELINE-sized bf16 forward) instead of x;
@@ -85,15 +87,15 @@ __global__ __launch_bounds__(256) void sf_layernorm_kernel(const float* __restri
 
 hipError_t sf_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y_f32,
                                bf16_t* y_hi, bf16_t* y_lo, int rows, int D, float eps, hipStream_t s, const bf16_t* xp_hi,
-                               const bf16_t* xp_lo, const bf16_t* xp_lo2) {
+                               const bf16_t* xp_lo, const bf16_t* xp_lo2, float* const* y_f32_ind) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > 64 * 4 * 16) return hipErrorInvalidValue;
   const dim3 grid((rows + 3) / 4), block(256);
   const int nv = (D / 4 + 63) / 64;
-  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
-  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
-  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
-  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2);
+  if (nv <= 1) hipLaunchKernelGGL(sf_layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2, y_f32_ind);
+  else if (nv <= 3) hipLaunchKernelGGL(sf_layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2, y_f32_ind);
+  else if (nv <= 8) hipLaunchKernelGGL(sf_layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2, y_f32_ind);
+  else hipLaunchKernelGGL(sf_layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y_f32, y_hi, y_lo, rows, D, eps, xp_hi, xp_lo, xp_lo2, y_f32_ind);
   return hipGetLastError();
 }
 
@@ -109,8 +111,10 @@ __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict
                                                           bf16_t* __restrict__ out_hi,
                                                           bf16_t* __restrict__ out_lo, int F, int C, int H,
                                                           int W, int P, int gh, int gw, SfPixelNorm norm,
-                                                          const SfStreamParams* __restrict__ sp) {
+                                                          const SfStreamParams* __restrict__ sp, SfStreamParams* sp_write,
+                                                          SfStreamParams sp_value) {
   if (sp) pixels = sp->pixels;
+  if (sp_write && blockIdx.x == 0 && threadIdx.x == 0) *sp_write = sp_value;
   const int Kp = C * P * P;
   const int chunks_per_row = Kp >> 3;
   const size_t total = (size_t)F * gh * gw * chunks_per_row;
@@ -152,8 +156,11 @@ __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict
 }
 
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
-                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* pnorm, const SfStreamParams* sp) {
+                              int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* pnorm, const SfStreamParams* sp,
+                              SfStreamParams* sp_write, const SfStreamParams* sp_value) {
   if (P % 8 || (pixel_kind == 2 && (W % 8 || C > 4))) return hipErrorInvalidValue;
+  SfStreamParams spv = {};
+  if (sp_write) { if (!sp_value) return hipErrorInvalidValue; spv = *sp_value; }
   SfPixelNorm norm;
   for (int i = 0; i < 4; ++i) { norm.scale[i] = 1.0f / 127.5f; norm.shift[i] = -1.0f; }    // mean = std = 0.5, rescale 1/255
   if (pnorm) norm = *pnorm;
@@ -162,11 +169,11 @@ hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi
   if (!total) return hipSuccess;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (pixel_kind == 2)
-    hipLaunchKernelGGL(sf_patchify_kernel<2>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp);
+    hipLaunchKernelGGL(sf_patchify_kernel<2>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp, sp_write, spv);
   else if (pixel_kind == 1)
-    hipLaunchKernelGGL(sf_patchify_kernel<1>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp);
+    hipLaunchKernelGGL(sf_patchify_kernel<1>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp, sp_write, spv);
   else
-    hipLaunchKernelGGL(sf_patchify_kernel<0>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp);
+    hipLaunchKernelGGL(sf_patchify_kernel<0>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, norm, sp, sp_write, spv);
   return hipGetLastError();
 }
 
