@@ -324,6 +324,12 @@ int sf_bench_attention(sf_encoder* enc, int B, int T, int which, int iters, void
                        size_t workspace_bytes, sf_stream stream, float* mean_ms_out, double* bytes_out,
                        double* flops_out);
 
+/* Environment switches (A/B and tuning knobs of the measurements; csrc/sf_switches.h holds the one table): the library reads them
+ * once, at first use.  sf_reload_switches() re-reads the environment (tests flip a switch inside a process);
+ * sf_switch_info(i, 0) / (i, 1) return name / description of switch i, NULL past the end.                                      */
+void sf_reload_switches(void);
+const char* sf_switch_info(int index, int what);
+
 /* Launch floor of this device: `launches` dependent EMPTY kernels (256 workgroups of 256 threads) captured into one hipGraph and
  * replayed `iters` times; mean microseconds per launch.  What a chain of dependent launches costs when the kernels do nothing —
  * the yardstick next to the streamed frame's ~100-launch graph (bench.py `streaming.launch_floor`).                              */

@@ -92,6 +92,8 @@ SIGNATURES = {
     "sf_op_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     "sf_op_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sf_op_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "sf_reload_switches": (None, []),
+    "sf_switch_info": (C.c_char_p, [_I, _I]),
     "sf_bench_launch_floor": (_I, [_I, _I, _I, _P, C.POINTER(_F)]),
     "sf_bench_gemm": (_I, [_P, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double)]),
     "sf_bench_attention": (_I, [_P, _I, _I, _I, _I, _P, _SZ, _P, C.POINTER(_F), C.POINTER(C.c_double),

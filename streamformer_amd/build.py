@@ -16,10 +16,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamformer_hip.so")
-SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_pool_head.hip", "sf_loss.hip", "sf_encoder.hip",
+SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_switches.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_pool_head.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
 # lab library only (build.py --lab): round-4 kernels that were built to parity and did not beat the product path on the wall clock —
-# the two epilogue-overlap variants of the panel kernel, and the qkv projection with the temporal attention as its epilogue
+# the two epilogue-overlap variants of the panel kernel, and the qkv projection with the temporal attention as its epilogue.
+# They live in tools/lab/ (not in the package) and are never part of libstreamformer_hip.so.
+LAB_DIR = os.path.join(os.path.dirname(HERE), "tools", "lab")
 LAB_SOURCES = ["sf_gemm_pp.hip", "sf_gemm_pipe.hip", "sf_gemm_qkv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -44,15 +46,17 @@ def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build_lab" if lab else "build")
     lib_path = os.path.join(HERE, "libstreamformer_hip_lab.so") if lab else LIB
-    flags = FLAGS + (["-DSF_LAB"] if lab else [])
+    flags = FLAGS + (["-DSF_LAB", "-I" + CSRC] if lab else [])
     sources = SOURCES + (LAB_SOURCES if lab else [])
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "sf_train.h"), os.path.join(CSRC, "sf_internal.h"), os.path.join(CSRC, "sf_pool_head.h"),
+    if lab and not os.path.isdir(LAB_DIR):
+        raise RuntimeError("the lab kernels (tools/lab/) are not present in this checkout")
+    headers = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "sf_train.h"), os.path.join(CSRC, "sf_internal.h"), os.path.join(CSRC, "sf_pool_head.h"), os.path.join(CSRC, "sf_switches.h"),
                os.path.join(os.path.dirname(HERE), "include", "streamformer_hip.h")]
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        srcp = os.path.join(CSRC, src)
+        srcp = os.path.join(LAB_DIR if src in LAB_SOURCES else CSRC, src)
         if force or _stale(obj, [srcp] + headers):
             cmd = [hipcc, *flags, "-c", srcp, "-o", obj]
             if verbose:

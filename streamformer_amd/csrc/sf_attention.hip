@@ -14,6 +14,7 @@
 // ACC = the fp32-accurate mode: fp32 inputs are split into bf16 hi+lo and every product becomes
 // hi*hi + hi*lo + lo*hi (same three-term scheme as the GEMM).
 #include "sf_common.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 #define HD 64  // head_dim supported by these kernels (SigLIP-base/large: 64)
@@ -580,222 +581,8 @@ __global__ __launch_bounds__(SP_WAVES * 64) void sf_spatial_attn_dma_kernel(SfAt
 // wave has finished reading image i & 1 before the pieces of problem i + 2 may overwrite it.
 // bf16 mode, N <= 224, no probabilities; the tile arithmetic is the one of sf_spatial_attn_dma_kernel.
 // ================================================================================================
-#ifdef SF_LAB      // measured slower than the two-workgroups-per-CU kernel above (profiles/r04_spatial_pers_lab.txt): lab library only
-#define SPP_WAVES 8
-#define SPP_QT 2       // query tiles per wave (16 x 8 x 2 = 256 >= 224 queries)
-template <int MAXNT>
-__global__ __launch_bounds__(SPP_WAVES * 64) void sf_spatial_attn_pers_kernel(SfAttnArgs p, int nprob) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, g = lane >> 4;
-  const int N = p.N;
-  const int nkp = (N + 31) & ~31;
-  const int nt = nkp >> 4;
-  const int nqt = (N + 15) >> 4;
-  const int img_bytes = nkp * 256;                         // K image + V image of one problem
-  char* o_st = smem + 2 * img_bytes + wave * 2048;         // per-wave [16 rows][128 B]
-  const int nrg = nkp >> 3;                                // 8-row groups = DMA pieces per image (<= 28)
-  const int my_pieces = (nrg - wave + SPP_WAVES - 1) / SPP_WAVES;
-
-  // K / V pieces of a problem by LDS-DMA + this wave's Q fragments into registers (tiles past the last one load a clamped
-  // row: every wave then has the same number of loads per problem in its vmcnt queue)
-  auto issue = [&](int prob, int buf, bf16x8_t (&q)[SPP_QT][2]) {
-    const int frame = prob / p.heads, h = prob % p.heads;
-    const size_t row0 = (size_t)frame * N;
-    const bf16_t* kbase = reinterpret_cast<const bf16_t*>(p.k) + h * HD;
-    const bf16_t* vbase = reinterpret_cast<const bf16_t*>(p.v) + h * HD;
-    char* k_img = smem + buf * img_bytes;
-    char* v_img = k_img + nkp * 128;
-    for (int j = wave; j < nrg; j += SPP_WAVES) {
-      const int row = j * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ sp_bswz(row);
-      const int key = row < N ? row : N - 1;
-      const size_t src = (row0 + key) * (size_t)p.row_pitch_kv + chunk * 8;
-      __builtin_amdgcn_global_load_lds((sp_gptr_t)(kbase + src), (sp_lptr_t)(k_img + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((sp_gptr_t)(vbase + src), (sp_lptr_t)(v_img + j * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < SPP_QT; ++u) {
-      int qi = (wave + u * SPP_WAVES) * 16 + l15;
-      qi = qi < N ? qi : N - 1;
-      // inline asm: hipcc's own vmcnt bookkeeping drains the counter (vmcnt(0)) as soon as a tracked load result is needed
-      // while stores are pending, which would wait for the NEXT problem's pieces; the counted waits in trip() cover these
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (row0 + qi) * p.row_pitch_q + h * HD + ks * 32 + g * 8;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[u][ks]) : "v"(qp) : "memory");
-      }
-    }
-  };
-
-  // V^T fragment of keys r0 .. r0 + 31, head-dim tile et, by two transposed reads — inline asm: hipcc puts `s_waitcnt vmcnt(0)` in
-  // front of every ds_read_b64_tr_b16 it can see while an LDS-DMA of the wave is outstanding, here the next problem's
-  auto tr_issue = [&](const char* img, int r0, int et, s16x4_t& lo, s16x4_t& hi) {
-    const int t16 = lane & 15;
-    const int row = r0 + 4 * g + (t16 >> 2);
-    const unsigned off = (unsigned)(size_t)(img - smem) + sp_img_off(row, 2 * et + ((t16 & 3) >> 1)) + ((t16 & 1) << 3);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(off) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(off) : "memory");
-  };
-
-  const float c2 = p.scale * 1.44269504088896340736f;
-  auto compute = [&](int prob, int buf, const bf16x8_t (&qh)[SPP_QT][2]) {
-    const int frame = prob / p.heads, h = prob % p.heads;
-    const size_t row0 = (size_t)frame * N;
-    const char* k_img = smem + buf * img_bytes;
-    const char* v_img = k_img + nkp * 128;
-#pragma unroll
-    for (int u = 0; u < SPP_QT; ++u) {
-      const int qt = wave + u * SPP_WAVES;
-      if (qt >= nqt) continue;
-      f32x4_t s[MAXNT];
-#pragma unroll
-      for (int jt = 0; jt < MAXNT; ++jt) {
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        if (jt * 16 < N) {
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) acc = mfma16(sp_row_frag(k_img, jt * 16 + l15, ks * 4 + g), qh[u][ks], acc);
-        }
-        s[jt] = acc;
-      }
-      __builtin_amdgcn_sched_barrier(0);      // row maximum in a second pass over the finished tiles (see the kernel above)
-      float mx = -INFINITY;
-#pragma unroll
-      for (int jt = 0; jt < MAXNT; ++jt) {
-        if (jt * 16 < N) {
-          if (jt * 16 + 16 > N) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (jt * 16 + 4 * g + r >= N) s[jt][r] = -INFINITY;
-          }
-          mx = fmaxf(mx, fmaxf(fmaxf(s[jt][0], s[jt][1]), fmaxf(s[jt][2], s[jt][3])));
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mc = mx * c2;
-      float sum = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < MAXNT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = 0.f;
-          if (jt * 16 < N) e = __builtin_amdgcn_exp2f(fmaf(s[jt][r], c2, -mc));
-          s[jt][r] = e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-      if (p.lse2_out && g == 0) {
-        const int qi = qt * 16 + l15;
-        if (qi < N) p.lse2_out[((size_t)frame * p.heads + h) * N + qi] = mc + __log2f(sum);
-      }
-      f32x4_t o[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      // two fragment sets: the eight transposed reads of key pair j2 + 1 are issued before the MFMAs of pair j2 (LDS returns in
-      // order: lgkmcnt(8) = everything but the youngest eight reads has returned)
-      s16x4_t va[4][2], vb[4][2];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) tr_issue(v_img, 0, dt, va[dt][0], va[dt][1]);
-#pragma unroll
-      for (int j2 = 0; j2 < MAXNT / 2; ++j2) {
-        if (2 * j2 < nt) {
-          s16x4_t (&vc)[4][2] = (j2 & 1) ? vb : va;
-          s16x4_t (&vn)[4][2] = (j2 & 1) ? va : vb;
-          const bool more = 2 * (j2 + 1) < nt && j2 + 1 < MAXNT / 2;
-          if (more) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) tr_issue(v_img, (j2 + 1) * 32, dt, vn[dt][0], vn[dt][1]);
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vc[0][0]), "+v"(vc[0][1]), "+v"(vc[1][0]), "+v"(vc[1][1]), "+v"(vc[2][0]), "+v"(vc[2][1]), "+v"(vc[3][0]), "+v"(vc[3][1])::"memory");
-          } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vc[0][0]), "+v"(vc[0][1]), "+v"(vc[1][0]), "+v"(vc[1][1]), "+v"(vc[2][0]), "+v"(vc[2][1]), "+v"(vc[3][0]), "+v"(vc[3][1])::"memory");
-          }
-          const u32x4_t pu = {pack_bf2(s[2 * j2][0], s[2 * j2][1]), pack_bf2(s[2 * j2][2], s[2 * j2][3]),
-                              pack_bf2(s[2 * j2 + 1][0], s[2 * j2 + 1][1]), pack_bf2(s[2 * j2 + 1][2], s[2 * j2 + 1][3])};
-          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pu);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            bf16x8_t f;
-            f[0] = vc[dt][0][0]; f[1] = vc[dt][0][1]; f[2] = vc[dt][0][2]; f[3] = vc[dt][0][3];
-            f[4] = vc[dt][1][0]; f[5] = vc[dt][1][1]; f[6] = vc[dt][1][2]; f[7] = vc[dt][1][3];
-            o[dt] = mfma16(f, pf, o[dt]);
-          }
-        }
-      }
-      // context rows through the per-wave patch (inline-asm LDS accesses: they share the lgkmcnt counter with the asm reads
-      // above, which the compiler cannot count): write, wait, read, wait
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const unsigned off = (unsigned)(size_t)(o_st - smem) + l15 * 128 + (((dt * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8;
-        const f32x4_t ov = o[dt] * inv;
-        const u32x2_t hv = {pack_bf2(ov[0], ov[1]), pack_bf2(ov[2], ov[3])};
-        asm volatile("ds_write_b64 %0, %1" ::"v"(off), "v"(hv) : "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      u32x4_t rows[2];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = it * 64 + lane;
-        const int r = idx >> 3, c = idx & 7;
-        const unsigned off = (unsigned)(size_t)(o_st - smem) + r * 128 + ((c ^ (r & 7)) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(rows[it]) : "v"(off) : "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rows[0]), "+v"(rows[1])::"memory");
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = it * 64 + lane;
-        const int r = idx >> 3, c = idx & 7;
-        const int qi = qt * 16 + r;
-        if (qi < N) {
-          const size_t oo = (row0 + qi) * p.D + h * HD + c * 8;
-          *reinterpret_cast<u32x4_t*>(p.ctx_hi + oo) = rows[it];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  };
-
-  bf16x8_t q0[SPP_QT][2], q1[SPP_QT][2];
-  int prob = blockIdx.x;
-  if (prob >= nprob) return;
-  issue(prob, 0, q0);
-  // problem i computes from image i & 1 with q0 (even i) / q1 (odd i): two problems per trip keep the register sets static
-  auto trip = [&](int buf, bf16x8_t (&qc)[SPP_QT][2], bf16x8_t (&qn)[SPP_QT][2]) {
-    const int next = prob + (int)gridDim.x;
-    const bool more = next < nprob;
-    if (more) issue(next, buf ^ 1, qn);
-    // problem i landed: loads return in order, and the only ones this wave issued after it are the next problem's pieces
-    // (2 per 8-row group) and Q fragments (4); the context stores of problem i - 1 are older and only make the wait conservative
-    if (more) {
-      if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("" : "+v"(qc[0][0]), "+v"(qc[0][1]), "+v"(qc[1][0]), "+v"(qc[1][1]));
-    // bare s_barrier (a __syncthreads() carries a workgroup fence that drains vmcnt, i.e. waits for the NEXT problem's pieces too);
-    // LDS ordering: the pieces are in LDS once the issuing wave's counted wait has passed, ds_reads follow the barrier in program order
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();        // A: every wave's pieces of this problem are in LDS
-    asm volatile("" ::: "memory");
-    compute(prob, buf, qc);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();        // B: nobody reads this image pair any more
-    asm volatile("" ::: "memory");
-    prob = next;
-    return more;
-  };
-  for (;;) {
-    if (!trip(0, q0, q1)) break;
-    if (!trip(1, q1, q0)) break;
-  }
-}
-
+#ifdef SF_LAB      // measured slower than the two-workgroups-per-CU kernel above (profiles/r04_spatial_pers_lab.txt): lab library only, source in tools/lab/
+#include "../../tools/lab/sf_spatial_pers.inc"
 #endif   // SF_LAB
 
 // ================================================================================================
@@ -1039,13 +826,13 @@ static int vt_pitch(int nkp) {
 
 // accurate mode: may the caller hand q / k / v as hi + lo bf16 planes (DMA kernel) instead of fp32?
 bool sf_spatial_planes_ok(int N, bool probs) {
-  const bool off = getenv("SF_DISABLE_SPATIAL_DMA_ACC") != nullptr;
+  const bool off = sf_sw(SW_DISABLE_SPATIAL_DMA_ACC) != nullptr;
   return !off && !probs && N > 0 && ((N + 31) & ~31) <= 32 * 7;
 }
 
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
-  if (a.drop.on && (accurate || a.probs || a.N > 224 || getenv("SF_DISABLE_SPATIAL_DMA") || (a.row_pitch_kv % 8))) return hipErrorInvalidValue;   // dropout: DMA kernel only
+  if (a.drop.on && (accurate || a.probs || a.N > 224 || sf_sw(SW_DISABLE_SPATIAL_DMA) || (a.row_pitch_kv % 8))) return hipErrorInvalidValue;   // dropout: DMA kernel only
   const int nkp = (a.N + 31) & ~31;
   if (nkp > 32 * 7) {                               // more than 224 tokens per frame: streaming-key kernel
     const int qblocks = (a.N + 127) / 128;
@@ -1068,7 +855,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
     if (fh <= 32) qsplit = (nqt + 1) / 2;           // two query tiles per workgroup: 84 workgroups for one 196-patch frame
     else if (fh <= 64) qsplit = (nqt + 3) / 4;
     else if (fh <= 128) qsplit = (nqt + 7) / 8;
-    static const char* env = getenv("SF_SPATIAL_TPW");   // tuning: query tiles per workgroup
+    const char* env = sf_sw(SW_SPATIAL_TPW);   // tuning: query tiles per workgroup
     if (env) qsplit = (nqt + atoi(env) - 1) / atoi(env);
     if (qsplit < 1) qsplit = 1;
   }
@@ -1078,7 +865,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_kernel<true, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  static const bool dma_off = getenv("SF_DISABLE_SPATIAL_DMA") != nullptr;
+  const bool dma_off = sf_sw(SW_DISABLE_SPATIAL_DMA) != nullptr;
   static SfPerDeviceOnce attr2;
   if (attr2.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_dma_kernel<14, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1087,7 +874,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (!accurate && !a.probs && !dma_off && (a.row_pitch_kv % 8) == 0) {
 #ifdef SF_LAB
     // many (frame, head) problems: the persistent double-buffered kernel (>= 4 problems per CU, so that the pipeline has something to overlap)
-    static const bool pers_off = getenv("SF_SPATIAL_PERS") == nullptr;
+    const bool pers_off = sf_sw(SW_SPATIAL_PERS) == nullptr;
     static int cus = 0;
     if (!cus) {
       int dev = 0;
@@ -1111,7 +898,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
       hipLaunchKernelGGL((sf_spatial_attn_dma_kernel<14, false, true>), grid, block, lds2, s, a, qsplit);
       return hipGetLastError();
     }
-    static const bool ntc_off = getenv("SF_DISABLE_SPATIAL_NTC") != nullptr;      // A/B switch
+    const bool ntc_off = sf_sw(SW_DISABLE_SPATIAL_NTC) != nullptr;      // A/B switch
     if (!ntc_off && ((a.N + 15) >> 4) == 13) {       // 193 .. 208 tokens per frame (224^2 inputs): the tile count as a compile-time constant
       static SfPerDeviceOnce attr5;
       if (attr5.first())
@@ -1125,7 +912,7 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
   if (accurate && !a.in_is_f32) {       // hi + lo bf16 planes (sf_spatial_planes_ok): the DMA kernel with three products
     if (a.probs || a.lo_plane_off <= 0 || (a.row_pitch_kv % 8) || (a.lo_plane_off % 8)) return hipErrorInvalidValue;
     const size_t lds2 = (size_t)nkp * 512 + SP_WAVES * 4096;
-    static const bool ntc_acc_off = getenv("SF_DISABLE_SPATIAL_NTC") != nullptr;      // A/B switch (shared with the bf16 instance)
+    const bool ntc_acc_off = sf_sw(SW_DISABLE_SPATIAL_NTC) != nullptr;      // A/B switch (shared with the bf16 instance)
     if (!ntc_acc_off && ((a.N + 15) >> 4) == 13) {       // compile-time tile count: 129.9 -> 118.2 us per launch, bit-identical (profiles/r04_spatial_ntc_acc_ab.txt)
       static SfPerDeviceOnce attr6;
       if (attr6.first())
@@ -1605,15 +1392,15 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
 
 // accurate mode: may the caller hand q / k / v of the temporal attention as hi + lo bf16 planes (short clips, no cache)?
 bool sf_temporal_planes_ok(int Tq, int Tk) {
-  const bool off = getenv("SF_DISABLE_TEMPORAL_DMA_ACC") != nullptr || getenv("SF_DISABLE_TEMPORAL_DMA") != nullptr;
+  const bool off = sf_sw(SW_DISABLE_TEMPORAL_DMA_ACC) != nullptr || sf_sw(SW_DISABLE_TEMPORAL_DMA) != nullptr;
   return !off && Tq > 1 && Tq <= 16 && Tk <= 32;
 }
 
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
   if (a.D != a.heads * HD || a.Tq <= 0 || a.Tk <= 0 || a.B <= 0 || a.N <= 0) return hipErrorInvalidValue;
   // dropout on the probabilities (training forward): the DMA-staged whole-clip kernel only
-  if (a.drop.on && (accurate || a.Tq == 1 || a.Tq > 16 || a.Tk > 32 || (a.row_pitch_kv % 8) || getenv("SF_DISABLE_TEMPORAL_DMA"))) return hipErrorInvalidValue;
-  static const bool decode_off = getenv("SF_DISABLE_TEMPORAL_DECODE") != nullptr;
+  if (a.drop.on && (accurate || a.Tq == 1 || a.Tq > 16 || a.Tk > 32 || (a.row_pitch_kv % 8) || sf_sw(SW_DISABLE_TEMPORAL_DMA))) return hipErrorInvalidValue;
+  const bool decode_off = sf_sw(SW_DISABLE_TEMPORAL_DECODE) != nullptr;
   if (a.Tq == 1 && a.Tk <= 256 && !decode_off) {        // one new frame per stream: the matrix-vector kernel
     const int ntasks = a.B * a.N * a.heads;
     const dim3 grid((ntasks + 3) / 4), block(256);
@@ -1624,7 +1411,7 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
 #undef SF_TD
     return hipGetLastError();
   }
-  static const bool tdma_off = getenv("SF_DISABLE_TEMPORAL_DMA") != nullptr;
+  const bool tdma_off = sf_sw(SW_DISABLE_TEMPORAL_DMA) != nullptr;
   if (!accurate && !tdma_off && a.Tq <= 16 && a.Tk <= 32 && (a.row_pitch_kv % 8) == 0) {     // every full 16-frame clip
     const int ntasks = a.B * a.N * a.heads;
     hipLaunchKernelGGL(sf_temporal_attn_dma_kernel<false>, dim3((ntasks + 3) / 4), dim3(256), 4 * 10240, s, a, ntasks);

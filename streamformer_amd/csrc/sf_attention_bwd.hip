@@ -19,6 +19,7 @@
 // Spatial: one 8-wave workgroup per (frame, head), L <= 224.  Temporal: one WAVE per (batch, patch,
 // head) sequence with wave-private images, L <= 32.
 #include "sf_train.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -520,7 +521,7 @@ hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_spatial_attn_bwd_kernel<false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   static const int lab = SF_LAB_SWITCH("SF_ATTN_BWD_LAB");      // timing lab: phases off, results invalid (lab builds only)
-  static const bool ntc_off = getenv("SF_DISABLE_SPATIAL_NTC") != nullptr;      // A/B switch (same one as the forward kernel)
+  const bool ntc_off = sf_sw(SW_DISABLE_SPATIAL_NTC) != nullptr;      // A/B switch (same one as the forward kernel)
   SfAttnBwdArgs b = a;
   b.lab = lab;
   const int nt = (a.L + 15) >> 4;

@@ -3,6 +3,7 @@
 // streaming copy vqa_enc:1316-1392).  See include/streamformer_hip.h for the contract.
 #include "sf_internal.h"
 #include "sf_common.h"
+#include "sf_switches.h"
 #include "sf_pool_head.h"
 
 #include <cmath>
@@ -14,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5
 static const int kLoraRank = 32;  // modeling:1280-1281
 
 // ------------------------------------------------------------------------------------------------
@@ -625,7 +626,7 @@ static bool ln_fold_small_ok(const sf_encoder* e, int M);
 // and the 256^2 kernel as every consumer (it applies them): true for the BASELINE shape.
 static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16) return false;
-  if (getenv("SF_DISABLE_LN_FOLD")) return false;        // A/B switch for measurements
+  if (sf_sw(SW_DISABLE_LN_FOLD)) return false;        // A/B switch for measurements
   if (ln_fold_small_ok(e, M)) return false;              // the small-M fold (in-kernel statistics: skinny / 64 x 64 / tile kernels) takes these
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -646,7 +647,7 @@ static bool ln_fold_ok(const sf_encoder* e, int M) {
 // precision every bf16x3 operand has anyway.  SF_DISABLE_ACC_FOLD restores fp32 residual + standalone LayerNorm (A/B).
 static bool ln_fold_acc_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16X3 || e->D != 768) return false;
-  static const bool off = getenv("SF_DISABLE_ACC_FOLD") != nullptr;
+  const bool off = sf_sw(SW_DISABLE_ACC_FOLD) != nullptr;
   if (off) return false;
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -667,7 +668,7 @@ static bool ln_fold_acc_ok(const sf_encoder* e, int M) {
 // it reads anyway, every residual producer only adds the bf16 copy of its output rows.
 static bool ln_fold_small_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16 || M > sf_infold_max_rows()) return false;
-  static const bool off = getenv("SF_DISABLE_STREAM_FOLD") != nullptr;
+  const bool off = sf_sw(SW_DISABLE_STREAM_FOLD) != nullptr;
   if (off) return false;
   auto takes = [](const SfGemmArgs& g) { return sf_gemm_skinny_supported(g, false) || sf_gemm_tile_supported(g, false); };
   SfGemmArgs g;
@@ -746,9 +747,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // pm: the residual stream of a whole bf16 forward at BASELINE-sized M travels as hi + lo bf16 planes (hi = xn_hi, the A operand
   // of the folded Linears; lo = res_lo) instead of fp32: every residual producer moves 154 MB instead of 192 (no separate bf16
   // copy).  Only for complete forwards without hidden_states (the fp32 tensor is the interface of the stage-wise entry points).
-  static const bool planes_off = getenv("SF_DISABLE_RESID_PLANES") != nullptr;
+  const bool planes_off = sf_sw(SW_DISABLE_RESID_PLANES) != nullptr;
   bool pm = !planes_off && !acc && !streaming && ws.res_lo && !hidden_states && (stages & 7) == 7 && ln_fold_ok(e, M) && ws.embed_tab &&
-            ws.patch_buf && e->Kp % 32 == 0 && e->Kp >= 128 && D == 768 && !getenv("SF_EMBED_VIA_GEMM128");
+            ws.patch_buf && e->Kp % 32 == 0 && e->Kp >= 128 && D == 768 && !sf_sw(SW_EMBED_VIA_GEMM128);
   if (stages & 1) {
   SfRowIndex idx;
   int rc = time_rows(e, t_row, T, streaming, &idx);
@@ -769,7 +770,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // panel kernel, out = table[m % (T N)] + patches W^T + b with table = pos + time rows)
   bool embed_panel = false;
   if (ln_fold_ok(e, M) && !streaming && (stages & 2) && ws.embed_tab && ws.patch_buf && e->Kp % 32 == 0 && e->Kp >= 128 && D == 768 &&
-      !getenv("SF_EMBED_VIA_GEMM128"))
+      !sf_sw(SW_EMBED_VIA_GEMM128))
     embed_panel = true;
   bf16_t* patches = embed_panel ? ws.patch_buf : ws.xn_hi;
   if (!patches_ready)
@@ -811,7 +812,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // sfold: the same algebra at small M (streamed frames), statistics computed inside the consumer GEMM
   const bool sfold = !fold && ws.res_bf && ln_fold_small_ok(e, M);
   // xm: the accurate mode's counterpart of fold + pm (ln_fold_acc_ok): whole clips on the plane-fed attention kernels
-  static const bool two_planes = getenv("SF_ACC_TWO_PLANES") != nullptr;      // A/B: drop the third plane (max-abs 1.4e-4 instead of 5e-5)
+  const bool two_planes = sf_sw(SW_ACC_TWO_PLANES) != nullptr;      // A/B: drop the third plane (max-abs 1.4e-4 instead of 5e-5)
   bf16_t* plo2 = two_planes ? nullptr : ws.res_lo2;
   const bool xm = acc && !streaming && !hidden_states && (stages & 7) == 7 && !layer_tqkv && cap == T && t_past == 0 &&
                   sf_temporal_planes_ok(T, T) && sf_spatial_planes_ok(N, attentions != nullptr) && ln_fold_acc_ok(e, M);
@@ -1211,7 +1212,7 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
   // itself, or asked for eager launches.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
-  static const bool graphs_off = getenv("SF_DISABLE_STREAM_GRAPH") != nullptr;
+  const bool graphs_off = sf_sw(SW_DISABLE_STREAM_GRAPH) != nullptr;
   const bool use_graph = !graphs_off && !hidden_states && !attentions && cap == hipStreamCaptureStatusNone && T_new < 256 && c->len < 65536;
   if (!use_graph) {
     rc = run_forward(e, pixels, pixel_dtype, c->B, T_new, c->H, c->W, last_hidden, pooler, hidden_states, pos_dev, ws,
@@ -1224,7 +1225,7 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
   // and the position reach the kernels through a small device block written by one tiny launch in front of the replay;
   // only the number of 64-key passes of the single-query attention is compiled in (1 / 2 / 4 -> at most three graphs).
   // Several frames per call keep one graph per (position, count): their attention kernels take the position by value.
-  static const bool posfree_off = getenv("SF_STREAM_GRAPH_PER_POSITION") != nullptr;
+  const bool posfree_off = sf_sw(SW_STREAM_GRAPH_PER_POSITION) != nullptr;
   const bool posfree = T_new == 1 && !posfree_off && c->dparams != nullptr;
   const int kp = (pos3[2] + 63) >> 6;
   const int kcls = kp <= 1 ? 1 : (kp <= 2 ? 2 : 4);
@@ -1471,7 +1472,7 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   if (acc && epi == SF_EPI_RESID_F32) oh = nullptr;     // the accurate mode keeps no bf16 copy of the residual (no LayerNorm fold)
   // bf16 mode at BASELINE-sized M: the residual projections as the forward launches them — hi + lo planes in and out, LayerNorm
   // row sums of the next Linear (run_forward's `pm`); fp32 residual + bf16 copy otherwise
-  static const bool planes_off = getenv("SF_DISABLE_RESID_PLANES") != nullptr;
+  const bool planes_off = sf_sw(SW_DISABLE_RESID_PLANES) != nullptr;
   const bool pm = !planes_off && !acc && epi == SF_EPI_RESID_F32 && ln_fold_ok(e, M);
   float* st = pm ? c.take<float>((size_t)M * 8) : nullptr;
   if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);

@@ -14,6 +14,7 @@
 //     fragment pair (hi*hi + hi*lo + lo*hi), BK halves so the LDS footprint stays 64 KB.
 //   * block id -> tile map is XCD-aware: the 8 XCDs each walk a contiguous band of row panels.
 #include "sf_common.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 #define BM 128
@@ -242,7 +243,7 @@ hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
     if (sf_gemm_skinny_supported(a, split)) return sf_launch_gemm_skinny(a, split, s);
     return sf_gemm_tile_supported(a, split) ? sf_launch_gemm_tile(a, s) : hipErrorInvalidValue;
   }
-  if (sf_gemm_skinny_supported(a, split) && !getenv("SF_DISABLE_SKINNY")) return sf_launch_gemm_skinny(a, split, s);
+  if (sf_gemm_skinny_supported(a, split) && !sf_sw(SW_DISABLE_SKINNY)) return sf_launch_gemm_skinny(a, split, s);
   if (sf_gemm_tile_supported(a, split)) return sf_launch_gemm_tile(a, s);
 #ifdef SF_LAB      // round-4 epilogue-overlap experiments (profiles/r04_panel_overlap_lab.txt): lab library only, behind SF_PANEL_PIPE / SF_PANEL_PP
   if (sf_gemm_pipe_supported(a, split)) return sf_launch_gemm_pipe(a, s);

@@ -19,6 +19,7 @@
 //   * LDS image of a piece is [128 rows][64 k] bf16, lane-linear for the DMA, with the 16-byte slot
 //     XOR (row>>1)&7 applied to the SOURCE address and mirrored on ds_read_b128.
 #include "sf_common.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 #define G_THREADS 512
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 }
 
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
-  if (split && (!a.a_lo || !a.w_lo || a.aux_mode || getenv("SF_DISABLE_G256_SPLIT"))) return false;
+  if (split && (!a.a_lo || !a.w_lo || a.aux_mode || sf_sw(SW_DISABLE_G256_SPLIT))) return false;
   if (split && a.ln_stats && (!a.ln_stats_wide || !a.ln_s || a.K != 768 || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
   if (!split && a.resid_hi) return false;
   if (a.epi == SF_EPI_EMBED_F32) return false;
@@ -524,7 +525,7 @@ bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
   if (!split && a.epi == SF_EPI_ACT_BF16 && a.act != 0 && a.act != 99) return false;   // other activations: 128^2 kernel
   if (a.K % 128 || a.K < 128) return false;
   int min_n = 1024;                             // N = 768: 294 tiles on 256 CUs -> the panel / 128^2 kernels win
-  if (split) { min_n = 768; if (const char* e = getenv("SF_G256_SPLIT_MIN_N")) min_n = atoi(e); }    // bf16x3: 392 / 120 us against 415 / 127 on the 128^2 kernel
+  if (split) { min_n = 768; if (const char* e = sf_sw(SW_G256_SPLIT_MIN_N)) min_n = atoi(e); }    // bf16x3: 392 / 120 us against 415 / 127 on the 128^2 kernel
   if (a.N % 256 || a.N < min_n) return false;
   if (a.M < 2048 || (size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return false;                 // small problems: the 128x128 kernel fills the chip better
   if (a.out_lo && !split) return false;
@@ -541,7 +542,7 @@ static int g256_grid() {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (const char* e = getenv("SF_ASSUME_CUS")) cus = atoi(e);      // experiment: kernels sized for a CU-masked stream
+    if (const char* e = sf_sw(SW_ASSUME_CUS)) cus = atoi(e);      // experiment: kernels sized for a CU-masked stream
     if (cus < 8) cus = 256;
     cus &= ~7;      // the XCD-aware walk wants a multiple of 8
   }
@@ -577,12 +578,12 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   // Measured optimum on the SigLIP-base shapes: 3 groups, 0.19-0.23 of the period (6-7 us for the MLP up-projection): -5.8 % on the whole forward.
   // SF_G256_STAGGER_NS / SF_G256_STAGGER_PCT / SF_G256_STAGGER_GROUPS override for A/B runs (NS=0 disables).
   int stagger = 0, sgroups = 3;
-  if (const char* ge = getenv("SF_G256_STAGGER_GROUPS")) sgroups = atoi(ge) > 1 ? atoi(ge) : 2;
+  if (const char* ge = sf_sw(SW_G256_STAGGER_GROUPS)) sgroups = atoi(ge) > 1 ? atoi(ge) : 2;
   {
     const int rounds = (tiles + (int)grid.x - 1) / (int)grid.x;
     double pct = 21.0;
-    if (const char* pe = getenv("SF_G256_STAGGER_PCT")) pct = atof(pe);
-    const char* env = getenv("SF_G256_STAGGER_NS");
+    if (const char* pe = sf_sw(SW_G256_STAGGER_PCT)) pct = atof(pe);
+    const char* env = sf_sw(SW_G256_STAGGER_NS);
     if (env) stagger = sf_wall_clock_ticks(atoi(env));
     else if (rounds >= 3) {
       const double mfma_x = (a.a_lo && a.w_lo) ? 3.0 : 1.0;
@@ -590,7 +591,7 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
       stagger = sf_wall_clock_ticks((int)(tile_ns * pct / 100.0));
     }
   }
-  if (const char* only = getenv("SF_G256_STAGGER_ONLY")) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs
+  if (const char* only = sf_sw(SW_G256_STAGGER_ONLY)) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs
     if (a.epi != atoi(only)) stagger = 0;
   }
 #define SF_LAUNCH256(E, L, SP) hipLaunchKernelGGL((sf_gemm256_kernel<E, L, BM, SP>), grid, block, lds, s, a, tiles, stagger, sgroups)
@@ -639,19 +640,19 @@ hipError_t sf_launch_gemm256(const SfGemmArgs& a, hipStream_t s) {
   // pick the row-tile height that wastes fewer tile slots of the persistent grid
   const int g = g256_grid(), nt = a.N / 256;
   auto cost = [&](int bm) { const int tiles = ((a.M + bm - 1) / bm) * nt; return (long)((tiles + g - 1) / g) * bm; };
-  if (a.a_lo && a.w_lo && !getenv("SF_G256_NO_SHORT_BM")) {
+  if (a.a_lo && a.w_lo && !sf_sw(SW_G256_NO_SHORT_BM)) {
     // bf16x3 runs N = 768 here too (3 column tiles): shorter row tiles fill the second round of the persistent grid.
     // A K-tile of the short quadrant costs the read segment of the other wave row, not its own few MFMAs, hence the
     // per-height time factors (cycles per K-tile: 4 x max(MFMA segment, read segment ~ 350)).
     auto t = [&](int bm, double f) { return (double)cost(bm) / bm * f; };
     const double t256 = t(256, 1632), t224 = t(224, 1472), t192 = t(192, 1370), t160 = t(160, 1268);
     const double best = fmin(fmin(t256, t224), fmin(t192, t160));
-    if (const char* fe = getenv("SF_G256_FORCE_BM")) {
+    if (const char* fe = sf_sw(SW_G256_FORCE_BM)) {
       switch (atoi(fe)) { case 160: return launch_bm<160, true>(a, s); case 192: return launch_bm<192, true>(a, s); case 224: return launch_bm<224>(a, s); default: return launch_bm<256>(a, s); }
     }
     if (best == t160 && t160 < 0.97 * fmin(t224, t256)) return launch_bm<160, true>(a, s);
     if (best == t192 && t192 < 0.97 * fmin(t224, t256)) return launch_bm<192, true>(a, s);
   }
-  if (cost(224) < cost(256) && !getenv("SF_G256_NO_BM224")) return launch_bm<224>(a, s);   // env: A/B switch
+  if (cost(224) < cost(256) && !sf_sw(SW_G256_NO_BM224)) return launch_bm<224>(a, s);   // env: A/B switch
   return launch_bm<256>(a, s);
 }

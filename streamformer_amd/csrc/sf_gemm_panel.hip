@@ -15,6 +15,7 @@
 // an MFMA segment that has since completed, and read one phase after the vmcnt that retires it.  (Round 1 issued the
 // refill in front of the wave's own MFMAs: 144-146 us per K = 3072 launch against 138-140 us now, same box.)
 #include "sf_common.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 #define P_THREADS 512
@@ -321,7 +322,7 @@ static int panel_cus() {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (const char* e = getenv("SF_ASSUME_CUS")) cus = atoi(e);      // experiment: kernels sized for a CU-masked stream
+    if (const char* e = sf_sw(SW_ASSUME_CUS)) cus = atoi(e);      // experiment: kernels sized for a CU-masked stream
     if (cus < 16) cus = 256;
     cus &= ~15;
   }
@@ -344,7 +345,7 @@ static PanelPlan panel_plan(int M) {
   // >= 75 % of the MFMA rows real; from five clips on 55 % is enough — the folded schedule (and the plane-form residual that comes
   // with it) beats LayerNorm launches + the 256^2 / 128^2 residual kernels there (tools/bsweep.py: 5 clips 6.44 -> 6.09 ms, 6 clips
   // 6.95 -> 6.64; three clips at 66 % lose 6 %).  SF_PANEL_MIN_FILL_PCT forces one threshold (lab).
-  static const int forced = getenv("SF_PANEL_MIN_FILL_PCT") ? atoi(getenv("SF_PANEL_MIN_FILL_PCT")) : 0;
+  const int forced = sf_sw(SW_PANEL_MIN_FILL_PCT) ? atoi(sf_sw(SW_PANEL_MIN_FILL_PCT)) : 0;
   const int min_fill = forced ? forced : (M >= 14000 ? 55 : 75);
   pl.panels = panels; pl.rows = rows; pl.ok = rows * 100 >= pl.mt * 16 * min_fill;
   return pl;
@@ -380,9 +381,9 @@ hipError_t sf_launch_gemm_panel(const SfGemmArgs& a_in, hipStream_t s) {
   // residual read + store bursts of the epilogues.  Box-dependent: -3.3 % on the whole forward on one MI355X,
   // neutral on another; never slower in the sweeps (tools/stagger_sweep.py).  SF_PANEL_STAGGER_NS overrides.
   int stagger = (ntiles >= cus && pl.mt == 13) ? sf_wall_clock_ticks(3500) : 0;      // full-height tiles only: small tiles finish before a step elapses
-  if (const char* e = getenv("SF_PANEL_STAGGER_NS")) stagger = sf_wall_clock_ticks(atoi(e));
+  if (const char* e = sf_sw(SW_PANEL_STAGGER_NS)) stagger = sf_wall_clock_ticks(atoi(e));
   if (const int lm = SF_LAB_SWITCH("SF_PANEL_LAB_EPI")) a.w_nt = 78 + lm;      // lab builds only
-  static const int pad_clamp = getenv("SF_PANEL_PAD_CLAMP") ? 1 : 0;      // A/B switch
+  const int pad_clamp = sf_sw(SW_PANEL_PAD_CLAMP) ? 1 : 0;      // A/B switch
   const dim3 grid(ntiles < cus ? ntiles : cus), block(P_THREADS);
   const size_t lds = 4 * P_SLOT_BYTES;
   switch (pl.mt) {

@@ -15,6 +15,7 @@
 //   * A is re-read by the N/32 column workgroups from L2 (it is 0.3-1.2 MB), W by the M/32 row groups.
 // SPLIT = the fp32-accurate bf16x3 mode (hi/lo planes of both operands, three MFMAs per fragment pair).
 #include "sf_common.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 #define SK_BM 32
@@ -507,8 +508,8 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_mid_kernel(SfGemmArgs p) {
 }
 
 static bool mid_ok(const SfGemmArgs& a, bool split) {
-  static const bool off = getenv("SF_DISABLE_GEMM_MID") != nullptr;
-  static const int min_m = getenv("SF_GEMM_MID_MIN_M") ? atoi(getenv("SF_GEMM_MID_MIN_M")) : 512;
+  const bool off = sf_sw(SW_DISABLE_GEMM_MID) != nullptr;
+  const int min_m = sf_sw(SW_GEMM_MID_MIN_M) ? atoi(sf_sw(SW_GEMM_MID_MIN_M)) : 512;
   return !off && !split && a.M > min_m && a.N >= 64 && a.epi != SF_EPI_EMBED_F32 && !a.out_lo;
 }
 static hipError_t mid_launch(const SfGemmArgs& a, hipStream_t s) {
@@ -561,7 +562,7 @@ static hipError_t skg_launch(const SfGemmArgs& a, dim3 grid, hipStream_t s) {
 #undef SKG_ATTR
   }
   if constexpr (!SPLIT && KG == 4) {        // the streamed K = 768 residual projections (24 of a frame's 108 launches): three K-tiles per group, unrolled
-    static const bool pg_off = getenv("SF_DISABLE_SKG_UNROLL") != nullptr;      // A/B switch
+    const bool pg_off = sf_sw(SW_DISABLE_SKG_UNROLL) != nullptr;      // A/B switch
     if (!pg_off && a.epi == SF_EPI_RESID_F32 && a.K == 64 * KG * 3) {
       static SfPerDeviceOnce attr_pg;
       if (attr_pg.first())
@@ -591,7 +592,7 @@ int sf_skinny_max_rows() {
   if (!m) {
     m = 2560;      // several streams per call (M = 196 per stream): 4 streams 2.51 -> 1.58 ms, 8 streams 2.79 -> 2.43 ms per step against
                    // the 128^2 kernel; from 16 streams (M = 3136) on the large-tile kernels win
-    if (const char* e = getenv("SF_SKINNY_MAX_M")) m = atoi(e) > 0 ? atoi(e) : 2560;
+    if (const char* e = sf_sw(SW_SKINNY_MAX_M)) m = atoi(e) > 0 ? atoi(e) : 2560;
   }
   return m;
 }
@@ -635,13 +636,13 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a_in, bool split, hipStream_t
   if (!sf_gemm_skinny_supported(a_in, split)) return hipErrorInvalidValue;
   // non-temporal policy on the weight stream of a single streamed frame (each 32-row slab is read by the 7 row tiles of one
   // XCD, once): config #5 p50 0.773 -> 0.751 ms; neutral from 8 streams on (M = 1568), where the default policy stays
-  static const int nt_env = getenv("SF_SKINNY_NT") ? atoi(getenv("SF_SKINNY_NT")) : -1;
+  const int nt_env = sf_sw(SW_SKINNY_NT) ? atoi(sf_sw(SW_SKINNY_NT)) : -1;
   SfGemmArgs a = a_in;
   a.w_nt = nt_env >= 0 ? nt_env : (a.M <= 512 ? 1 : 0);
   if (mid_ok(a, split)) return mid_launch(a, s);
   const dim3 grid((a.N + SK_BN - 1) / SK_BN, (a.M + SK_BM - 1) / SK_BM);
   // every workgroup gets its own CU and the K loop is long: the K-parallel variant
-  if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !getenv("SF_SKINNY_NO_KG"))
+  if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !sf_sw(SW_SKINNY_NO_KG))
     return split ? skg_launch<true, 2>(a, grid, s) : skg_launch<false, 4>(a, grid, s);
   const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
   if (a.ln_inkernel) {
@@ -650,7 +651,7 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a_in, bool split, hipStream_t
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, SF_EPI_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
     }
-    static const int tps_env = getenv("SF_SKINNY_TPS") ? atoi(getenv("SF_SKINNY_TPS")) : 0;
+    const int tps_env = sf_sw(SW_SKINNY_TPS) ? atoi(sf_sw(SW_SKINNY_TPS)) : 0;
     const int nkt = a.K / SK_BK;
     int tps = tps_env ? tps_env : 4;
     while (tps > 1 && (nkt % tps)) --tps;

@@ -21,6 +21,7 @@
 // Epilogue: the C tile leaves through LDS, 16 WM rows at a time, as whole rows with 16-byte accesses: fp32 residual
 // read-modify-write + bf16 copy, bf16 (+ LayerNorm finish, bias, erf-GELU), embedding table add.
 #include "sf_common.h"
+#include "sf_switches.h"
 #include <cstdlib>
 
 #define TL_CONSUMERS 512          // 8 MFMA waves
@@ -305,7 +306,7 @@ static int tile_cus() {
   return cus;
 }
 int sf_tile_min_rows() {
-  static const int m = getenv("SF_TILE_MIN_M") ? atoi(getenv("SF_TILE_MIN_M")) : 2560;      // below: skinny / 64 x 64 kernels
+  const int m = sf_sw(SW_TILE_MIN_M) ? atoi(sf_sw(SW_TILE_MIN_M)) : 2560;      // below: skinny / 64 x 64 kernels
   return m;
 }
 int sf_tile_max_rows() {
@@ -314,7 +315,7 @@ int sf_tile_max_rows() {
   // 39 / 64 -> 3.02 against 3.36 ms for two clips (the narrow producers carry it; the two LayerNorm folds — in-kernel
   // statistics here, statistics buffer on the 256^2 kernel — do not mix, so the consumers come along); M = 12544: level or
   // slower everywhere.
-  static const int m = getenv("SF_TILE_MAX_M") ? atoi(getenv("SF_TILE_MAX_M")) : 6272;
+  const int m = sf_sw(SW_TILE_MAX_M) ? atoi(sf_sw(SW_TILE_MAX_M)) : 6272;
   return m;
 }
 
@@ -352,7 +353,7 @@ static const TlShape* pick_shape(const SfGemmArgs& a) {
 }
 
 bool sf_gemm_tile_supported(const SfGemmArgs& a, bool split) {
-  static const bool off = getenv("SF_DISABLE_GEMM_TILE") != nullptr;
+  const bool off = sf_sw(SW_DISABLE_GEMM_TILE) != nullptr;
   if (off || split || a.a_lo || a.out_lo || a.aux_mode || a.ln_stats || a.ln_stats_out || a.resid_mod > 0) return false;
   if (a.M <= sf_tile_min_rows() || a.M > sf_tile_max_rows()) return false;
   if (a.K < 128 || (a.K % 64) || (a.ldc % 8) || (a.N % 8)) return false;
@@ -413,7 +414,7 @@ static hipError_t tl_wide(const SfGemmArgs& a, hipStream_t s) {
 hipError_t sf_launch_gemm_tile(const SfGemmArgs& a, hipStream_t s) {
   if (!sf_gemm_tile_supported(a, false)) return hipErrorInvalidValue;
   const TlShape* sh = pick_shape(a);
-  static const int force = getenv("SF_TILE_SHAPE") ? atoi(getenv("SF_TILE_SHAPE")) : -1;      // lab switch: force a candidate id
+  const int force = sf_sw(SW_TILE_SHAPE) ? atoi(sf_sw(SW_TILE_SHAPE)) : -1;      // lab switch: force a candidate id
   int id = sh->id;
   if (force >= 0 && force < 6 && shape_takes(kShapes[force], a)) id = force;
   switch (id) {

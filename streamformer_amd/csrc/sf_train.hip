@@ -5,6 +5,7 @@
 // semantics of tools/finetune_tools.py:395-573 and the optimizer grouping of optim_factory.py:59-104.
 #include "sf_internal.h"
 #include "sf_common.h"
+#include "sf_switches.h"
 #include "sf_train.h"
 #include "sf_pool_head.h"
 
@@ -815,7 +816,7 @@ static hipError_t lin_wgrad_queued(const BwdCtx& c, LayerWgrads& q, const TLin& 
 // the side stream of the LoRA gradients: created on first use; SF_TRAIN_SIDE_STREAM=0 keeps everything on the caller's stream (A/B)
 static bool side_stream_ready(sf_trainer* t) {
   if (t->side_state == 0) {
-    const char* e = getenv("SF_TRAIN_SIDE_STREAM");
+    const char* e = sf_sw(SW_TRAIN_SIDE_STREAM);
     t->side_state = -1;
     if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess &&
         hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) == hipSuccess &&
@@ -856,7 +857,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
 
   // drop_path: the gradient entering a dropped branch carries the branch's factor (0 or 1 / keep per sample group)
   const float* dp = t->f_dp ? t->f_dp + (size_t)li * ((size_t)B * N + (size_t)B * T + (size_t)B) : nullptr;
-  static const bool ungrouped = getenv("SF_WGRAD_UNGROUPED") != nullptr;
+  const bool ungrouped = sf_sw(SW_WGRAD_UNGROUPED) != nullptr;
   LayerWgrads q;
   memset(&q.g, 0, sizeof(q.g));
   q.g.M = M; q.g.partial = ws.wg_partial;

@@ -5,6 +5,7 @@
 // (torch.optim.AdamW as configured by optim_factory.py:59-104).  All HBM-bound; every reduction is
 // two-stage with a fixed order, so gradients are bit-reproducible run to run.
 #include "sf_train.h"
+#include "sf_switches.h"
 
 // ------------------------------------------------------------------------------------------------
 // GELU
@@ -325,7 +326,7 @@ hipError_t sf_launch_ln_bwd(const float* x, const void* dy, int dy_is_bf16, cons
   if (D % 4 || D > 64 * 4 * 8) return hipErrorInvalidValue;
   // 512 workgroups = 8 waves per CU run at the HBM rate (fp32 dy, M = 25 088: 49 us = 6.2 TB/s; 1024 .. 2048 workgroups measure 50 .. 54 us
   // and a slower finish kernel, profiles/r04_ln_bwd_lab.txt).  SF_LN_BWD_BLOCKS overrides (lab).
-  static const int cap = getenv("SF_LN_BWD_BLOCKS") ? atoi(getenv("SF_LN_BWD_BLOCKS")) : 512;
+  const int cap = sf_sw(SW_LN_BWD_BLOCKS) ? atoi(sf_sw(SW_LN_BWD_BLOCKS)) : 512;
   int blocks = (rows + 3) / 4;
   if (blocks > cap) blocks = cap;
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;

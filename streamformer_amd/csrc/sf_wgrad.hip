@@ -13,6 +13,7 @@
 // with (row & 7) on the DMA source address, so the 8 rows a half-wave reads hit all 64 banks.
 // The M range is split across workgroups (fp32 partial tiles) and reduced in a fixed order.
 #include "sf_train.h"
+#include "sf_switches.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -422,7 +423,7 @@ static int wg_cus() {
 // split count of a group of `ntiles` tiles over kt K-steps: rounds x (K-steps per workgroup + the tile write) + the reduce
 // pass, in K-step units (a K-step is ~2.4 us, a 256 KB partial write ~6 of them, reducing one split of one tile ~0.03)
 static int wgg_nsplit(int ntiles, int kt) {
-  static const int forced = getenv("SF_WGRAD_NSPLIT") ? atoi(getenv("SF_WGRAD_NSPLIT")) : 0;     // lab: tools/wgrad_lab.py
+  const int forced = sf_sw(SW_WGRAD_NSPLIT) ? atoi(sf_sw(SW_WGRAD_NSPLIT)) : 0;     // lab: tools/wgrad_lab.py
   if (forced > 0) return forced;
   const int cus = wg_cus();
   int best = 1;
@@ -438,7 +439,7 @@ static int wgg_nsplit(int ntiles, int kt) {
   return best;
 }
 bool sf_wgrad_groupable(int M, int N1, int N2) {
-  static const bool small_only = getenv("SF_WGRAD_SMALL_TILES") != nullptr;
+  const bool small_only = sf_sw(SW_WGRAD_SMALL_TILES) != nullptr;
   return N1 > 0 && N2 > 0 && (N1 % WB_T == 0) && (N2 % WB_T == 0) && (M + WG_KM - 1) / WG_KM >= 32 && !small_only;
 }
 size_t sf_wgrad_group_partial_floats(int M, int ntiles, int sum_n1) {

@@ -107,13 +107,13 @@ def test_op_linear(sa, M, N, K, mode):
 
 @pytest.mark.parametrize("M,N,K,bm256", [(2300, 1024, 256, False), (2100, 1280, 128, True), (2077, 768, 256, 160), (2500, 768, 128, 192)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_op_linear_large_tiles(sa, M, N, K, bm256, mode, monkeypatch):
+def test_op_linear_large_tiles(sa, M, N, K, bm256, mode, switches):
     """The 256x256 (and 224x256) persistent MFMA kernel incl. its bf16x3 variant (hi + lo planes, three products):
     ragged M, every epilogue the encoder uses on it."""
     if bm256 is True:
-        monkeypatch.setenv("SF_G256_NO_BM224", "1")
+        switches("SF_G256_NO_BM224")
     elif bm256:
-        monkeypatch.setenv("SF_G256_FORCE_BM", str(bm256))        # the short row tiles of the bf16x3 variant
+        switches("SF_G256_FORCE_BM", bm256)        # the short row tiles of the bf16x3 variant
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) * K ** -0.5
@@ -187,10 +187,10 @@ def test_op_spatial_attention(sa, frames_, N, heads, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("frames_,N,heads", [(2, 196, 2), (1, 37, 12), (3, 224, 1)])
-def test_op_spatial_attention_accurate_fp32_inputs(sa, frames_, N, heads, monkeypatch):
+def test_op_spatial_attention_accurate_fp32_inputs(sa, frames_, N, heads, switches):
     """The accurate mode's register-staged kernel (fp32 q / k / v: what streaming and output_attentions use) next to
     the DMA kernel on hi + lo planes that the plain call above takes."""
-    monkeypatch.setenv("SF_DISABLE_SPATIAL_DMA_ACC", "1")
+    switches("SF_DISABLE_SPATIAL_DMA_ACC")
     _spatial_attention_case(sa, frames_, N, heads, 1)
 
 
@@ -257,10 +257,10 @@ def test_op_temporal_attention(sa, B, L, Nt, heads, causal, mode):
 
 
 @pytest.mark.parametrize("B,L,Nt,heads,causal", [(2, 16, 9, 2, 1), (1, 5, 4, 12, 1), (2, 16, 5, 3, 0)])
-def test_op_temporal_attention_accurate_fp32_inputs(sa, B, L, Nt, heads, causal, monkeypatch):
+def test_op_temporal_attention_accurate_fp32_inputs(sa, B, L, Nt, heads, causal, switches):
     """Short sequences in the accurate mode on the register-staged kernel with fp32 q / k / v (what streaming keeps using);
     the plain call above takes the DMA kernel on hi + lo planes for L <= 16."""
-    monkeypatch.setenv("SF_DISABLE_TEMPORAL_DMA_ACC", "1")
+    switches("SF_DISABLE_TEMPORAL_DMA_ACC")
     _temporal_attention_case(sa, B, L, Nt, heads, causal, 1)
 
 
@@ -918,6 +918,56 @@ def test_several_streams_per_call_vs_oracle(mode, tol_l, tol_p, streams, nframes
     cache.reset()
     outs2 = [m(xd[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(nframes)]
     assert torch.equal(torch.cat([o.last_hidden_state for o in outs2], 1), lhs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol_l,tol_p", [("fp32", ACC_TOL, ACC_TOL), ("bf16", BF16_LHS, BF16_POOL)])
+def test_forward_non_base_width_vs_oracle(mode, tol_l, tol_p):
+    """StreamformerConfig accepts any hidden_size / heads (models/configuration_streamformer.py:90-135); a ViT-L-shaped
+    encoder (D = 1024, 16 heads, I = 4096, head_dim 64) leaves every SigLIP-base-only fast path (N = 768 panel tiles, the plane-form
+    residual stream) and must still equal the oracle: whole clips at two batch sizes (M = 392 on the small-M kernels, M = 6272 on
+    the generic 128^2 / 256^2 tiles), the pooling head at 16 heads, and three streamed frames through the KV-cache (the head's
+    row-vector tail at K = 4096)."""
+    import streamformer_amd as sa
+    from streamformer_amd.configuration import StreamformerConfig
+    cfg = StreamformerConfig(image_size=224, patch_size=16, num_frames=16, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
+                             intermediate_size=4096, enable_causal_temporal=True)
+    sd = make_state_dict(cfg, seed=12)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    for B, T, seed in ((1, 2, 5), (2, 16, 6)):
+        x = frames(seed, (B, T, 3, 224, 224))
+        want = O.forward(sd, cfg, x)
+        out = m(x.cuda())
+        assert out.last_hidden_state.shape == (B, T, 196, 1024) and out.pooler_output.shape == (B, T, 1024)
+        assert maxabs(out.last_hidden_state, want["last_hidden_state"]) <= tol_l, (B, T)
+        assert maxabs(out.pooler_output, want["pooler_output"]) <= tol_p, (B, T)
+        again = m(x.cuda())
+        assert torch.equal(out.last_hidden_state, again.last_hidden_state) and torch.equal(out.pooler_output, again.pooler_output)
+    x = frames(7, (1, 3, 3, 224, 224))
+    want = O.forward(sd, cfg, x)
+    cache = m.new_cache(1, 16)
+    outs = [m(x.cuda()[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(3)]
+    assert maxabs(torch.cat([o.last_hidden_state for o in outs], 1), want["last_hidden_state"]) <= tol_l
+    assert maxabs(torch.cat([o.pooler_output for o in outs], 1), want["pooler_output"]) <= tol_p
+
+
+@pytest.mark.gpu
+def test_unsupported_widths_are_refused_with_a_message():
+    """head_dim != 64 (a SigLIP-so400m-shaped 1152 / 16 = 72) and more than 16 heads are refused at construction with SF_ERR_INVALID
+    and a message that names the limit — not a wrong answer, not a crash at the first forward."""
+    import streamformer_amd as sa
+    import streamformer_amd._native as nat
+    from streamformer_amd.configuration import StreamformerConfig
+    for kw, word in ((dict(hidden_size=1152, num_attention_heads=16, intermediate_size=4304), "head_dim"),
+                     (dict(hidden_size=1280, num_attention_heads=20, intermediate_size=5120), "heads")):
+        cfg = StreamformerConfig(image_size=224, patch_size=16, num_frames=16, num_hidden_layers=1, enable_causal_temporal=True, **kw)
+        with pytest.raises(nat.NativeError) as ei:
+            m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
+            m.load_state_dict(make_state_dict(cfg, seed=1))
+            m.to("cuda").eval()(frames(1, (1, 1, 3, 224, 224)).cuda())
+        assert word in str(ei.value)
 
 
 @pytest.mark.gpu

@@ -23,4 +23,5 @@ for gq in groups:
         key = os.environ.get("SWEEP_KEY", "SF_G256_STAGGER_NS")
         if v is None: os.environ.pop(key, None)
         else: os.environ[key] = str(v)
+        sa._native.lib.sf_reload_switches()          # the library reads its switch table once; re-read after every change
         print(f"groups {gq} stagger {'auto' if v is None else v:>6}: {run():.3f} ms", flush=True)
