@@ -126,7 +126,7 @@ def timed_steps(model, x, steps, warmup, dist, world, nstreams=1):
 
 def power_under_load(model, x, seconds=2.5):
     """Package power (W) and shader clock (MHz) from rocm-smi while the forward runs back to back: the forward is bound by the
-    power envelope, this is the evidence on the line itself.  None if rocm-smi is absent / unreadable."""
+    power envelope (docs/history.md H.4), this is the evidence on the line itself.  None if rocm-smi is absent / unreadable."""
     import json as _json, shutil, subprocess, threading
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(exe):
@@ -415,7 +415,7 @@ def streaming_bench(dev):
                                    "per frame, ~32 % of its kernel time)", "launches": dom, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "whole_frame": {"achieved": round(gb / mean, 1), "frac": round(gb / mean / PEAK_HBM_GBS, 4)},
                                    "note": "a streamed frame is ~100 dependent launches of 4-10 us: latency-bound, not bandwidth-bound "
-                                           "(DESIGN.md 4.1)"},
+                                           "(docs/history.md A.4.1)"},
             "eight_streams": {"p50_ms_per_call": round(1e3 * lat8[len(lat8) // 2], 3),
                               "frames_per_s": round(S / (sum(lat8) / len(lat8)), 1),
                               "config": "same model, 8 independent streams advance one frame per call (one cache, B = 8)"}}
@@ -652,7 +652,8 @@ def main():
         panel_tflops = panel_flop / panel_ms / 1e9
         traffic, traffic_note, traffic_from = None, "no PMC file", None
         try:   # HBM-side bytes per launch IMPORTED from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
             traffic_from = "profiles/" + pmc_file
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
@@ -669,10 +670,31 @@ def main():
                 traffic_note = f"{traffic_from} was taken on an older sf_gemm_panel.hip: traffic withheld until the PMC passes are re-run"
         except Exception as e:
             traffic_note = f"PMC file unreadable: {e!r}"
+        # MFMA-busy share of the dominant kernel's SIMD-cycles (north_star: "MFMA utilisation against gfx950 peak"): IMPORTED from the
+        # committed SQ / GRBM counter passes, guarded by the same source hash as `traffic`
+        mfma_busy = {"value": None, "note": "no SQ counter file"}
+        try:
+            sqf = os.path.join(ROOT, "profiles", "r05_pmc_sq.json")
+            with open(sqf) as f:
+                sq = json.load(f)
+            import hashlib
+            hsrc = hashlib.sha256(open(os.path.join(ROOT, "streamformer_amd", "csrc", "sf_gemm_panel.hip"), "rb").read()).hexdigest()[:16]
+            ent = next(v for k, v in sq["kernels"].items() if k.startswith("void sf_gemm_panel_kernel<13>"))
+            if sq.get("panel_source_sha16") == hsrc:
+                mfma_busy = {"value": ent.get("mfma_busy_frac_of_simd_cycles"), "effective_clock_GHz": ent.get("effective_clock_GHz_if_counter_sums_8_xcds"),
+                             "lds_bank_conflict_over_active_lds": ent.get("lds_bank_conflict_over_active_lds"),
+                             "wait_inst_any_over_wave_cycles": ent.get("wait_inst_any_over_wave_cycles"),
+                             "imported_from": "profiles/r05_pmc_sq.json",
+                             "note": "IMPORTED, not measured by this run: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), mean over the kernel's "
+                                     "dispatches of a forward (K = 768 and K = 3072 launches together); separate rocprofv3 --pmc passes"}
+            else:
+                mfma_busy["note"] = "profiles/r05_pmc_sq.json was taken on an older sf_gemm_panel.hip: withheld until the counter passes are re-run"
+        except Exception as e:
+            mfma_busy["note"] = f"SQ counter file unreadable: {e!r}"
         out["roofline"] = {"kernel": "sf_gemm_panel_kernel<13> (N = 768 residual projections: 2 x attention out-proj K=768 + MLP down-proj K=3072 per layer, "
                                      "epilogue = residual read-modify-write on hi + lo bf16 planes + LayerNorm row sums; M=%d)" % M,
                            "bound": "mfma", "achieved": round(panel_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(panel_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_imported_from": traffic_from,
+                           "frac": round(panel_tflops / PEAK_BF16_TFLOPS, 4), "mfma_busy": mfma_busy, "traffic": traffic, "traffic_imported_from": traffic_from,
                            "traffic_note": traffic_note, "avg_launch_ms": round(panel_ms / 3, 4), "timing": timing,
                            "in_situ": insitu,
                            "isolated": {"achieved": round(panel_flop / panel_ms_isolated / 1e9, 1), "frac": round(panel_flop / panel_ms_isolated / 1e9 / PEAK_BF16_TFLOPS, 4),
@@ -680,7 +702,7 @@ def main():
                            # live: the kernel's launches of one forward (per layer 2 x K=768 + 1 x K=3072, + the embedding GEMM, also
                            # K = 768) at their HIP-event times of this run, over this run's ms_per_step
                            "share_of_step_time_live": round((L * panel_ms + gemms["out_proj"]["ms"]) / (1e3 * dt / args.steps), 4),
-                           "share_from_profile": "profiles/r04_forward_kernel_stats.txt (rocprofv3 --kernel-trace --stats of this command)",
+                           "share_from_profile": "profiles/r05_forward_kernel_stats.txt (rocprofv3 --kernel-trace --stats of this command)",
                            "launches": {"out_proj_K768": gemms["out_proj"], "mlp_down_K3072": gemms["mlp_down"]},
                            "hbm_view_K768": {"algorithmic_GB": 0.1939,
                                              "GBps": round(0.1939 / (insitu["out_proj_K768"]["ms"] if insitu and insitu["out_proj_K768"]["ms"] > 0 else gemms["out_proj"]["ms"]) * 1e3, 1),
@@ -688,7 +710,7 @@ def main():
                            "other_gemms": {"mlp_up": gemms["mlp_up"], "qkv": gemms["qkv"]},
                            "clock_note": "peak is the nominal 2.4 GHz figure the contract asks for; in-kernel cycle stamps put the shader clock of "
                                          "these MFMA loops at 1.88 GHz on random data (power budget; the same binary runs 12 % faster on all-zero "
-                                         "operands), i.e. 1024 SIMDs x 16384 FLOP / 17.6 cycles x 1.88 GHz = 1790 TFLOP/s issue-bound (DESIGN.md 4.1c)",
+                                         "operands), i.e. 1024 SIMDs x 16384 FLOP / 17.6 cycles x 1.88 GHz = 1790 TFLOP/s issue-bound (docs/history.md A.4.1c)",
                            "frac_of_issue_bound_at_measured_clock": round(panel_tflops / 1790.0, 4)}
         if world == 1 and not args.profile:
             out["power_under_load"] = power_under_load(model, x)

@@ -12,7 +12,12 @@ from collections import defaultdict
 
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 dur = defaultdict(lambda: [0.0, 0])
-for d in sys.argv[1:]:
+args = sys.argv[1:]
+note = "rocprofv3 --pmc passes over `bench.py --profile --steps 2 --warmup 1` (B = 8, bf16 mode); means per dispatch"
+if args and args[0] == "--note":
+    note = args[1]
+    args = args[2:]
+for d in args:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -33,7 +38,18 @@ for k in sorted(acc):
         e["effective_clock_GHz_if_counter_sums_8_xcds"] = round(e["GRBM_GUI_ACTIVE"] / ns / 8, 3)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "SQ_BUSY_CYCLES" in e and e["SQ_BUSY_CYCLES"]:
         e["mfma_busy_over_sq_busy"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"], 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs' cycles with an MFMA in the pipe:
+        # fraction of the kernel's SIMD-cycles in which the matrix pipe was busy = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024)
+        e["mfma_busy_frac_of_simd_cycles"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 128.0), 4)
+    if "SQ_ACTIVE_INST_LDS" in e and "SQ_LDS_BANK_CONFLICT" in e and e["SQ_ACTIVE_INST_LDS"]:
+        e["lds_bank_conflict_over_active_lds"] = round(e["SQ_LDS_BANK_CONFLICT"] / (4.0 * e["SQ_ACTIVE_INST_LDS"]), 4)   # cycles / (quad-cycles * 4)
+    if "SQ_WAIT_INST_ANY" in e and "SQ_WAVE_CYCLES" in e and e["SQ_WAVE_CYCLES"]:
+        e["wait_inst_any_over_wave_cycles"] = round(e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 4)
     if "SQ_ACTIVE_INST_VALU" in e and "SQ_WAVE_CYCLES" in e and e["SQ_WAVE_CYCLES"]:
         e["valu_active_over_wave_cycles"] = round(e["SQ_ACTIVE_INST_VALU"] / e["SQ_WAVE_CYCLES"], 4)
     out[k] = e
-print(json.dumps({"note": "rocprofv3 --pmc passes over `bench.py --profile --steps 2 --warmup 1` (B = 8, bf16 mode); means per dispatch", "kernels": out}, indent=1))
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sha = hashlib.sha256(open(os.path.join(root, "streamformer_amd", "csrc", "sf_gemm_panel.hip"), "rb").read()).hexdigest()[:16]
+print(json.dumps({"note": note, "panel_source_sha16": sha, "kernels": out}, indent=1))

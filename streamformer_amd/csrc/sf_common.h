@@ -115,7 +115,7 @@ SF_DEVICE float gelu_fast(float x) {
 // g(16) = 1/8, i.e. Phi(-a) = 0 for a >= 4 (exact saturation on both sides).  |error| <= 1.4e-4 absolute against the exact
 // erf form (peak at |x| = 4: 0.4 % of a bf16 ulp there), 12 VALU ops without a transcendental one and all of them
 // packed-fp32 material, against 2 quarter-rate + ~10 full-rate ops of gelu_fast: the up-projection epilogue was spending
-// ~28 us per launch at M = 25 088 on the activation.
+// ~28 us per launch at M = 25 088 on the activation (docs/history.md A.4.2a).
 SF_DEVICE float gelu_bf16(float x) {
   const float a = fminf(fabsf(x), 4.0f);
   const float u = a * a;

@@ -837,7 +837,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     const bool tplanes = acc && !layer_tqkv && cap == T && t_past == 0 && sf_temporal_planes_ok(T, T);
     const size_t tsz = tplanes ? 2 : esz;
     // lab library, SF_QKV_FUSED=1 (bf16 mode, whole 16-frame clips, no cache): qkv projection + temporal attention in ONE launch
-    // (sf_gemm_qkv.hip; bit-identical, -0.27 ms of kernel time per forward under rocprof, +0.07 ms on the wall clock: DESIGN.md section 4)
+    // (sf_gemm_qkv.hip; bit-identical, -0.27 ms of kernel time per forward under rocprof, +0.07 ms on the wall clock: docs/history.md H.4)
     bool t_fused_attn = false;
 #ifdef SF_LAB
     if (fold && !acc && !layer_tqkv && cap == T && t_past == 0 && tk == T && !sp && l.t_qkv_fp.w_hi) {
