@@ -47,6 +47,7 @@
   X(TILE_MAX_M, "SF_TILE_MAX_M", "tile-GEMM family: largest M") \
   X(TILE_MIN_M, "SF_TILE_MIN_M", "tile-GEMM family: smallest M") \
   X(TILE_SHAPE, "SF_TILE_SHAPE", "tile-GEMM family: force a tile shape (tools/tile_lab.py)") \
+  X(TRAIN_UNFUSED_TEMPORAL, "SF_TRAIN_UNFUSED_TEMPORAL", "training: temporal_attention.output.dense and temporal_dense as two launches instead of one fused projection (A/B)") \
   X(TRAIN_SIDE_STREAM, "SF_TRAIN_SIDE_STREAM", "training: 0 keeps the LoRA gradients on the caller stream (A/B)") \
   X(WGRAD_NSPLIT, "SF_WGRAD_NSPLIT", "weight-gradient GEMM: force the token splits") \
   X(WGRAD_SMALL_TILES, "SF_WGRAD_SMALL_TILES", "weight-gradient GEMM: 128^2 tiles only") \

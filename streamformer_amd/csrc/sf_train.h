@@ -124,9 +124,20 @@ hipError_t sf_launch_head_query_bwd(const float* dq, const float* probe, const f
                                     float* d_bq, float* d_probe, int D, hipStream_t s);
 // temporal gate: h1 = h + tanh(g) * (t_out W^T + b).  G = unscaled dW, cs = unscaled db (colsum of dL/dh1):
 //   dW += tanh(g) G, db += tanh(g) cs, dgate += (1 - tanh(g)^2) * (<G, W> + <cs, b>)
+//   r1 != nullptr: G is taken as G + cs (x) r1 (the bias term of the fused temporal projections)
 hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, const float* b, const float* gate,
                                float* d_w, float* d_b, float* d_gate, float* partial /* >= 128 floats */, int N, int K,
-                               hipStream_t s);
+                               hipStream_t s, const float* r1 = nullptr);
+// temporal_dense o temporal_attention.output.dense as one projection of the training step (sf_train_kernels.hip): per layer
+//   wf [D, D] = (tanh(g) W_d) W_o as bf16, wfT its transpose, bf [D] = tanh(g) (W_d b_o + b_d)
+struct SfFuseJob {
+  const bf16_t* wd; const bf16_t* woT;     // bf16 working copies: tanh(g) W_d [D, D], W_o^T [D, D]
+  bf16_t* wf; bf16_t* wfT; float* bf;
+  long wd_off, bo_off, bd_off, gate_off;   // fp32 parameter offsets (floats) for the bias
+};
+hipError_t sf_launch_fuse_temporal(const float* base, const SfFuseJob* jobs_dev, int layers, int D, hipStream_t s);
+// out[k] += sum_i w[i, k] v[i]  (w bf16 [rows, ld])
+hipError_t sf_launch_matvec_t_bf16(const bf16_t* w, int ld, const float* v, float* out, int rows, int cols, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // optimizer

@@ -43,6 +43,9 @@ struct TLayer {
   int gate, ln_t_g, ln_t_b, ln_b_g, ln_b_b, ln_a_g, ln_a_b;
   TLin t_qkv, t_out, t_dense, s_qkv, s_out, up, down;
   size_t seg_off, seg_end;
+  // temporal_dense o temporal_attention.output.dense as one projection (drop rates 0): W_f = tanh(g) W_d W_o [D, D], its transpose,
+  // b_f = tanh(g) (W_d b_o + b_d); refreshed with the working weights (sf_launch_fuse_temporal)
+  bf16_t* wf = nullptr; bf16_t* wfT = nullptr; float* bf = nullptr;
 };
 
 struct sf_trainer {
@@ -69,6 +72,8 @@ struct sf_trainer {
   float* red_partial = nullptr;
   SfPrepJob* prep_jobs = nullptr;   // device table for sf_trainer_sync_weights
   int n_prep_jobs = 0, prep_tiles = 0;
+  SfFuseJob* fuse_jobs = nullptr;   // device table of the fused temporal projections (one per layer)
+  bool f_tfuse = false;             // the last forward ran the temporal branch's two projections as one (its backward follows)
   const float* params_dev = nullptr;
   int fB = 0, fT = 0;               // geometry of the last forward (0 = none)
   const float* dp_scales = nullptr; // drop_path factors of the next forward (device, caller-owned), nullptr = none
@@ -121,6 +126,7 @@ static void free_trainer_device(sf_trainer* t) {
   if (t->arena) (void)hipFree(t->arena);
   if (t->farena) (void)hipFree(t->farena);
   if (t->prep_jobs) (void)hipFree(t->prep_jobs);
+  if (t->fuse_jobs) (void)hipFree(t->fuse_jobs);
 }
 
 extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_spatial, int n_extra, sf_trainer** out) {
@@ -260,6 +266,8 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
     }
     nf += (size_t)D + 64 + 2048 + (size_t)16 * D;          // head query + reduction scratch + the head's folded key projection
     nb += (size_t)2 * 16 * D;
+    nb += (size_t)t->L * 2 * D * D;                        // fused temporal projections: wf + wfT per layer
+    nf += (size_t)t->L * D;                                //                             + b_f
     if (hipMalloc(&t->arena, nb * sizeof(bf16_t)) != hipSuccess || hipMalloc(&t->farena, nf * sizeof(float)) != hipSuccess) {
       free_trainer_device(t); delete t;
       return sf_set_err(SF_ERR_HIP, "hipMalloc failed (working weights, %zu bytes)", nb * 2);
@@ -280,6 +288,11 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
     t->head_u = fp; fp += (size_t)16 * D;
     t->head_u_hi = bp; bp += (size_t)16 * D;
     t->head_u_lo = bp; bp += (size_t)16 * D;
+    for (TLayer& l : t->layers) {
+      l.wf = bp; bp += (size_t)D * D;
+      l.wfT = bp; bp += (size_t)D * D;
+      l.bf = fp; fp += (size_t)D;
+    }
     t->red_partial = fp;
     // one-launch weight refresh: job table with offsets into the flat parameter buffer
     std::vector<SfPrepJob> jobs;
@@ -306,6 +319,18 @@ extern "C" int sf_trainer_create(const sf_config* cfg, int device, int freeze_sp
       return sf_set_err(SF_ERR_HIP, "hipMalloc failed (prep table)");
     }
     (void)hipMemcpy(t->prep_jobs, jobs.data(), jobs.size() * sizeof(SfPrepJob), hipMemcpyHostToDevice);
+    std::vector<SfFuseJob> fj;
+    for (TLayer& l : t->layers) {
+      SfFuseJob j;
+      j.wd = l.t_dense.w; j.woT = l.t_out.wT; j.wf = l.wf; j.wfT = l.wfT; j.bf = l.bf;
+      j.wd_off = off(l.t_dense.pw); j.bo_off = off(l.t_out.pb); j.bd_off = off(l.t_dense.pb); j.gate_off = off(l.gate);
+      fj.push_back(j);
+    }
+    if (hipMalloc(&t->fuse_jobs, fj.size() * sizeof(SfFuseJob)) != hipSuccess) {
+      free_trainer_device(t); delete t;
+      return sf_set_err(SF_ERR_HIP, "hipMalloc failed (fuse table)");
+    }
+    (void)hipMemcpy(t->fuse_jobs, fj.data(), fj.size() * sizeof(SfFuseJob), hipMemcpyHostToDevice);
   }
   *out = t;
   return SF_OK;
@@ -381,6 +406,8 @@ extern "C" int sf_trainer_sync_weights(sf_trainer* t, const float* params_dev, s
   // nn.MultiheadAttention scales q by head_dim^-0.5 after the in-projection (modeling:1145-1149)
   HIP_TRY(sf_launch_head_query(PP(t, params_dev, t->p_probe), PP(t, params_dev, t->p_inw), PP(t, params_dev, t->p_inb), 0.125f,
                                t->head_q, t->D, s));
+  // the temporal branch's two projections as one (used by forwards without drop_path / hidden dropout): from the fresh bf16 copies
+  HIP_TRY(sf_launch_fuse_temporal(params_dev, t->fuse_jobs, t->L, t->D, s));
   // the keys of the pooling head only meet that one query: U_h = Wk_h^T q_h (sf_pool_head.hip)
   HIP_TRY(sf_launch_pool_u(PP(t, params_dev, t->p_inw, (size_t)t->D * t->D), t->head_q, t->head_u, t->head_u_hi, t->head_u_lo, t->heads, t->D, s));
   return SF_OK;
@@ -420,6 +447,7 @@ struct TWs {
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
   bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
   float *wg_partial_side, *cs_partial_side;          // the side stream's own scratch (LoRA gradients, see sf_trainer::side)
+  float* dw_scratch2; bf16_t* g1_bf;                 // fused temporal projections: g^T t_out [D, D] fp32 and bf16(g^T ctx) [D, D]
   bf16_t *lora_u_side, *lora_v_side;
   bf16_t *g_bf1, *g_bf2, *d_wide_s, *d_wide_t;       // a layer's weight-gradient operands stay intact until its grouped launch
   float *gh, *d_hn, *d_pc, *dq_total, *pdz, *pdu;
@@ -486,6 +514,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
     w.wg_partial_side = c.take<float>(ws2);
   }
   w.dw_scratch = c.take<float>((size_t)3 * D * D);
+  w.dw_scratch2 = c.take<float>((size_t)D * D); w.g1_bf = c.take<bf16_t>((size_t)D * D);
   w.cs = c.take<float>(max_sz(I, 3 * D));
   w.ln_partial = c.take<float>(sf_ln_bwd_partial_floats(t->D));
   w.cs_partial = c.take<float>(sf_colsum_partial_floats((int)max_sz(I, 3 * D)));
@@ -620,6 +649,9 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
     return sf_set_err(SF_ERR_INVALID, "drop_path factors were set for B=%d T=%d, the forward runs B=%d T=%d", t->dp_B, t->dp_T, B, T);
   const float* dp = t->dp_scales;
   const size_t dp_per_layer = (size_t)B * N + (size_t)B * T + (size_t)B;
+  // the temporal branch's two projections as one: only without drop_path / hidden dropout (both sit between them);
+  // SF_TRAIN_UNFUSED_TEMPORAL keeps the two launches (A/B, and the path the drop rates use)
+  const bool tfuse = !dp && !hd && sf_sw(SW_TRAIN_UNFUSED_TEMPORAL) == nullptr;
   for (int li = 0; li < t->L; ++li) {
     const TLayer& l = t->layers[li];
     const TSavedLayer& sv = ws.sl[li];
@@ -637,11 +669,16 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
       if (ad) a.drop = asite(li, 4);
       HIP_TRY(sf_launch_temporal_attention(a, false, s));
     }
+    if (tfuse) {
+      // h1 = h + ctx W_f^T + b_f: output.dense and temporal_dense (modeling:947-958) have nothing between them at drop rates 0
+      HIP_TRY(tgemm(sv.ctx_t, l.wf, l.bf, M, D, D, SF_EPI_RESID_F32, s, sv.h1, nullptr, h));
+    } else {
     HIP_TRY(lin_fwd(t, l.t_out, sv.ctx_t, M, SF_EPI_BF16, s, nullptr, sv.t_out));
     // drop_path (modeling:949) sits between the attention output and temporal_dense: the saved t_out IS the dropped tensor
     // hidden dropout of the temporal SelfOutput (modeling:761) rides on the same pass
     if (dp || hd) HIP_TRY(sf_launch_rowscale_bf16(sv.t_out, sv.t_out, dp ? dp + (size_t)li * dp_per_layer : nullptr, M, D, 0, T, N, s, site(li, 0)));
     HIP_TRY(lin_fwd(t, l.t_dense, sv.t_out, M, SF_EPI_RESID_F32, s, sv.h1, nullptr, h));      // h1 = h + tanh(g) * dense(.)
+    }
     // spatial attention (modeling:962-996)
     HIP_TRY(sf_launch_layernorm(sv.h1, PP(t, P0, l.ln_b_g), PP(t, P0, l.ln_b_b), nullptr, sv.ln_b, nullptr, M, D, eps, s));
     HIP_TRY(lin_fwd(t, l.s_qkv, sv.ln_b, M, SF_EPI_BF16, s, nullptr, sv.sqkv));
@@ -695,7 +732,7 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
   HIP_TRY(lin_fwd(t, t->fc1, ws.hn, F, SF_EPI_BF16, s, nullptr, ws.hm_pre));
   HIP_TRY(sf_launch_gelu_fwd(ws.hm_pre, ws.hm, (size_t)F * I, s));
   HIP_TRY(lin_fwd(t, t->fc2, ws.hm, F, SF_EPI_RESID_F32, s, pooler, nullptr, ws.attn_out));
-  t->fB = B; t->fT = T; t->f_dp = dp;
+  t->fB = B; t->fT = T; t->f_dp = dp; t->f_tfuse = tfuse;
   t->f_drop_hidden = t->drop_hidden; t->f_drop_attn = t->drop_attn; t->f_drop_seed = t->drop_seed;
   return SF_OK;
 }
@@ -813,6 +850,32 @@ static hipError_t lin_wgrad_queued(const BwdCtx& c, LayerWgrads& q, const TLin& 
   return hipSuccess;
 }
 
+// Gradients of the fused temporal projections from G1 = g^T ctx (ws.dw_scratch, fp32 [D, D]) and cs = colsum g (ws.cs):
+//   G = g^T t_out = G1 W_o^T + cs b_o^T  ->  dW_d += tanh(g) G, db_d += tanh(g) cs, dgate += (1 - tanh^2)(<G, W_d> + <cs, b_d>)
+//   dW_o += (tanh(g) W_d)^T G1,  db_o += (tanh(g) W_d)^T cs                    (all D x D; bf16 operands like every backward GEMM)
+static hipError_t temporal_fused_grads(const BwdCtx& c, const TLayer& l, int D) {
+  const sf_trainer* t = c.t;
+  const TWs& ws = *c.ws;
+  const float* P0 = t->params_dev;
+  hipStream_t s = c.s;
+  hipError_t e;
+  if ((e = sf_launch_split(ws.dw_scratch, ws.g1_bf, nullptr, (size_t)D * D, s)) != hipSuccess) return e;
+  if ((e = tgemm(ws.g1_bf, l.t_out.w, nullptr, D, D, D, SF_EPI_F32, s, ws.dw_scratch2, nullptr)) != hipSuccess) return e;
+  if ((e = sf_launch_gate_grad(ws.dw_scratch2, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
+                               GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s,
+                               PP(t, P0, l.t_out.pb))) != hipSuccess) return e;
+  if (float* gwo = GG(t, c.grads, l.t_out.pw)) {
+    SfWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = l.t_dense.w; a.ldy = D; a.x = ws.g1_bf; a.ldx = D; a.M = D; a.N1 = D; a.N2 = D; a.out = gwo; a.ldo = D; a.accumulate = 1; a.alpha = 1.f;
+    a.partial = c.wg_partial();
+    if ((e = sf_launch_wgrad(a, s)) != hipSuccess) return e;
+  }
+  if (float* gbo = GG(t, c.grads, l.t_out.pb))
+    if ((e = sf_launch_matvec_t_bf16(l.t_dense.w, D, ws.cs, gbo, D, D, s)) != hipSuccess) return e;
+  return hipSuccess;
+}
+
 // the side stream of the LoRA gradients: created on first use; SF_TRAIN_SIDE_STREAM=0 keeps everything on the caller's stream (A/B)
 static bool side_stream_ready(sf_trainer* t) {
   if (t->side_state == 0) {
@@ -901,10 +964,36 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   HIP_TRY(sf_launch_ln_bwd(sv.h1, ws.d_ln_bf, 1, PP(t, P0, l.ln_b_g), ws.g, ws.g, ws.g_bf2, GG(t, c.grads, l.ln_b_g), GG(t, c.grads, l.ln_b_b),
                            ws.ln_partial, M, D, eps, s));
   // ---- temporal: h1 = h + tanh(gate) * dense(out(attn(qkv(LN_t(h))))) ----------------------------------------
+  const bool tfuse = t->f_tfuse;
+  bool dense_queued = false;
+  HIP_TRY(hipMemsetAsync(ws.cs, 0, (size_t)D * sizeof(float), s));
+  if (tfuse) {
+    // forward ran h1 = h + ctx W_f^T + b_f with W_f = tanh(g) W_d W_o.  One input-gradient GEMM, d_ctx = g W_f, and ONE token-
+    // contracting GEMM, G1 = g^T ctx [D, D] (+ cs = colsum g): everything else is D x D algebra after the grouped launch —
+    //   g^T t_out = G1 W_o^T + cs b_o^T (-> dW_d, db_d, dgate as before),  dW_o = (tanh(g) W_d)^T G1,  db_o = (tanh(g) W_d)^T cs
+    HIP_TRY(tgemm(ws.g_bf2, l.wfT, nullptr, M, D, D, SF_EPI_BF16, s, nullptr, ws.d_ctx));
+    SfWgradJob* J = nullptr;
+    SfWgradGroup lone;
+    if (q.on && sf_wgrad_groupable(M, D, D) && q.g.njobs < SF_WG_MAX_JOBS) { J = &q.g.job[q.g.njobs++]; dense_queued = true; }
+    else { memset(&lone, 0, sizeof(lone)); lone.njobs = 1; lone.M = M; lone.partial = ws.wg_partial; J = &lone.job[0]; }
+    memset(J, 0, sizeof(*J));
+    J->dy = ws.g_bf2; J->x = sv.ctx_t; J->ldy = D; J->ldx = D; J->N1 = D; J->N2 = D; J->ldo = D; J->alpha = 1.f; J->accumulate = 0;
+    J->out = ws.dw_scratch; J->dbias = ws.cs;
+    if (!dense_queued) {
+      if (sf_wgrad_groupable(M, D, D)) HIP_TRY(sf_launch_wgrad_group(lone, s));
+      else {
+        SfWgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dy = ws.g_bf2; a.ldy = D; a.x = sv.ctx_t; a.ldx = D; a.M = M; a.N1 = D; a.N2 = D; a.ldo = D; a.alpha = 1.f;
+        a.partial = ws.wg_partial; a.out = ws.dw_scratch; a.accumulate = 0; a.dbias = ws.cs; a.dbias_scratch = ws.cs_partial;
+        HIP_TRY(sf_launch_wgrad(a, s));
+      }
+      HIP_TRY(temporal_fused_grads(c, l, D));
+    }
+  } else {
   HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf2, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
   // unscaled G = g^T t_out and column sums -> dW, db, dgate (see sf_launch_gate_grad, after the grouped launch)
-  HIP_TRY(hipMemsetAsync(ws.cs, 0, (size_t)D * sizeof(float), s));
-  const bool dense_queued = q.on && sf_wgrad_groupable(M, D, D) && q.g.njobs < SF_WG_MAX_JOBS;
+  dense_queued = q.on && sf_wgrad_groupable(M, D, D) && q.g.njobs < SF_WG_MAX_JOBS;
   if (dense_queued) {
     SfWgradJob& J = q.g.job[q.g.njobs++];
     memset(&J, 0, sizeof(J));
@@ -923,6 +1012,7 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   if (dp || hd) HIP_TRY(sf_launch_rowscale_bf16(ws.d_tout, ws.d_tout, dp, M, D, 0, T, N, s, site(0)));     // through the drop_path / dropout in front of temporal_dense
   HIP_TRY(lin_dgrad(l.t_out, ws.d_tout, M, s, nullptr, ws.d_ctx));
   HIP_TRY(lin_wgrad_queued(c, q, l.t_out, ws.d_tout, sv.ctx_t, M));
+  }
   {
     SfAttnBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -935,7 +1025,8 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   HIP_TRY(lin_wgrad_queued(c, q, l.t_qkv, ws.d_wide_t, sv.ln_t, M));
   HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide_t, M, s, nullptr, ws.d_ln_bf));
   if (q.g.njobs > 0) HIP_TRY(sf_launch_wgrad_group(q.g, s));
-  if (dense_queued)
+  if (dense_queued && tfuse) HIP_TRY(temporal_fused_grads(c, l, D));
+  if (dense_queued && !tfuse)
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
                                 GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln_bf, 1, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),

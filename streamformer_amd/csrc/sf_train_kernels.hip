@@ -597,13 +597,18 @@ hipError_t sf_launch_head_query_bwd(const float* dq, const float* probe, const f
 __global__ __launch_bounds__(256) void sf_gate_grad_kernel(const float* __restrict__ G, const float* __restrict__ cs,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const float* gate, float* d_w, float* d_b, float* partial, int N,
-                                                           int K) {
+                                                           int K, const float* __restrict__ r1) {
   __shared__ float red[4];
   const float t = tanhf(*gate);
   float dot = 0.f;
   const size_t nv = ((size_t)N * K) >> 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)GATE_BLOCKS * 256) {
-    const f32x4_t g = reinterpret_cast<const f32x4_t*>(G)[i];
+    f32x4_t g = reinterpret_cast<const f32x4_t*>(G)[i];
+    if (r1) {          // G_eff = G + cs (x) r1: the bias term of the fused temporal projections (g^T t_out = G1 W_o^T + cs b_o^T)
+      const size_t e = i << 2;
+      const int n = (int)(e / (size_t)K), k = (int)(e - (size_t)n * K);
+      g += cs[n] * *reinterpret_cast<const f32x4_t*>(r1 + k);
+    }
     const f32x4_t ww = reinterpret_cast<const f32x4_t*>(w)[i];
     dot += (g[0] * ww[0] + g[1] * ww[1]) + (g[2] * ww[2] + g[3] * ww[3]);
     if (d_w) {
@@ -635,10 +640,76 @@ __global__ __launch_bounds__(64) void sf_gate_grad_finish_kernel(const float* __
   }
 }
 hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, const float* b, const float* gate,
-                               float* d_w, float* d_b, float* d_gate, float* partial, int N, int K, hipStream_t s) {
-  if (((size_t)N * K) % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sf_gate_grad_kernel, dim3(GATE_BLOCKS), dim3(256), 0, s, G, cs, w, b, gate, d_w, d_b, partial, N, K);
+                               float* d_w, float* d_b, float* d_gate, float* partial, int N, int K, hipStream_t s, const float* r1) {
+  if (((size_t)N * K) % 4 || (K % 4)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_gate_grad_kernel, dim3(GATE_BLOCKS), dim3(256), 0, s, G, cs, w, b, gate, d_w, d_b, partial, N, K, r1);
   hipLaunchKernelGGL(sf_gate_grad_finish_kernel, dim3(1), dim3(64), 0, s, partial, gate, d_gate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// temporal_dense o temporal_attention.output.dense as ONE projection in the training step (modeling:947-958: two Linear layers with
+// nothing in between at drop rates 0):  W_f = tanh(g) W_d W_o,  b_f = tanh(g) (W_d b_o + b_d).
+// sf_fuse_temporal_kernel: W_f[i][j] = sum_k wd[i][k] woT[j][k] from the bf16 working copies (wd carries tanh(g) already; woT is the
+// transposed copy of W_o), one 16 x 16 tile per wave, written as wf [D, D] (forward operand) and wfT [D, D] (input-gradient operand).
+// grid (D/16 * D/16 / 4, layers)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 v8bf_tk;
+__global__ __launch_bounds__(256) void sf_fuse_temporal_kernel(const SfFuseJob* __restrict__ jobs, int D) {
+  const SfFuseJob J = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int tn = D >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tn * tn) return;
+  const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16;
+  const bf16_t* ar = J.woT + (size_t)(j0 + l15) * D + g * 8;      // A operand rows: j
+  const bf16_t* br = J.wd + (size_t)(i0 + l15) * D + g * 8;       // B operand rows: i
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < D; k += 64) {                                // D % 64 == 0: two k-steps per trip, loads first
+    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ar + k), a1 = *reinterpret_cast<const bf16x8_t*>(ar + k + 32);
+    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(br + k), b1 = *reinterpret_cast<const bf16x8_t*>(br + k + 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_tk, a0), __builtin_bit_cast(v8bf_tk, b0), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_tk, a1), __builtin_bit_cast(v8bf_tk, b1), acc, 0, 0, 0);
+  }
+  // lane: W_f[i0 + l15][j0 + 4g + jj], jj = 0..3
+  const int i = i0 + l15, j = j0 + 4 * g;
+  *reinterpret_cast<u32x2_t*>(J.wf + (size_t)i * D + j) = (u32x2_t){pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) J.wfT[(size_t)(j + jj) * D + i] = (bf16_t)f2bf(acc[jj]);
+}
+// b_f[i] = tanh(g) (sum_k W_d[i][k] b_o[k] + b_d[i]) from the fp32 parameters; grid (D / 4, layers), one wave per row
+__global__ __launch_bounds__(256) void sf_fuse_temporal_bias_kernel(const float* __restrict__ base, const SfFuseJob* __restrict__ jobs, int D) {
+  const SfFuseJob J = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= D) return;
+  const float* wd = base + J.wd_off + (size_t)i * D;
+  const float* bo = base + J.bo_off;
+  float t = 0.f;
+  for (int k = lane; k < D; k += 64) t = fmaf(wd[k], bo[k], t);
+  t = wave_sum(t);
+  if (lane == 0) J.bf[i] = tanhf(base[J.gate_off]) * (t + base[J.bd_off + i]);
+}
+hipError_t sf_launch_fuse_temporal(const float* base, const SfFuseJob* jobs_dev, int layers, int D, hipStream_t s) {
+  if (layers <= 0) return hipSuccess;
+  if (D % 64) return hipErrorInvalidValue;
+  const int tiles = (D / 16) * (D / 16);
+  hipLaunchKernelGGL(sf_fuse_temporal_kernel, dim3((tiles + 3) / 4, layers), dim3(256), 0, s, jobs_dev, D);
+  hipLaunchKernelGGL(sf_fuse_temporal_bias_kernel, dim3((D + 3) / 4, layers), dim3(256), 0, s, base, jobs_dev, D);
+  return hipGetLastError();
+}
+// out[k] += sum_i w[i * ld + k] * v[i]   (w bf16 [rows, ld]): db_o = (tanh(g) W_d)^T colsum(g) of the fused temporal projections
+__global__ __launch_bounds__(256) void sf_matvec_t_bf16_kernel(const bf16_t* __restrict__ w, int ld, const float* __restrict__ v, float* __restrict__ out,
+                                                               int rows, int cols) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= cols) return;
+  float t = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < rows; ++i) t = fmaf(bf2f(w[(size_t)i * ld + k]), v[i], t);
+  out[k] += t;
+}
+hipError_t sf_launch_matvec_t_bf16(const bf16_t* w, int ld, const float* v, float* out, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(sf_matvec_t_bf16_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w, ld, v, out, rows, cols);
   return hipGetLastError();
 }
 

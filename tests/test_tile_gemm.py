@@ -139,4 +139,7 @@ def test_grouped_weight_gradients_equal_the_per_projection_launches(tmp_path, lo
     assert a[0]["loss"] == b[0]["loss"]            # the forward is the same code
     for n in a[1]:
         rel = float((a[1][n].double() - b[1][n].double()).norm() / (b[1][n].double().norm() + 1e-30))
-        assert rel < 1e-5, (n, rel)
+        # the fused temporal projections (round 5) derive dW_dense / dW_out / dgate from G1 = g^T ctx through D x D GEMMs with bf16
+        # operands: a last-bit difference of G1's token-split sums can flip the bf16 rounding of a few of its elements
+        fused = any(k in n for k in ("temporal_dense", "temporal_attention.output.dense", "temporal_attention_gating"))
+        assert rel < (2e-4 if fused else 1e-5), (n, rel)
