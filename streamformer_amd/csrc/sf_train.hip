@@ -93,6 +93,10 @@ struct sf_trainer {
   // side stream, forked from and joined into the caller's stream inside every layer: they fill the gaps of the MFMA-bound chain.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // D x D gradient algebra of the fused temporal projections (six small launches per layer): also on the side stream, joined one
+  // layer LATER (its inputs G1 / cs alternate between two buffers by layer parity), and before sf_trainer_backward returns
+  hipEvent_t ev_small[2] = {nullptr, nullptr};
+  int small_pending = 0;              // bit p: ev_small[p] has been recorded and not yet waited for
   int side_state = 0;                 // 0 = not tried, 1 = available, -1 = unavailable (creation failed / SF_TRAIN_SIDE_STREAM=0)
 };
 
@@ -344,6 +348,7 @@ extern "C" void sf_trainer_destroy(sf_trainer* t) {
   if (t->side) (void)hipStreamDestroy(t->side);
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  for (hipEvent_t e : t->ev_small) if (e) (void)hipEventDestroy(e);
   delete t;
 }
 
@@ -448,6 +453,7 @@ struct TWs {
   bf16_t *g_bf, *d_wide, *d_ctx, *d_tout, *lora_u, *lora_v;
   float *wg_partial_side, *cs_partial_side;          // the side stream's own scratch (LoRA gradients, see sf_trainer::side)
   float* dw_scratch2; bf16_t* g1_bf;                 // fused temporal projections: g^T t_out [D, D] fp32 and bf16(g^T ctx) [D, D]
+  float *g1_alt, *cs_alt;                            // second G1 / cs buffers: layers alternate, the side stream reads one layer behind
   bf16_t *lora_u_side, *lora_v_side;
   bf16_t *g_bf1, *g_bf2, *d_wide_s, *d_wide_t;       // a layer's weight-gradient operands stay intact until its grouped launch
   float *gh, *d_hn, *d_pc, *dq_total, *pdz, *pdu;
@@ -515,6 +521,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   }
   w.dw_scratch = c.take<float>((size_t)3 * D * D);
   w.dw_scratch2 = c.take<float>((size_t)D * D); w.g1_bf = c.take<bf16_t>((size_t)D * D);
+  w.g1_alt = c.take<float>((size_t)D * D); w.cs_alt = c.take<float>(max_sz(I, 3 * D));
   w.cs = c.take<float>(max_sz(I, 3 * D));
   w.ln_partial = c.take<float>(sf_ln_bwd_partial_floats(t->D));
   w.cs_partial = c.take<float>(sf_colsum_partial_floats((int)max_sz(I, 3 * D)));
@@ -853,15 +860,15 @@ static hipError_t lin_wgrad_queued(const BwdCtx& c, LayerWgrads& q, const TLin& 
 // Gradients of the fused temporal projections from G1 = g^T ctx (ws.dw_scratch, fp32 [D, D]) and cs = colsum g (ws.cs):
 //   G = g^T t_out = G1 W_o^T + cs b_o^T  ->  dW_d += tanh(g) G, db_d += tanh(g) cs, dgate += (1 - tanh^2)(<G, W_d> + <cs, b_d>)
 //   dW_o += (tanh(g) W_d)^T G1,  db_o += (tanh(g) W_d)^T cs                    (all D x D; bf16 operands like every backward GEMM)
-static hipError_t temporal_fused_grads(const BwdCtx& c, const TLayer& l, int D) {
+static hipError_t temporal_fused_grads(const BwdCtx& c, const TLayer& l, int D, const float* g1, const float* cs) {
   const sf_trainer* t = c.t;
   const TWs& ws = *c.ws;
   const float* P0 = t->params_dev;
   hipStream_t s = c.s;
   hipError_t e;
-  if ((e = sf_launch_split(ws.dw_scratch, ws.g1_bf, nullptr, (size_t)D * D, s)) != hipSuccess) return e;
+  if ((e = sf_launch_split(g1, ws.g1_bf, nullptr, (size_t)D * D, s)) != hipSuccess) return e;
   if ((e = tgemm(ws.g1_bf, l.t_out.w, nullptr, D, D, D, SF_EPI_F32, s, ws.dw_scratch2, nullptr)) != hipSuccess) return e;
-  if ((e = sf_launch_gate_grad(ws.dw_scratch2, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
+  if ((e = sf_launch_gate_grad(ws.dw_scratch2, cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
                                GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s,
                                PP(t, P0, l.t_out.pb))) != hipSuccess) return e;
   if (float* gwo = GG(t, c.grads, l.t_out.pw)) {
@@ -872,7 +879,7 @@ static hipError_t temporal_fused_grads(const BwdCtx& c, const TLayer& l, int D) 
     if ((e = sf_launch_wgrad(a, s)) != hipSuccess) return e;
   }
   if (float* gbo = GG(t, c.grads, l.t_out.pb))
-    if ((e = sf_launch_matvec_t_bf16(l.t_dense.w, D, ws.cs, gbo, D, D, s)) != hipSuccess) return e;
+    if ((e = sf_launch_matvec_t_bf16(l.t_dense.w, D, cs, gbo, D, D, s)) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -883,7 +890,9 @@ static bool side_stream_ready(sf_trainer* t) {
     t->side_state = -1;
     if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess &&
         hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) == hipSuccess)
+        hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&t->ev_small[0], hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&t->ev_small[1], hipEventDisableTiming) == hipSuccess)
       t->side_state = 1;
   }
   return t->side_state == 1;
@@ -966,7 +975,10 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   // ---- temporal: h1 = h + tanh(gate) * dense(out(attn(qkv(LN_t(h))))) ----------------------------------------
   const bool tfuse = t->f_tfuse;
   bool dense_queued = false;
-  HIP_TRY(hipMemsetAsync(ws.cs, 0, (size_t)D * sizeof(float), s));
+  const int par = li & 1;
+  float* const g1buf = (tfuse && par) ? ws.g1_alt : ws.dw_scratch;      // fused path: G1 / cs alternate by layer parity
+  float* const csbuf = (tfuse && par) ? ws.cs_alt : ws.cs;
+  HIP_TRY(hipMemsetAsync(csbuf, 0, (size_t)D * sizeof(float), s));
   if (tfuse) {
     // forward ran h1 = h + ctx W_f^T + b_f with W_f = tanh(g) W_d W_o.  One input-gradient GEMM, d_ctx = g W_f, and ONE token-
     // contracting GEMM, G1 = g^T ctx [D, D] (+ cs = colsum g): everything else is D x D algebra after the grouped launch —
@@ -978,17 +990,17 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
     else { memset(&lone, 0, sizeof(lone)); lone.njobs = 1; lone.M = M; lone.partial = ws.wg_partial; J = &lone.job[0]; }
     memset(J, 0, sizeof(*J));
     J->dy = ws.g_bf2; J->x = sv.ctx_t; J->ldy = D; J->ldx = D; J->N1 = D; J->N2 = D; J->ldo = D; J->alpha = 1.f; J->accumulate = 0;
-    J->out = ws.dw_scratch; J->dbias = ws.cs;
+    J->out = g1buf; J->dbias = csbuf;
     if (!dense_queued) {
       if (sf_wgrad_groupable(M, D, D)) HIP_TRY(sf_launch_wgrad_group(lone, s));
       else {
         SfWgradArgs a;
         memset(&a, 0, sizeof(a));
         a.dy = ws.g_bf2; a.ldy = D; a.x = sv.ctx_t; a.ldx = D; a.M = M; a.N1 = D; a.N2 = D; a.ldo = D; a.alpha = 1.f;
-        a.partial = ws.wg_partial; a.out = ws.dw_scratch; a.accumulate = 0; a.dbias = ws.cs; a.dbias_scratch = ws.cs_partial;
+        a.partial = ws.wg_partial; a.out = g1buf; a.accumulate = 0; a.dbias = csbuf; a.dbias_scratch = ws.cs_partial;
         HIP_TRY(sf_launch_wgrad(a, s));
       }
-      HIP_TRY(temporal_fused_grads(c, l, D));
+      HIP_TRY(temporal_fused_grads(c, l, D, g1buf, csbuf));
     }
   } else {
   HIP_TRY(lin_dgrad(l.t_dense, ws.g_bf2, M, s, nullptr, ws.d_tout));               // wT already carries tanh(gate)
@@ -1025,13 +1037,43 @@ static int backward_layer(const BwdCtx& c, int li, int B, int T) {
   HIP_TRY(lin_wgrad_queued(c, q, l.t_qkv, ws.d_wide_t, sv.ln_t, M));
   HIP_TRY(lin_dgrad(l.t_qkv, ws.d_wide_t, M, s, nullptr, ws.d_ln_bf));
   if (q.g.njobs > 0) HIP_TRY(sf_launch_wgrad_group(q.g, s));
-  if (dense_queued && tfuse) HIP_TRY(temporal_fused_grads(c, l, D));
+  bool small_forked = false;
+  if (dense_queued && tfuse) {
+    sf_trainer* tm = const_cast<sf_trainer*>(t);
+    if (side_ok && side_stream_ready(tm)) {
+      // on the side stream, behind the grouped launch; joined one layer later (small_join) — the LoRA work enqueued before it is
+      // marked complete first (ev_join), so that the end-of-layer join below does not wait for these launches
+      if (forked) HIP_TRY(hipEventRecord(tm->ev_join, tm->side));
+      HIP_TRY(hipEventRecord(tm->ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(tm->side, tm->ev_fork, 0));
+      BwdCtx cs2 = c;
+      cs2.s = tm->side; cs2.on_side = true;
+      HIP_TRY(temporal_fused_grads(cs2, l, D, g1buf, csbuf));
+      HIP_TRY(hipEventRecord(tm->ev_small[par], tm->side));
+      tm->small_pending |= 1 << par;
+      small_forked = true;
+    } else {
+      HIP_TRY(temporal_fused_grads(c, l, D, g1buf, csbuf));
+    }
+  }
   if (dense_queued && !tfuse)
     HIP_TRY(sf_launch_gate_grad(ws.dw_scratch, ws.cs, PP(t, P0, l.t_dense.pw), PP(t, P0, l.t_dense.pb), PP(t, P0, l.gate),
                                 GG(t, c.grads, l.t_dense.pw), GG(t, c.grads, l.t_dense.pb), GG(t, c.grads, l.gate), t->red_partial, D, D, s));
   HIP_TRY(sf_launch_ln_bwd(ws.h[li], ws.d_ln_bf, 1, PP(t, P0, l.ln_t_g), ws.g, ws.g, ws.g_bf, GG(t, c.grads, l.ln_t_g), GG(t, c.grads, l.ln_t_b),
                            ws.ln_partial, M, D, eps, s));
-  if (forked) HIP_TRY(side_join(c));   // the layer's gradient slice is complete in the caller's stream order from here on
+  if (forked) {
+    sf_trainer* tm = const_cast<sf_trainer*>(t);
+    if (small_forked) HIP_TRY(hipStreamWaitEvent(s, tm->ev_join, 0));      // recorded above, in front of the small launches
+    else HIP_TRY(side_join(c));
+  }
+  {   // the PREVIOUS layer's D x D algebra (other parity) must be done before the next layer reuses its G1 / cs buffers
+    sf_trainer* tm = const_cast<sf_trainer*>(t);
+    const int other = par ^ 1;
+    if (tm->small_pending & (1 << other)) {
+      HIP_TRY(hipStreamWaitEvent(s, tm->ev_small[other], 0));
+      tm->small_pending &= ~(1 << other);
+    }
+  }
   return SF_OK;
 }
 
@@ -1078,6 +1120,13 @@ extern "C" int sf_trainer_backward(sf_trainer* t, const float* d_pooler, const f
     else rc = backward_layer(c, t->L - st, B, T);
     if (rc) return rc;
   }
+  // every gradient slice of the stages just run must be complete in the caller's stream order when this call returns (the
+  // caller all-reduces them): join what is still on the side stream
+  for (int p = 0; p < 2; ++p)
+    if (t->small_pending & (1 << p)) {
+      HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, t->ev_small[p], 0));
+      t->small_pending &= ~(1 << p);
+    }
   return SF_OK;
 }
 

@@ -142,4 +142,5 @@ def test_grouped_weight_gradients_equal_the_per_projection_launches(tmp_path, lo
         # the fused temporal projections (round 5) derive dW_dense / dW_out / dgate from G1 = g^T ctx through D x D GEMMs with bf16
         # operands: a last-bit difference of G1's token-split sums can flip the bf16 rounding of a few of its elements
         fused = any(k in n for k in ("temporal_dense", "temporal_attention.output.dense", "temporal_attention_gating"))
-        assert rel < (2e-4 if fused else 1e-5), (n, rel)
+        # (the gate is a 0-dim parameter whose gradient is a cancelling sum over D x D products: 1e-3)
+        assert rel < ((1e-3 if "gating" in n else 2e-4) if fused else 1e-5), (n, rel)
