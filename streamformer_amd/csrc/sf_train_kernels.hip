@@ -655,28 +655,46 @@ hipError_t sf_launch_gate_grad(const float* G, const float* cs, const float* w, 
 // grid (D/16 * D/16 / 4, layers)
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 v8bf_tk;
+SF_DEVICE f32x4_t tk_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_tk, a), __builtin_bit_cast(v8bf_tk, b), c, 0, 0, 0);
+}
+// a wave computes a 16 (i) x 64 (j) strip: the wd fragment is shared by four MFMAs, ten loads per trip are in flight
 __global__ __launch_bounds__(256) void sf_fuse_temporal_kernel(const SfFuseJob* __restrict__ jobs, int D) {
   const SfFuseJob J = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int tn = D >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tn * tn) return;
-  const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16;
-  const bf16_t* ar = J.woT + (size_t)(j0 + l15) * D + g * 8;      // A operand rows: j
+  const int sj = D >> 6, si = D >> 4;           // strips along j, along i
+  const int strip = blockIdx.x * 4 + wave;
+  if (strip >= si * sj) return;
+  const int i0 = (strip / sj) * 16, j0 = (strip % sj) * 64;
   const bf16_t* br = J.wd + (size_t)(i0 + l15) * D + g * 8;       // B operand rows: i
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < D; k += 64) {                                // D % 64 == 0: two k-steps per trip, loads first
-    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ar + k), a1 = *reinterpret_cast<const bf16x8_t*>(ar + k + 32);
-    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(br + k), b1 = *reinterpret_cast<const bf16x8_t*>(br + k + 32);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_tk, a0), __builtin_bit_cast(v8bf_tk, b0), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_tk, a1), __builtin_bit_cast(v8bf_tk, b1), acc, 0, 0, 0);
-  }
-  // lane: W_f[i0 + l15][j0 + 4g + jj], jj = 0..3
-  const int i = i0 + l15, j = j0 + 4 * g;
-  *reinterpret_cast<u32x2_t*>(J.wf + (size_t)i * D + j) = (u32x2_t){pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+  const bf16_t* ar = J.woT + (size_t)(j0 + l15) * D + g * 8;      // A operand rows: j (four 16-row tiles, 16 D apart)
+  f32x4_t acc[4];
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) J.wfT[(size_t)(j + jj) * D + i] = (bf16_t)f2bf(acc[jj]);
+  for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < D; k += 64) {                                // D % 64 == 0: two k-steps per trip, loads first
+    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(br + k), b1 = *reinterpret_cast<const bf16x8_t*>(br + k + 32);
+    bf16x8_t a0[4], a1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a0[q] = *reinterpret_cast<const bf16x8_t*>(ar + (size_t)q * 16 * D + k);
+      a1[q] = *reinterpret_cast<const bf16x8_t*>(ar + (size_t)q * 16 * D + k + 32);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = tk_mfma(a0[q], b0, acc[q]);
+      acc[q] = tk_mfma(a1[q], b1, acc[q]);
+    }
+  }
+  // lane: W_f[i0 + l15][j0 + 16 q + 4g + jj], jj = 0..3
+  const int i = i0 + l15;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = j0 + 16 * q + 4 * g;
+    *reinterpret_cast<u32x2_t*>(J.wf + (size_t)i * D + j) = (u32x2_t){pack_bf2(acc[q][0], acc[q][1]), pack_bf2(acc[q][2], acc[q][3])};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) J.wfT[(size_t)(j + jj) * D + i] = (bf16_t)f2bf(acc[q][jj]);
+  }
 }
 // b_f[i] = tanh(g) (sum_k W_d[i][k] b_o[k] + b_d[i]) from the fp32 parameters; grid (D / 4, layers), one wave per row
 __global__ __launch_bounds__(256) void sf_fuse_temporal_bias_kernel(const float* __restrict__ base, const SfFuseJob* __restrict__ jobs, int D) {
@@ -693,23 +711,32 @@ __global__ __launch_bounds__(256) void sf_fuse_temporal_bias_kernel(const float*
 hipError_t sf_launch_fuse_temporal(const float* base, const SfFuseJob* jobs_dev, int layers, int D, hipStream_t s) {
   if (layers <= 0) return hipSuccess;
   if (D % 64) return hipErrorInvalidValue;
-  const int tiles = (D / 16) * (D / 16);
-  hipLaunchKernelGGL(sf_fuse_temporal_kernel, dim3((tiles + 3) / 4, layers), dim3(256), 0, s, jobs_dev, D);
+  const int strips = (D / 16) * (D / 64);
+  hipLaunchKernelGGL(sf_fuse_temporal_kernel, dim3((strips + 3) / 4, layers), dim3(256), 0, s, jobs_dev, D);
   hipLaunchKernelGGL(sf_fuse_temporal_bias_kernel, dim3((D + 3) / 4, layers), dim3(256), 0, s, base, jobs_dev, D);
   return hipGetLastError();
 }
 // out[k] += sum_i w[i * ld + k] * v[i]   (w bf16 [rows, ld]): db_o = (tanh(g) W_d)^T colsum(g) of the fused temporal projections
-__global__ __launch_bounds__(256) void sf_matvec_t_bf16_kernel(const bf16_t* __restrict__ w, int ld, const float* __restrict__ v, float* __restrict__ out,
-                                                               int rows, int cols) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= cols) return;
+__global__ __launch_bounds__(1024) void sf_matvec_t_bf16_kernel(const bf16_t* __restrict__ w, int ld, const float* __restrict__ v, float* __restrict__ out,
+                                                                int rows, int cols) {
+  __shared__ float part[16][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;        // 64 columns x 16 row groups, partial sums met in a fixed order
+  const int k = blockIdx.x * 64 + c;
   float t = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < rows; ++i) t = fmaf(bf2f(w[(size_t)i * ld + k]), v[i], t);
-  out[k] += t;
+  if (k < cols)
+#pragma unroll 4
+    for (int i = rg; i < rows; i += 16) t = fmaf(bf2f(w[(size_t)i * ld + k]), v[i], t);
+  part[rg][c] = t;
+  __syncthreads();
+  if (rg == 0 && k < cols) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += part[r][c];
+    out[k] += a;
+  }
 }
 hipError_t sf_launch_matvec_t_bf16(const bf16_t* w, int ld, const float* v, float* out, int rows, int cols, hipStream_t s) {
-  hipLaunchKernelGGL(sf_matvec_t_bf16_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w, ld, v, out, rows, cols);
+  hipLaunchKernelGGL(sf_matvec_t_bf16_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, w, ld, v, out, rows, cols);
   return hipGetLastError();
 }
 
