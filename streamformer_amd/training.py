@@ -631,7 +631,9 @@ class StreamformerTrainer:
         The heads read ``logit_scale`` / ``logit_bias`` straight from the flat parameter buffer on the device:
         nothing here synchronises with the host, so the next micro-step can be enqueued behind this one.
         Retrieval with world > 1 uses every rank's captions as negatives (the reference's distributed SigLipLoss,
-        modeling:239-297) unless ``task_input["gather_negatives"]`` is False."""
+        modeling:239-297) unless ``task_input["gather_negatives"]`` is False.
+        Localization takes either one table for the whole batch (``label_emb`` [L, D]) or, as the reference head does, a dataset
+        name per clip (``datasets``: B names, ``label_embs``: {name: [L_name, D]}) with tables of different sizes."""
         from .heads import LocalizationHead, RetrievalHead
         ls, lb = self._view(f"task_heads.{task}.logit_scale"), self._view(f"task_heads.{task}.logit_bias")
         if task_input["kind"] == "retrieval":
@@ -642,6 +644,33 @@ class StreamformerTrainer:
                 text = all_gather_rows(text.contiguous(), group=self.group, at_world_1=True)
                 rank = self.rank
             return RetrievalHead(ls, lb).loss(pooler, text, rank=rank)
+        if "datasets" in task_input:
+            # The reference head walks the batch sample by sample with each clip's own dataset table (modeling:2250-2276: tables of
+            # different L in one batch): group the clips by dataset, one loss launch per table on that group's rows, weighted by the
+            # group's share of the batch — loss = mean over clips — and scatter the gradients back to the clips' rows.
+            names = list(task_input["datasets"])
+            tables = task_input["label_embs"]
+            labels = task_input["labels"]
+            B = pooler.shape[0]
+            if len(names) != B:
+                raise ValueError(f"{len(names)} dataset names for {B} clips")
+            loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            gp = torch.zeros_like(pooler, dtype=torch.float32)
+            gs = torch.zeros(2, dtype=torch.float32, device=self.device)
+            for name in dict.fromkeys(names):
+                idx = [i for i, d in enumerate(names) if d == name]
+                w = len(idx) / B
+                whole = len(idx) == B
+                ix = None if whole else torch.tensor(idx, device=self.device)
+                l_g, gp_g, gs_g = LocalizationHead(tables[name], ls, lb).loss(pooler if whole else pooler.index_select(0, ix),
+                                                                              labels if whole else labels.to(self.device).index_select(0, ix))
+                loss.add_(l_g, alpha=w)
+                gs.add_(gs_g, alpha=w)
+                if whole:
+                    gp.add_(gp_g, alpha=w)
+                else:
+                    gp.index_add_(0, ix, gp_g, alpha=w)
+            return loss, gp, gs
         return LocalizationHead(task_input["label_emb"], ls, lb).loss(pooler, task_input["labels"])
 
     def micro_step(self, task: str, pixel_values: torch.Tensor, task_input: dict, update_freq: int = 1,

@@ -777,6 +777,49 @@ def test_dropout_gradients_match_the_oracle_on_the_same_masks(task_idx, hid, att
     assert tr.last_dropout is None and abs(float(l3) - plain) < 2e-2 * abs(plain)
 
 
+def test_localization_batch_with_per_clip_dataset_tables():
+    """VERDICT r4 missing #4: the reference head walks the batch clip by clip with each clip's OWN dataset table — tables of different
+    sizes in one batch (modeling:2250-2276).  The fast trainer groups the clips by dataset (one loss launch per table, weighted by
+    the group's share) and scatters the gradients back: loss, d loss / d pooler_output and d loss / d (logit_scale, logit_bias)
+    against the oracle's per-clip restatement, and the whole micro-step's parameter gradients against its autograd."""
+    from oracle import streamformer_oracle as O
+    cfg = small_cfg(add_lora_spatial=True)
+    tr, orc = _trainer_and_oracle(cfg, True, seed=8, lora=True)
+    dev = tr.device
+    g = torch.Generator().manual_seed(77)
+    B, T, D = 5, 16, cfg.hidden_size
+    names = ["thumos", "tvseries", "thumos", "ek100", "tvseries"]
+    sizes = {"thumos": 21, "tvseries": 31, "ek100": 7}
+    tables = {}
+    for k, L in sizes.items():
+        e = torch.randn(L, D, generator=g)
+        tables[k] = e / e.norm(dim=-1, keepdim=True)
+    labels = torch.stack([torch.randint(-1, sizes[n], (T,), generator=g) for n in names])
+    x = torch.randn(B, T, 3, 48, 48, generator=g)
+    # ---- the head alone on a fixed pooler_output -------------------------------------------------------------------
+    pooler = torch.randn(B, T, D, generator=g)
+    ls, lb = torch.tensor(math.log(10.0), requires_grad=True), torch.tensor(-2.0, requires_grad=True)
+    pw = pooler.clone().requires_grad_(True)
+    want = sum(O.localization_loss(pw[i:i + 1], tables[n], labels[i:i + 1], ls, lb) for i, n in enumerate(names)) / B
+    want.backward()
+    ti = {"kind": "localization", "datasets": names, "label_embs": {k: v.to(dev) for k, v in tables.items()}, "labels": labels.to(dev)}
+    loss, gp, gs = tr.loss_and_grad("localization", pooler.to(dev), ti)
+    assert abs(float(loss) - float(want)) <= 2e-5 * abs(float(want))
+    assert float((gp.cpu() - pw.grad).abs().max()) <= 1e-6
+    assert abs(float(gs[0]) - float(ls.grad)) <= 2e-5 * abs(float(ls.grad)) + 1e-6 and abs(float(gs[1]) - float(lb.grad)) <= 2e-5 * abs(float(lb.grad)) + 1e-6
+    # ---- one whole micro-step: every parameter gradient against the oracle's autograd through the same per-clip loss ------------
+    out = O.forward_graph(orc.sd, cfg, x)
+    h = orc.heads["localization"]
+    want2 = sum(O.localization_loss(out["pooler_output"][i:i + 1], tables[n], labels[i:i + 1], h["logit_scale"], h["logit_bias"])
+                for i, n in enumerate(names)) / B
+    want2.backward()
+    tr.zero_grad()
+    l2 = tr.micro_step("localization", x.to(dev), ti, update_freq=2)       # update_freq 2: gradients stay in the buffer (scaled by 1/2)
+    assert abs(float(l2) - float(want2)) < 2e-2 * abs(float(want2))
+    tr.grads.mul_(2.0)
+    _compare_grads(tr, orc)
+
+
 def test_trainer_rejects_what_it_cannot_do():
     import streamformer_amd._native as nat
     from streamformer_amd.init_weights import make_state_dict
