@@ -13,6 +13,7 @@ struct SfPoolArgs {
   float* zpart;                            // [F, S, heads, D] weighted token sums of each split (normalised when S == 1)
   float* ml;                               // [F, S, heads, 2] {max score, sum of exp} per split (needed when S > 1)
   float* probs;                            // optional (S == 1): softmax probabilities [F, heads, N] fp32, kept for the backward
+  int probs_raw;                           // probs holds the RAW scores and ml the {max, sum} per head: the backward finishes the softmax itself
   int F, N, heads, D, S, normalize;
 };
 int sf_pool_splits(int F, int N, int heads);                       // token splits per frame the launcher wants for this shape
@@ -51,7 +52,9 @@ hipError_t sf_launch_pool_ctx_bwd(const float* dctx, const bf16_t* wT, int ldt, 
                                   float* dbv, int F, int heads, int D, hipStream_t s);
 struct SfPoolBwdArgs {
   const bf16_t* x_bf;                      // [F * N, D] bf16 normalised tokens
-  const float* probs;                      // [F, heads, N]
+  const float* probs;                      // [F, heads, N] probabilities, or (probs_raw) raw scores with ml = {max, sum} [F, heads, 2]
+  const float* ml; int probs_raw;          // ml [F, ml_splits, heads, 2] as the forward's token splits wrote it
+  int ml_splits;
   const float* z; const float* dz;         // [F, heads, D]
   const float* u;                          // [16, D] fp32
   const float* d_lhs;                      // optional [F * N, D]: gradient arriving through last_hidden_state, added to dx

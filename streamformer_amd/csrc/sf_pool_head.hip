@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void sf_pool_probe_kernel(SfPoolArgs p) {
     o[0] = stf[tid];
     o[1] = stf[16 + tid];
   }
-  if (p.probs) {      // raw scores (written by this workgroup above; S == 1) -> probabilities
+  if (p.probs && !p.probs_raw) {      // raw scores (written by this workgroup above; S == 1) -> probabilities
     __threadfence_block();
     __syncthreads();
     for (int i = tid; i < p.heads * nt; i += 256) {
@@ -261,7 +261,7 @@ size_t sf_pool_ml_floats(int F, int N, int heads) { return (size_t)F * sf_pool_s
 
 hipError_t sf_launch_pool_probe(const SfPoolArgs& a, hipStream_t s) {
   if (a.heads > 16 || a.D != a.heads * 64 || a.D > 1024 || a.F <= 0 || a.N <= 0 || a.S < 1) return hipErrorInvalidValue;
-  if ((a.normalize || a.probs) && a.S != 1) return hipErrorInvalidValue;
+  if ((a.normalize || (a.probs && !a.probs_raw)) && a.S != 1) return hipErrorInvalidValue;
   if (a.S > 1 && !a.ml) return hipErrorInvalidValue;
   const size_t lds = ((size_t)PCH * (a.D + 4) + 4 * 64 * 4 + 16 * PCH + 96) * sizeof(float) + (size_t)2 * 16 * (a.D + 8) * sizeof(bf16_t);
   const dim3 grid(a.F * a.S);
@@ -356,17 +356,26 @@ __global__ __launch_bounds__(256) void sf_pool_ctx_kernel(SfPoolCtxArgs p) {
         if (p.z_out && ct == 0) *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)f0 * p.heads + h) * D + e0 * 4) = v;
       }
     } else {
-      for (int e = tid; e < nf * nv4; e += 256) {
-        const int fr = e / nv4, c4 = e - fr * nv4;
-        const float* zr = p.zpart + (((size_t)(f0 + fr) * S) * p.heads + h) * D + c4 * 4;
-        f32x4_t pv[8];
+      const int tot = nf * nv4;
+      for (int e0b = 0; e0b < tot; e0b += 3 * 256) {       // three elements per thread and trip: 24 independent loads in flight
+        f32x4_t pv[3][8];
+        int fr3[3], c43[3];
 #pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx) pv[sidx] = *reinterpret_cast<const f32x4_t*>(zr + (size_t)(sidx < S ? sidx : 0) * p.heads * D);
-        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 3; ++u) {
+          const int e = e0b + u * 256 + tid < tot ? e0b + u * 256 + tid : tot - 1;        // past the end: the last element again
+          fr3[u] = e / nv4; c43[u] = e - fr3[u] * nv4;
+          const float* zr = p.zpart + (((size_t)(f0 + fr3[u]) * S) * p.heads + h) * D + c43[u] * 4;
 #pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx) v += (sidx < S ? wl[fr * 8 + sidx] : 0.f) * pv[sidx];
-        *reinterpret_cast<f32x4_t*>(zs + fr * ZP + c4 * 4) = v;
-        if (p.z_out && ct == 0) *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)(f0 + fr) * p.heads + h) * D + c4 * 4) = v;
+          for (int sidx = 0; sidx < 8; ++sidx) pv[u][sidx] = *reinterpret_cast<const f32x4_t*>(zr + (size_t)(sidx < S ? sidx : 0) * p.heads * D);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int sidx = 0; sidx < 8; ++sidx) v += (sidx < S ? wl[fr3[u] * 8 + sidx] : 0.f) * pv[u][sidx];
+          *reinterpret_cast<f32x4_t*>(zs + fr3[u] * ZP + c43[u] * 4) = v;       // a repeated last element rewrites the same value
+          if (p.z_out && ct == 0) *reinterpret_cast<f32x4_t*>(p.z_out + ((size_t)(f0 + fr3[u]) * p.heads + h) * D + c43[u] * 4) = v;
+        }
       }
     }
     __syncthreads();
@@ -603,36 +612,63 @@ hipError_t sf_launch_pool_ctx_bwd(const float* dctx, const bf16_t* wT, int ldt, 
   return hipGetLastError();
 }
 
-// probe attention backward: grid (F, S2), 256 threads.  LDS: T = [dz ; U]^T as hi + lo bf16 [D][40] (k = 0..15 dz heads, 16..31 U heads),
-// PD = [p | ds] of this workgroup's tokens [tokens][36] fp32, delta[16]
+// probe attention backward: grid (F, S2), 256 threads; bf16 operands like every backward GEMM.
+// LDS: T = [dz ; U]^T [D][40] bf16 (k = 0..15 dz heads, 16..31 U heads: the A operand of dx), dz rows [16][D + 8] as hi + lo bf16 planes (the
+// A operand of dp: two products per k-step), PD = [p | ds] of this workgroup's tokens [tokens][36] fp32, delta[16], {max, sum} of the forward's softmax [16][2].
+// KS = k-steps of the dp product (D / 32, rounded up to an instantiated count): all of a token tile's x fragments are loaded before its
+// first MFMA, the dz fragments come from LDS — one memory round trip per tile.
 #define TP 40
 #define PDP 36
+template <int KS>
 __global__ __launch_bounds__(256) void sf_pool_probe_bwd_kernel(SfPoolBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int f = blockIdx.x, sp = blockIdx.y;
-  const int D = p.D, N = p.N, heads = p.heads;
+  const int D = p.D, N = p.N, heads = p.heads, ZP = D + 8;
   const int per = (((N + gridDim.y - 1) / gridDim.y) + 15) & ~15;
   const int n0 = sp * per;
   const int n1 = n0 + per < N ? n0 + per : N;
   const int nt = n1 > n0 ? n1 - n0 : 0;
   const int tiles = (nt + 15) >> 4;
   bf16_t* T_hi = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* T_lo = T_hi + (size_t)D * TP;
-  float* PD = reinterpret_cast<float*>(T_lo + (size_t)D * TP);
+  bf16_t* dzs = T_hi + (size_t)D * TP;              // hi plane [16][ZP], then the lo plane
+  bf16_t* dzl = dzs + (size_t)16 * ZP;
+  float* PD = reinterpret_cast<float*>(dzl + (size_t)16 * ZP);
   float* delta = PD + (size_t)per * PDP;
+  float* mls = delta + 16;
   const float* dzf = p.dz + (size_t)f * heads * D;
   const float* zf = p.z + (size_t)f * heads * D;
-  for (int i = tid; i < 32 * D; i += 256) {
-    const int k = i / D, d = i - k * D;
-    float v = 0.f;
-    if (k < 16) { if (k < heads) v = dzf[(size_t)k * D + d]; }
-    else if (k - 16 < heads) v = p.u[(size_t)(k - 16) * D + d];
-    unsigned hi, lo;
-    split_bf(v, hi, lo);
-    T_hi[d * TP + k] = (bf16_t)hi;
-    T_lo[d * TP + k] = (bf16_t)lo;
+  // a thread takes 4 columns: 16 + 16 row loads issued together (rows past `heads`: row 0 again, value zeroed), then the images
+  for (int c4 = tid; c4 * 4 < D; c4 += 256) {
+    f32x4_t vz[16], vu[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int kc = k < heads ? k : 0;
+      vz[k] = *reinterpret_cast<const f32x4_t*>(dzf + (size_t)kc * D + c4 * 4);
+      vu[k] = *reinterpret_cast<const f32x4_t*>(p.u + (size_t)kc * D + c4 * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float keep = k < heads ? 1.f : 0.f;
+      vz[k] *= keep; vu[k] *= keep;
+      unsigned h4[4], l4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf(vz[k][j], h4[j], l4[j]);
+      *reinterpret_cast<u32x2_t*>(dzs + k * ZP + c4 * 4) = (u32x2_t){h4[0] | (h4[1] << 16), h4[2] | (h4[3] << 16)};
+      *reinterpret_cast<u32x2_t*>(dzl + k * ZP + c4 * 4) = (u32x2_t){l4[0] | (l4[1] << 16), l4[2] | (l4[3] << 16)};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // T[d][k]: 32 consecutive k per column = four 16-byte stores
+      bf16_t* row = T_hi + (size_t)(c4 * 4 + j) * TP;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<u32x4_t*>(row + q * 8) = (u32x4_t){pack_bf2(vz[q * 8][j], vz[q * 8 + 1][j]), pack_bf2(vz[q * 8 + 2][j], vz[q * 8 + 3][j]),
+                                                              pack_bf2(vz[q * 8 + 4][j], vz[q * 8 + 5][j]), pack_bf2(vz[q * 8 + 6][j], vz[q * 8 + 7][j])};
+        *reinterpret_cast<u32x4_t*>(row + 16 + q * 8) = (u32x4_t){pack_bf2(vu[q * 8][j], vu[q * 8 + 1][j]), pack_bf2(vu[q * 8 + 2][j], vu[q * 8 + 3][j]),
+                                                                   pack_bf2(vu[q * 8 + 4][j], vu[q * 8 + 5][j]), pack_bf2(vu[q * 8 + 6][j], vu[q * 8 + 7][j])};
+      }
+    }
   }
   for (int h = wave; h < 16; h += 4) {
     float t = 0.f;
@@ -641,7 +677,22 @@ __global__ __launch_bounds__(256) void sf_pool_probe_bwd_kernel(SfPoolBwdArgs p)
     t = wave_sum(t);
     if (lane == 0) delta[h] = t;
   }
+  if (tid < 16) {      // {max, sum} of the forward's softmax for head tid, combined over the forward's token splits
+    float m = 0.f, L = 1.f;
+    if (p.ml && tid < heads) {
+      const int S = p.ml_splits > 0 ? p.ml_splits : 1;
+      m = -INFINITY;
+      for (int sidx = 0; sidx < S; ++sidx) m = fmaxf(m, p.ml[(((size_t)f * S + sidx) * heads + tid) * 2]);
+      L = 0.f;
+      for (int sidx = 0; sidx < S; ++sidx) {
+        const float* o = p.ml + (((size_t)f * S + sidx) * heads + tid) * 2;
+        if (o[1] > 0.f) L += o[1] * __builtin_amdgcn_exp2f((o[0] - m) * LOG2E);
+      }
+    }
+    mls[2 * tid] = m; mls[2 * tid + 1] = L;
+  }
   __syncthreads();
+  const int nks = D >> 5;
   for (int t = wave; t < tiles; t += 4) {
     // ---- dp[head][token] = dz[head] . x[token]  (x: the saved bf16 normalised tokens) -----------------------------
     const int tl = t * 16 + l15;                 // token inside this workgroup's range
@@ -649,28 +700,32 @@ __global__ __launch_bounds__(256) void sf_pool_probe_bwd_kernel(SfPoolBwdArgs p)
     const bool tv = tok < n1;
     const size_t row = (size_t)f * N + (tv ? tok : N - 1);
     const bf16_t* xr = p.x_bf + row * D + g * 8;
-    const float* ar = dzf + (size_t)(l15 < heads ? l15 : 0) * D + g * 8;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < D; k += 64) {
-      const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(ar + k), a1 = *reinterpret_cast<const f32x4_t*>(ar + k + 4);
-      const f32x4_t a2 = *reinterpret_cast<const f32x4_t*>(ar + k + 32), a3 = *reinterpret_cast<const f32x4_t*>(ar + k + 36);
-      const bf16x8_t xb0 = *reinterpret_cast<const bf16x8_t*>(xr + k), xb1 = *reinterpret_cast<const bf16x8_t*>(xr + k + 32);
-      bf16x8_t ah, al;
-      split8(a0, a1, ah, al);
-      acc = pmfma(al, xb0, acc);
-      acc = pmfma(ah, xb0, acc);
-      split8(a2, a3, ah, al);
-      acc = pmfma(al, xb1, acc);
-      acc = pmfma(ah, xb1, acc);
+    bf16x8_t xb[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) xb[i] = *reinterpret_cast<const bf16x8_t*>(xr + (i < nks ? i : nks - 1) * 32);
+    const bf16_t* ar = dzs + l15 * ZP + g * 8;
+    const bf16_t* arl = dzl + l15 * ZP + g * 8;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {               // k-steps past the end (ragged instantiation) multiply a zeroed fragment
+      const bf16x8_t z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int kc = i < nks ? i : nks - 1;
+      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ar + kc * 32);
+      const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(arl + kc * 32);
+      acc = pmfma(i < nks ? a0 : z8, xb[i], acc);            // dz = hi + lo: two products, x is stored in bf16
+      acc2 = pmfma(i < nks ? a1 : z8, xb[i], acc2);
     }
+    acc += acc2;
     // lane: dp[head 4g + j][token l15]
     float pr[4], ds[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int h = 4 * g + j;
       const bool ok = tv && h < heads;
-      pr[j] = ok ? p.probs[((size_t)f * heads + h) * N + tok] : 0.f;
-      ds[j] = ok ? pr[j] * (acc[j] - delta[h]) : 0.f;
+      float pv = ok ? p.probs[((size_t)f * heads + h) * N + tok] : 0.f;
+      if (p.probs_raw) pv = ok ? __builtin_amdgcn_exp2f((pv - mls[2 * h]) * LOG2E) / mls[2 * h + 1] : 0.f;     // raw score -> probability
+      pr[j] = pv;
+      ds[j] = ok ? pv * (acc[j] - delta[h]) : 0.f;
     }
     *reinterpret_cast<f32x4_t*>(PD + (size_t)tl * PDP + 4 * g) = (f32x4_t){pr[0], pr[1], pr[2], pr[3]};
     *reinterpret_cast<f32x4_t*>(PD + (size_t)tl * PDP + 16 + 4 * g) = (f32x4_t){ds[0], ds[1], ds[2], ds[3]};
@@ -686,30 +741,48 @@ __global__ __launch_bounds__(256) void sf_pool_probe_bwd_kernel(SfPoolBwdArgs p)
     split8(*reinterpret_cast<const f32x4_t*>(pdr), *reinterpret_cast<const f32x4_t*>(pdr + 4), bh, bl);
     float* orow = p.dx + ((size_t)f * N + (tv ? tok : N - 1)) * D + 4 * g;
     const float* lrow = p.d_lhs ? p.d_lhs + ((size_t)f * N + (tv ? tok : N - 1)) * D + 4 * g : nullptr;
-    for (int dt = 0; dt * 16 < D; ++dt) {
-      const bf16x8_t th = *reinterpret_cast<const bf16x8_t*>(T_hi + (size_t)(dt * 16 + l15) * TP + 8 * g);
-      const bf16x8_t tlv = *reinterpret_cast<const bf16x8_t*>(T_lo + (size_t)(dt * 16 + l15) * TP + 8 * g);
-      f32x4_t a2 = {0.f, 0.f, 0.f, 0.f};
-      a2 = pmfma(tlv, bh, a2);
-      a2 = pmfma(th, bl, a2);
-      a2 = pmfma(th, bh, a2);
+    for (int dt = 0; dt * 16 < D; dt += 4) {           // D % 64 == 0: four column tiles per trip
+      f32x4_t o4[4], l4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16x8_t th = *reinterpret_cast<const bf16x8_t*>(T_hi + (size_t)((dt + q) * 16 + l15) * TP + 8 * g);
+        o4[q] = pmfma(th, bl, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        o4[q] = pmfma(th, bh, o4[q]);
+        if (lrow) l4[q] = *reinterpret_cast<const f32x4_t*>(lrow + (dt + q) * 16);
+      }
       if (tv) {
-        if (lrow) a2 += *reinterpret_cast<const f32x4_t*>(lrow + dt * 16);
-        *reinterpret_cast<f32x4_t*>(orow + dt * 16) = a2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (lrow) o4[q] += l4[q];
+          *reinterpret_cast<f32x4_t*>(orow + (dt + q) * 16) = o4[q];
+        }
       }
     }
   }
 }
 hipError_t sf_launch_pool_probe_bwd(const SfPoolBwdArgs& a, hipStream_t s) {
   if (a.heads > 16 || a.D != a.heads * 64 || a.D > 1024 || a.F <= 0 || a.N <= 0) return hipErrorInvalidValue;
+  if (a.probs_raw && !a.ml) return hipErrorInvalidValue;
   int S2 = 1;
   while (S2 < 4 && a.F * S2 < 256 && (a.N + 2 * S2 - 1) / (2 * S2) >= 16) S2 *= 2;
   const int per = (((a.N + S2 - 1) / S2) + 15) & ~15;
-  const size_t lds = (size_t)2 * a.D * TP * sizeof(bf16_t) + (size_t)per * PDP * sizeof(float) + 16 * sizeof(float);
+  const size_t lds = ((size_t)a.D * TP + (size_t)2 * 16 * (a.D + 8)) * sizeof(bf16_t) + ((size_t)per * PDP + 16 + 32) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static SfPerDeviceOnce once;
-  if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_probe_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(sf_pool_probe_bwd_kernel, dim3(a.F, S2), dim3(256), lds, s, a);
+  const dim3 grid(a.F, S2);
+#define SF_PB_CASE(KS)                                                                                                 \
+  {                                                                                                                    \
+    static SfPerDeviceOnce once;                                                                                       \
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_probe_bwd_kernel<KS>),          \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+    hipLaunchKernelGGL(sf_pool_probe_bwd_kernel<KS>, grid, dim3(256), lds, s, a);                                      \
+  }
+  const int nks = a.D / 32;
+  if (nks <= 4) SF_PB_CASE(4)
+  else if (nks <= 8) SF_PB_CASE(8)
+  else if (nks <= 16) SF_PB_CASE(16)
+  else if (nks <= 24) SF_PB_CASE(24)
+  else SF_PB_CASE(32)
+#undef SF_PB_CASE
   return hipGetLastError();
 }
 

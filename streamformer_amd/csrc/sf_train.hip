@@ -446,7 +446,7 @@ struct TWs {
   std::vector<TSavedLayer> sl;
   bf16_t *xn, *pc, *hn, *hm_pre, *hm;
   float* attn_out;
-  float *pz, *pprobs;                  // pooling head: z_h = sum_n p_hn x_n [F, heads, D] and the probabilities [F, heads, N]
+  float *pz, *pprobs, *pml, *pzpart;   // pooling head: z_h = sum_n p_hn x_n [F, heads, D], the raw scores [F, heads, N], {max, sum} and partial sums per token split
   // backward scratch
   bf16_t* d_ln_bf;
   float *g, *d_ln, *wg_partial, *dw_scratch, *cs, *ln_partial, *cs_partial, *s_tn;
@@ -485,6 +485,8 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
   }
   w.xn = c.take<bf16_t>(M * D); w.pc = c.take<bf16_t>(F * D);
   w.pz = c.take<float>(F * (size_t)t->heads * D); w.pprobs = c.take<float>(F * (size_t)t->heads * N);
+  w.pml = c.take<float>(sf_pool_ml_floats((int)F, (int)N, t->heads));
+  w.pzpart = c.take<float>(sf_pool_z_floats((int)F, (int)N, t->heads, (int)D));
   w.attn_out = c.take<float>(F * D); w.hn = c.take<bf16_t>(F * D);
   w.hm_pre = c.take<bf16_t>(F * I); w.hm = c.take<bf16_t>(F * I);
   // scratch
@@ -725,13 +727,17 @@ extern "C" int sf_trainer_forward(sf_trainer* t, const void* pixels, int pixel_d
   {
     SfPoolArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.x = xf; pa.u_hi = t->head_u_hi; pa.u_lo = t->head_u_lo; pa.zpart = ws.pz; pa.probs = ws.pprobs;
-    pa.F = F; pa.N = N; pa.heads = heads; pa.D = D; pa.S = 1; pa.normalize = 1;
+    // token splits as in inference (a frame's tokens over S workgroups): the raw scores and {max, sum} per split are kept, the backward
+    // finishes the softmax itself; the combined, normalised sums z land in ws.pz (directly when S == 1)
+    const int S = sf_pool_splits(F, N, heads);
+    pa.x = xf; pa.u_hi = t->head_u_hi; pa.u_lo = t->head_u_lo; pa.zpart = S == 1 ? ws.pz : ws.pzpart; pa.probs = ws.pprobs; pa.probs_raw = 1; pa.ml = ws.pml;
+    pa.F = F; pa.N = N; pa.heads = heads; pa.D = D; pa.S = S; pa.normalize = S == 1;
     HIP_TRY(sf_launch_pool_probe(pa, s));
     SfPoolCtxArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.zpart = ws.pz; ca.wv = PP(t, P0, t->p_inw, (size_t)2 * D * D); ca.ldw = D; ca.bv = PP(t, P0, t->p_inb, (size_t)2 * D);
-    ca.ctx_hi = ws.pc; ca.F = F; ca.heads = heads; ca.D = D; ca.S = 1;
+    ca.zpart = pa.zpart; ca.ml = ws.pml; ca.z_out = S == 1 ? nullptr : ws.pz;
+    ca.wv = PP(t, P0, t->p_inw, (size_t)2 * D * D); ca.ldw = D; ca.bv = PP(t, P0, t->p_inb, (size_t)2 * D);
+    ca.ctx_hi = ws.pc; ca.F = F; ca.heads = heads; ca.D = D; ca.S = S;
     HIP_TRY(sf_launch_pool_ctx(ca, s));
   }
   HIP_TRY(lin_fwd(t, t->head_out, ws.pc, F, SF_EPI_F32, s, ws.attn_out, nullptr));
@@ -820,7 +826,7 @@ static int backward_head(const BwdCtx& c, const float* d_pooler, const float* d_
   {
     SfPoolBwdArgs pb;
     memset(&pb, 0, sizeof(pb));
-    pb.x_bf = ws.xn; pb.probs = ws.pprobs; pb.z = ws.pz; pb.dz = ws.pdz; pb.u = t->head_u; pb.d_lhs = d_lhs; pb.dx = ws.d_ln; pb.ds_bf = ws.pds;
+    pb.x_bf = ws.xn; pb.probs = ws.pprobs; pb.probs_raw = 1; pb.ml = ws.pml; pb.ml_splits = sf_pool_splits(F, N, t->heads); pb.z = ws.pz; pb.dz = ws.pdz; pb.u = t->head_u; pb.d_lhs = d_lhs; pb.dx = ws.d_ln; pb.ds_bf = ws.pds;
     pb.F = F; pb.N = N; pb.heads = t->heads; pb.D = D;
     HIP_TRY(sf_launch_pool_probe_bwd(pb, s));
   }

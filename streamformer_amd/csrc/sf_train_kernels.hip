@@ -669,9 +669,9 @@ __global__ __launch_bounds__(256) void sf_fuse_temporal_kernel(const SfFuseJob* 
   const int i0 = (strip / sj) * 16, j0 = (strip % sj) * 64;
   const bf16_t* br = J.wd + (size_t)(i0 + l15) * D + g * 8;       // B operand rows: i
   const bf16_t* ar = J.woT + (size_t)(j0 + l15) * D + g * 8;      // A operand rows: j (four 16-row tiles, 16 D apart)
-  f32x4_t acc[4];
+  f32x4_t acc[4], acct[4];             // acct: the same products with the operand roles swapped = the transposed tile's lane layout
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < 4; ++q) { acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acct[q] = acc[q]; }
   for (int k = 0; k < D; k += 64) {                                // D % 64 == 0: two k-steps per trip, loads first
     const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(br + k), b1 = *reinterpret_cast<const bf16x8_t*>(br + k + 32);
     bf16x8_t a0[4], a1[4];
@@ -684,6 +684,8 @@ __global__ __launch_bounds__(256) void sf_fuse_temporal_kernel(const SfFuseJob* 
     for (int q = 0; q < 4; ++q) {
       acc[q] = tk_mfma(a0[q], b0, acc[q]);
       acc[q] = tk_mfma(a1[q], b1, acc[q]);
+      acct[q] = tk_mfma(b0, a0[q], acct[q]);
+      acct[q] = tk_mfma(b1, a1[q], acct[q]);
     }
   }
   // lane: W_f[i0 + l15][j0 + 16 q + 4g + jj], jj = 0..3
@@ -692,8 +694,8 @@ __global__ __launch_bounds__(256) void sf_fuse_temporal_kernel(const SfFuseJob* 
   for (int q = 0; q < 4; ++q) {
     const int j = j0 + 16 * q + 4 * g;
     *reinterpret_cast<u32x2_t*>(J.wf + (size_t)i * D + j) = (u32x2_t){pack_bf2(acc[q][0], acc[q][1]), pack_bf2(acc[q][2], acc[q][3])};
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) J.wfT[(size_t)(j + jj) * D + i] = (bf16_t)f2bf(acc[q][jj]);
+    // acct lane: W_f[i0 + 4g + jj][j0 + 16 q + l15] -> wfT[j][i0 + 4g .. + 3]: 8-byte stores instead of 2-byte scatters
+    *reinterpret_cast<u32x2_t*>(J.wfT + (size_t)(j0 + 16 * q + l15) * D + i0 + 4 * g) = (u32x2_t){pack_bf2(acct[q][0], acct[q][1]), pack_bf2(acct[q][2], acct[q][3])};
   }
 }
 // b_f[i] = tanh(g) (sum_k W_d[i][k] b_o[k] + b_d[i]) from the fp32 parameters; grid (D / 4, layers), one wave per row
