@@ -954,6 +954,28 @@ def test_forward_non_base_width_vs_oracle(mode, tol_l, tol_p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol_l,tol_p", [("fp32", ACC_TOL, ACC_TOL), ("bf16", BF16_LHS, BF16_POOL)])
+def test_forward_three_heads_vs_oracle(mode, tol_l, tol_p):
+    """D = 192 / 3 heads: the ragged k-step splits of the pooling-head kernels (six k-steps over four waves) in whole clips (token splits
+    S = 1 and S > 1) and streamed frames, against the oracle."""
+    import streamformer_amd as sa
+    cfg = small_cfg(hidden_size=192, num_attention_heads=3, intermediate_size=384, image_size=96)      # 36 patches
+    sd = make_state_dict(cfg, seed=31)
+    m = build(sa, cfg, sd, mode)
+    for B, T, seed in ((1, 3, 1), (20, 16, 2)):
+        x = frames(seed, (B, T, 3, 96, 96))
+        want = O.forward(sd, cfg, x)
+        out = m(x.cuda())
+        assert maxabs(out.last_hidden_state, want["last_hidden_state"]) <= tol_l and maxabs(out.pooler_output, want["pooler_output"]) <= tol_p, (B, T)
+    x = frames(3, (2, 4, 3, 96, 96))
+    want = O.forward(sd, cfg, x)
+    cache = m.new_cache(2, 16, 96, 96)
+    outs = [m(x.cuda()[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(4)]
+    assert maxabs(torch.cat([o.last_hidden_state for o in outs], 1), want["last_hidden_state"]) <= tol_l
+    assert maxabs(torch.cat([o.pooler_output for o in outs], 1), want["pooler_output"]) <= tol_p
+
+
+@pytest.mark.gpu
 def test_unsupported_widths_are_refused_with_a_message():
     """head_dim != 64 (a SigLIP-so400m-shaped 1152 / 16 = 72) and more than 16 heads are refused at construction with SF_ERR_INVALID
     and a message that names the limit — not a wrong answer, not a crash at the first forward."""

@@ -227,6 +227,28 @@ def test_small_model_gradients_match_oracle(task_idx, lora, freeze):
     _compare_grads(tr, orc)
 
 
+def test_three_head_model_gradients_match_oracle():
+    """D = 192 (three heads of 64): six k-steps of 32 do not divide over the four waves / the instantiated k-step counts of the pooling-head
+    kernels (forward K-split, backward KS = 8 over nks = 6) and the fused temporal projections run at D % 128 != 0 — the ragged paths
+    (clamped addresses, zeroed fragments) against the oracle's autograd, both tasks."""
+    from oracle import train_oracle as TO
+    cfg = small_cfg(add_lora_spatial=True, hidden_size=192, num_attention_heads=3, intermediate_size=384)
+    for task_idx in (0, 1):
+        tr, orc = _trainer_and_oracle(cfg, True, seed=9, lora=True)
+        task, x, ti, _ = TO.schedule(cfg)[task_idx]
+        want_loss = orc.loss(task, x, ti)
+        want_loss.backward()
+        dev = tr.device
+        _, pooler = tr.forward(x.to(dev))
+        loss, gp, gs = tr.loss_and_grad(task, pooler, _to_dev(ti, dev))
+        tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+        tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+        tr.backward(gp)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(want_loss)) < 2e-2 * abs(float(want_loss))
+        _compare_grads(tr, orc)
+
+
 def test_gradients_are_deterministic_and_accumulate():
     from oracle import train_oracle as TO
     cfg = small_cfg(add_lora_spatial=True)
