@@ -646,7 +646,7 @@ static bool ln_fold_ok(const sf_encoder* e, int M) {
 // {sum x, sum x^2} pair per 256-column tile; no fp32 residual, no LayerNorm launch.  The planes hold x to 2^-18 relative, the
 // precision every bf16x3 operand has anyway.  SF_DISABLE_ACC_FOLD restores fp32 residual + standalone LayerNorm (A/B).
 static bool ln_fold_acc_ok(const sf_encoder* e, int M) {
-  if (e->compute != SF_COMPUTE_BF16X3 || e->D != 768) return false;
+  if (e->compute != SF_COMPUTE_BF16X3 || (e->D % 256) || e->D > 1024) return false;      // one statistics pair per 256-column producer tile, four per row
   const bool off = sf_sw(SW_DISABLE_ACC_FOLD) != nullptr;
   if (off) return false;
   SfGemmArgs g;
@@ -662,6 +662,27 @@ static bool ln_fold_acc_ok(const sf_encoder* e, int M) {
   if (!sf_gemm256_supported(g, true)) return false;
   g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
   return sf_gemm256_supported(g, true);
+}
+
+// bf16 mode at widths the panel kernel does not take (D = 1024: a ViT-L-shaped encoder): the same plane-form residual stream + fold with
+// the 256^2 kernel as producer (planes in / out + one statistics pair per 256-column tile) and consumer (its bf16 LNF instance sums
+// the four pairs).  Without it those widths pay three standalone LayerNorm launches per layer (9.7 % of the ViT-L forward).
+static bool ln_fold_g256_ok(const sf_encoder* e, int M) {
+  if (e->compute != SF_COMPUTE_BF16 || (e->D % 256) || e->D > 1024) return false;
+  if (sf_sw(SW_DISABLE_LN_FOLD)) return false;
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.ln_stats_wide = 1;
+  g.M = M; g.N = e->D; g.K = e->D; g.epi = SF_EPI_RESID_F32;
+  g.out_hi = (bf16_t*)1; g.out_lo = (bf16_t*)1; g.ln_stats_out = (float*)1; g.resid_hi = (const bf16_t*)1; g.resid_lo = (const bf16_t*)1;
+  if (!sf_gemm256_supported(g, false)) return false;
+  g.K = e->I;
+  if (!sf_gemm256_supported(g, false)) return false;
+  g.ln_stats_out = nullptr; g.out_hi = (bf16_t*)1; g.out_lo = nullptr; g.resid_hi = g.resid_lo = nullptr; g.ln_stats = (const float*)1; g.ln_s = (const float*)1;
+  g.epi = SF_EPI_BF16; g.K = e->D; g.N = 3 * e->D;
+  if (!sf_gemm256_supported(g, false)) return false;
+  g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
+  return sf_gemm256_supported(g, false);
 }
 
 // Small-M variant (the per-frame streaming step): the skinny GEMM derives the row statistics itself from the A fragments
@@ -816,15 +837,18 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   bf16_t* plo2 = two_planes ? nullptr : ws.res_lo2;
   const bool xm = acc && !streaming && !hidden_states && (stages & 7) == 7 && !layer_tqkv && cap == T && t_past == 0 &&
                   sf_temporal_planes_ok(T, T) && sf_spatial_planes_ok(N, attentions != nullptr) && ln_fold_acc_ok(e, M);
-  bf16_t* fold_hi = (fold || xm) ? ws.xn_hi : (sfold ? ws.res_bf : nullptr);
-  float* fold_st = (fold || xm) ? ws.ln_stats : nullptr;
+  // gm: the bf16 mode's counterpart at widths without a panel kernel (ln_fold_g256_ok): lo plane = res_lo, two planes
+  const bool gm = !acc && !fold && !sfold && !streaming && !hidden_states && (stages & 7) == 7 && ws.res_lo != nullptr && ln_fold_g256_ok(e, M);
+  bf16_t* fold_hi = (fold || xm || gm) ? ws.xn_hi : (sfold ? ws.res_bf : nullptr);
+  float* fold_st = (fold || xm || gm) ? ws.ln_stats : nullptr;
   const bf16_t* ln_in = sfold ? ws.res_bf : ws.xn_hi;       // A operand of the three LayerNorm'd Linears
-  const bool anyfold = fold || sfold || xm;
-  const bool rplanes = pm || xm;                             // residual stream as two bf16 planes: hi = xn_hi, lo = plo
-  bf16_t* plo = pm ? ws.res_lo : (xm ? ws.xn_lo : nullptr);
+  const bool anyfold = fold || sfold || xm || gm;
+  const bool rplanes = pm || xm || gm;                       // residual stream as two bf16 planes: hi = xn_hi, lo = plo
+  bf16_t* plo = (pm || gm) ? ws.res_lo : (xm ? ws.xn_lo : nullptr);
   if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, nullptr, nullptr, 1));
   if (!xm) plo2 = nullptr;
   if (xm) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, ws.xn_lo, plo2));      // embeddings -> planes + wide statistics
+  if (gm) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, ws.res_lo, nullptr));
   if (sfold && (stages & 2) && !(stages & 1) && !(ready & 2)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
   for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];

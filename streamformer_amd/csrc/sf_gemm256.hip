@@ -399,8 +399,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
             const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 8);
             const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(p.ln_stats + (size_t)mrow * 8 + 4);
             const float invd = 1.0f / (float)K;
-            ln_mu = ((s0[0] + s0[2]) + s1[0]) * invd;
-            ln_r = rsqrtf(((s0[1] + s0[3]) + s1[1]) * invd - ln_mu * ln_mu + p.ln_eps);
+            ln_mu = ((s0[0] + s0[2]) + (s1[0] + s1[2])) * invd;        // four pairs (the fourth is zero at K = 768: x + 0 is exact)
+            ln_r = rsqrtf(((s0[1] + s0[3]) + (s1[1] + s1[3])) * invd - ln_mu * ln_mu + p.ln_eps);
           }
 #pragma unroll
           for (int nq = 0; nq < 2; ++nq)
@@ -441,10 +441,11 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
               if (p.out_lo) *reinterpret_cast<u32x4_t*>(p.out_lo + o) = l;
             }
           }
-        } else if (SPLIT && EPI == SF_EPI_RESID_F32 && p.resid_hi) {
-          // fp32-accurate mode, residual stream as hi + lo bf16 planes (they ARE the operand planes of the folded Linear that
-          // follows): a lane takes 8 columns — 16 bytes of each plane in, 16 out — and the 32 lanes of a row reduce this
-          // 256-column tile's {sum x, sum x^2} for the wide statistics
+        } else if (EPI == SF_EPI_RESID_F32 && p.resid_hi) {
+          // residual stream as hi + lo bf16 planes (they ARE the operand planes of the folded Linear that follows) — the fp32-accurate
+          // mode at any width, and since round 5 the bf16 mode at widths the panel kernel does not take (D = 1024): a lane takes
+          // 8 columns — 16 bytes of each plane in, 16 out — and the 32 lanes of a row reduce this 256-column tile's
+          // {sum x, sum x^2} into pair n0 / 256 of the row's wide statistics (up to four pairs: N <= 1024)
 #pragma unroll 2
           for (int it = 0; it < 8; ++it) {
             const int idx = it * G_THREADS + tid;
@@ -512,13 +513,16 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 
 bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
   if (split && (!a.a_lo || !a.w_lo || a.aux_mode || sf_sw(SW_DISABLE_G256_SPLIT))) return false;
-  if (split && a.ln_stats && (!a.ln_stats_wide || !a.ln_s || a.K != 768 || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
-  if (!split && a.resid_hi) return false;
+  if (split && a.ln_stats && (!a.ln_stats_wide || !a.ln_s || (a.K % 256) || a.K > 1024 || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
   if (a.epi == SF_EPI_EMBED_F32) return false;
+  bool planes = false;
   if (a.epi == SF_EPI_RESID_F32 && a.out_hi) {
-    // bf16 mode: no bf16 copy of the new residual here (panel kernel).  fp32-accurate mode: the residual as hi + lo planes, in
-    // and out, with the wide LayerNorm statistics of the Linear that follows
-    if (!split || !a.out_lo || !a.resid_hi || !a.resid_lo || !a.ln_stats_out || !a.ln_stats_wide || a.N != 768 || a.grp_rows > 0) return false;
+    // No plain bf16 copy of the new residual here (panel kernel).  The residual as hi + lo planes, in and out, with the wide LayerNorm
+    // statistics of the Linear that follows (one pair per 256-column tile: N <= 1024): the fp32-accurate mode, and the bf16 mode at
+    // widths the panel kernel does not take
+    if (!a.out_lo || !a.resid_hi || !a.resid_lo || !a.ln_stats_out || !a.ln_stats_wide || (a.N % 256) || a.N > 1024 || a.grp_rows > 0) return false;
+    if (!split && (a.resid_lo2 || a.out_lo2)) return false;
+    planes = true;
   } else if (a.resid_hi) {
     return false;
   }
@@ -528,7 +532,7 @@ bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
   if (split) { min_n = 768; if (const char* e = sf_sw(SW_G256_SPLIT_MIN_N)) min_n = atoi(e); }    // bf16x3: 392 / 120 us against 415 / 127 on the 128^2 kernel
   if (a.N % 256 || a.N < min_n) return false;
   if (a.M < 2048 || (size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return false;                 // small problems: the 128x128 kernel fills the chip better
-  if (a.out_lo && !split) return false;
+  if (a.out_lo && !split && !planes) return false;
   return true;
 }
 

@@ -936,7 +936,9 @@ def test_forward_non_base_width_vs_oracle(mode, tol_l, tol_p):
     m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
     m.load_state_dict(sd)
     m.to("cuda").eval()
-    for B, T, seed in ((1, 2, 5), (2, 16, 6)):
+    # M = 392 (small-M kernels), 6 272 (generic tiles, fp32 residual stream + standalone LayerNorms), 9 408 (round 5: plane-form residual
+    # stream + LayerNorm fold on the 256^2 kernel as producer and consumer, both modes)
+    for B, T, seed in ((1, 2, 5), (2, 16, 6), (3, 16, 8)):
         x = frames(seed, (B, T, 3, 224, 224))
         want = O.forward(sd, cfg, x)
         out = m(x.cuda())
