@@ -765,8 +765,12 @@ hipError_t sf_launch_pool_probe_bwd(const SfPoolBwdArgs& a, hipStream_t s) {
   if (a.probs_raw && !a.ml) return hipErrorInvalidValue;
   int S2 = 1;
   while (S2 < 4 && a.F * S2 < 256 && (a.N + 2 * S2 - 1) / (2 * S2) >= 16) S2 *= 2;
-  const int per = (((a.N + S2 - 1) / S2) + 15) & ~15;
-  const size_t lds = ((size_t)a.D * TP + (size_t)2 * 16 * (a.D + 8)) * sizeof(bf16_t) + ((size_t)per * PDP + 16 + 32) * sizeof(float);
+  auto lds_for = [&](int s2) {
+    const int per = (((a.N + s2 - 1) / s2) + 15) & ~15;
+    return ((size_t)a.D * TP + (size_t)2 * 16 * (a.D + 8)) * sizeof(bf16_t) + ((size_t)per * PDP + 16 + 32) * sizeof(float);
+  };
+  while (lds_for(S2) > 160 * 1024 && S2 < 16 && (a.N + S2 - 1) / S2 > 16) S2 *= 2;      // D = 1024: the images take 148 KB, more token splits shrink the rest
+  const size_t lds = lds_for(S2);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const dim3 grid(a.F, S2);
 #define SF_PB_CASE(KS)                                                                                                 \

@@ -249,6 +249,27 @@ def test_three_head_model_gradients_match_oracle():
         _compare_grads(tr, orc)
 
 
+def test_wide_model_gradients_match_oracle():
+    """D = 1024 / 16 heads / I = 4096 (a ViT-L-shaped layer): the trainer's kernels at the widest supported shape — the pooling-head
+    backward's LDS images need more token splits there, the fused temporal projections and the D x D algebra run at D = 1024."""
+    from oracle import train_oracle as TO
+    cfg = small_cfg(add_lora_spatial=True, hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=1, image_size=224,
+                    num_frames=4)
+    tr, orc = _trainer_and_oracle(cfg, True, seed=10, lora=True)
+    task, x, ti, _ = TO.schedule(cfg, B=2)[1]
+    want_loss = orc.loss(task, x, ti)
+    want_loss.backward()
+    dev = tr.device
+    _, pooler = tr.forward(x.to(dev))
+    loss, gp, gs = tr.loss_and_grad(task, pooler, _to_dev(ti, dev))
+    tr.grad(f"task_heads.{task}.logit_scale").add_(gs[0])
+    tr.grad(f"task_heads.{task}.logit_bias").add_(gs[1])
+    tr.backward(gp)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(want_loss)) < 2e-2 * abs(float(want_loss))
+    _compare_grads(tr, orc)
+
+
 def test_gradients_are_deterministic_and_accumulate():
     from oracle import train_oracle as TO
     cfg = small_cfg(add_lora_spatial=True)
