@@ -1390,6 +1390,117 @@ __global__ __launch_bounds__(256) void sf_temporal_decode_kernel(SfAttnArgs p, i
   }
 }
 
+// The same problem with whole cache lines per load instruction (bf16 rows, <= 128 keys).  A key row of one head is ONE 128-byte
+// line; in the kernel above a lane owns a key, so every K load instruction touches 64 lines for 16 bytes each (and is issued
+// eight times over the same lines): the vector-memory path serves 8x the lines the data needs.  Here lane = (key mod 8, 16-byte
+// chunk) for K exactly as for V: an instruction reads 8 keys x 128 B; the lane dots its 8 dims with its 16 bytes of q (one
+// load instead of eight), the 8 chunks of a key meet by three DPP adds (quad_perm x 2, row_half_mirror: bit-identical in all 8
+// lanes), so the lane that holds V[key][chunk] already holds p[key] (no ds_bpermute for the probabilities); max / sum / output
+// cross the 8 key groups by one DPP row rotate + two xor-shuffles instead of six dependent shuffles each.
+template <int CTRL>
+SF_DEVICE float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int KP>
+__global__ __launch_bounds__(256) void sf_temporal_decode_lines_kernel(SfAttnArgs p, int ntasks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= ntasks) return;
+  const int h = task % p.heads, bn = task / p.heads;
+  const int b = bn / p.N, n = bn % p.N;
+  int q_t0 = p.q_t0, Tk = p.Tk, t_past = p.t_past;
+  if (p.pos_dev) {                                 // streamed frame replayed from the position-free graph: {slot, keys} in one scalar load
+    struct __attribute__((aligned(4))) SlotKeys { int slot, tk; };
+    const SlotKeys sk = *reinterpret_cast<const SlotKeys*>(p.pos_dev);
+    q_t0 = sk.slot;
+    Tk = min(sk.tk, KP * 64);
+    t_past = Tk - 1;
+  }
+  const int tsub = lane >> 3, ch = lane & 7;       // key = 64 kp + 8 i + tsub, dims 8 ch .. 8 ch + 7
+  const char* kb = reinterpret_cast<const char*>(p.k);
+  const char* vb = reinterpret_cast<const char*>(p.v);
+  const size_t qoff = ((((size_t)b * p.Tq_cap + q_t0) * p.N + n) * p.row_pitch_q + h * HD + ch * 8) * 2;
+  const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.q) + qoff);
+  u32x4_t kv[KP][8], vv[KP][8];
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int key = kp * 64 + i * 8 + tsub;
+      key = key < Tk ? key : Tk - 1;               // clamped rows (one line, already in the cache) are masked below
+      const size_t off = ((((size_t)b * p.Tcap + key) * p.N + n) * p.row_pitch_kv + h * HD + ch * 8) * 2;
+      kv[kp][i] = *reinterpret_cast<const u32x4_t*>(kb + off);
+      vv[kp][i] = *reinterpret_cast<const u32x4_t*>(vb + off);
+    }
+  __builtin_amdgcn_sched_barrier(0);     // every load of the task ahead of the arithmetic (one latency per task)
+
+  float qf[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qf[2 * j] = bf2f(qv[j] & 0xffffu);
+    qf[2 * j + 1] = __uint_as_float(qv[j] & 0xffff0000u);
+  }
+  float sc[KP][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0 = fmaf(qf[2 * j], bf2f(kv[kp][i][j] & 0xffffu), a0);
+        a1 = fmaf(qf[2 * j + 1], __uint_as_float(kv[kp][i][j] & 0xffff0000u), a1);
+      }
+      float a = a0 + a1;
+      a += dpp_move<0xB1>(a);                      // quad_perm [1,0,3,2]
+      a += dpp_move<0x4E>(a);                      // quad_perm [2,3,0,1]
+      a += dpp_move<0x141>(a);                     // row_half_mirror: the other quad of the 8 chunk lanes
+      const int key = kp * 64 + i * 8 + tsub;
+      const bool ok = key < Tk && (!p.causal || key <= t_past);
+      sc[kp][i] = ok ? a : -INFINITY;
+      mx = fmaxf(mx, sc[kp][i]);
+    }
+  mx = fmaxf(mx, dpp_move<0x128>(mx));             // row_ror:8 : key group tsub ^ 1
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float c2 = p.scale * 1.44269504088896340736f;
+  float sum = 0.f;
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float pt = __builtin_amdgcn_exp2f((sc[kp][i] - mx) * c2);        // masked: 2^-inf = 0
+      sum += pt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[2 * j] = fmaf(pt, bf2f(vv[kp][i][j] & 0xffffu), o[2 * j]);
+        o[2 * j + 1] = fmaf(pt, __uint_as_float(vv[kp][i][j] & 0xffff0000u), o[2 * j + 1]);
+      }
+    }
+  sum += dpp_move<0x128>(sum);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] += dpp_move<0x128>(o[j]);
+  sum += __shfl_xor(sum, 16, 64);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], 32, 64);
+  if (tsub == 0) {
+    const float inv = 1.0f / sum;
+    const size_t o_off = (((size_t)b * p.Tq) * p.N + n) * p.D + h * HD + ch * 8;
+    unsigned int hb[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf(o[j] * inv, hb[j], lb[j]);
+    *reinterpret_cast<u32x4_t*>(p.ctx_hi + o_off) = (u32x4_t){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+    if (p.ctx_lo) *reinterpret_cast<u32x4_t*>(p.ctx_lo + o_off) = (u32x4_t){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+  }
+}
+
 // accurate mode: may the caller hand q / k / v of the temporal attention as hi + lo bf16 planes (short clips, no cache)?
 bool sf_temporal_planes_ok(int Tq, int Tk) {
   const bool off = sf_sw(SW_DISABLE_TEMPORAL_DMA_ACC) != nullptr || sf_sw(SW_DISABLE_TEMPORAL_DMA) != nullptr;
@@ -1407,6 +1518,11 @@ hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipS
     const int kp = (a.Tk + 63) >> 6;
 #define SF_TD(F, KPV) hipLaunchKernelGGL((sf_temporal_decode_kernel<F, KPV>), grid, block, 0, s, a, ntasks)
     if (accurate) { if (kp <= 1) SF_TD(true, 1); else if (kp <= 2) SF_TD(true, 2); else SF_TD(true, 4); }
+    else if (kp <= 2 && (a.row_pitch_kv % 8) == 0 && (a.row_pitch_q % 8) == 0 && !sf_sw(SW_TEMPORAL_DECODE_LANE_KEY)) {
+      // bf16 rows, <= 128 keys: whole cache lines per load instruction
+      if (kp <= 1) hipLaunchKernelGGL(sf_temporal_decode_lines_kernel<1>, grid, block, 0, s, a, ntasks);
+      else hipLaunchKernelGGL(sf_temporal_decode_lines_kernel<2>, grid, block, 0, s, a, ntasks);
+    }
     else { if (kp <= 1) SF_TD(false, 1); else if (kp <= 2) SF_TD(false, 2); else SF_TD(false, 4); }
 #undef SF_TD
     return hipGetLastError();

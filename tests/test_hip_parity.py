@@ -525,6 +525,27 @@ def test_sliding_window_cache_outlives_num_frames(sa, mode, tol, num_frames, cap
     assert out.shape[1] == 3 and torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", ACC_CEIL), ("bf16", BF16_LHS)])
+@pytest.mark.parametrize("cap", [72, 132])
+def test_long_cache_single_query_temporal_attention(sa, mode, tol, cap):
+    """The single-query temporal kernels past 64 cached frames: whole-line loads with two key passes (65..128 keys, bf16
+    rows), one key per lane with four passes (129..256 keys, and every fp32 row) — one frame per call against the oracle, the last
+    frames of a `cap`-frame stream (every key pass of the wave holds live keys there), eagerly and from the position-free graph."""
+    cfg = small_cfg(num_frames=cap, num_hidden_layers=1)
+    sd = make_state_dict(cfg, seed=6)
+    m = build(sa, cfg, sd, mode)
+    x = frames(12, (1, cap, 3, 48, 48))
+    ocache = O.new_cache(cfg)
+    cache = m.new_cache(1, cap)
+    for t in range(cap):
+        want = O.forward(sd, cfg, x[:, t:t + 1], cache=ocache)
+        got = m(x[:, t:t + 1].cuda(), use_cache=True, past_key_values=cache)
+        if t < 3 or t % 16 == 15 or t >= cap - 3:
+            assert maxabs(got.last_hidden_state, want["last_hidden_state"]) <= tol, t
+            assert maxabs(got.pooler_output, want["pooler_output"]) <= tol, t
+    assert cache.get_seq_length() == cap
+
+
 def test_stale_cache_is_refused(sa):
     """a cache created before the weights were re-packed must not be written with another element size."""
     nat = sa._native

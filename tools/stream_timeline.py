@@ -17,15 +17,17 @@ for f in frames:
     prev_end = None
     for name, s, e in f:
         short = name.split("(")[0].replace("void ", "")[:60]
-        d = agg.setdefault(short, [0, 0.0, 0.0])
+        d = agg.setdefault(short, [0, 0.0, 0.0, []])
         d[0] += 1; d[1] += (e - s)
         if prev_end is not None:
-            d[2] += max(0, s - prev_end); idle += max(0, s - prev_end)
+            d[2] += max(0, s - prev_end); idle += max(0, s - prev_end); d[3].append(max(0, s - prev_end))
         busy += e - s
         prev_end = e
     span += f[-1][2] - f[0][1]
 n = len(frames)
 print(f"{n} frames; per frame: kernels {sum(len(f) for f in frames)/n:.1f}, busy {busy/n/1e3:.1f} us, idle between kernels {idle/n/1e3:.1f} us, span {span/n/1e3:.1f} us")
-print(f"{'per_frame':>9} {'dur_us':>8} {'gap_before_us':>13} {'total_us/frame':>14}  kernel")
-for k, (c, d, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{c/n:9.1f} {d/c/1e3:8.2f} {g/c/1e3:13.2f} {(d+g)/n/1e3:14.1f}  {k}")
+print(f"{'per_frame':>9} {'dur_us':>8} {'gap_before_us':>13} {'gap_p50/p90':>11} {'total_us/frame':>14}  kernel")
+for k, (c, d, g, gl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    gl.sort()
+    q = f"{gl[len(gl)//2]/1e3:.2f}/{gl[int(len(gl)*0.9)]/1e3:.2f}" if gl else "-"
+    print(f"{c/n:9.1f} {d/c/1e3:8.2f} {g/c/1e3:13.2f} {q:>11} {(d+g)/n/1e3:14.1f}  {k}")
