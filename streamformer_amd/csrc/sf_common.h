@@ -225,6 +225,7 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a, bool split, hipStream_t s)
 bool sf_gemm_tile_supported(const SfGemmArgs& a, bool split);                    // sf_gemm_tile.hip: one to a few clips (2560 < M <= sf_tile_max_rows())
 hipError_t sf_launch_gemm_tile(const SfGemmArgs& a, hipStream_t s);
 int sf_tile_max_rows();
+int sf_tile_fold_min_rows();                                                     // tile producers emit row statistics from here up (sf_gemm_tile.hip)
 int sf_infold_max_rows();                                                        // largest M of the in-kernel-statistics LayerNorm fold (skinny + tile kernels)
 // LayerNorm-folded qkv projection on the panel tile (sf_gemm_qkv.hip): plain = the [M, 3D] bf16 tensor (spatial attention's input),
 // fused = the temporal attention of a full 16-frame clip computed in the epilogue, ctx [M, D] written instead of qkv

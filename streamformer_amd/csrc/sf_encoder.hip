@@ -624,9 +624,31 @@ static bool ln_fold_small_ok(const sf_encoder* e, int M);
 
 // LayerNorm folding needs the panel kernel as every residual producer (it emits the row statistics)
 // and the 256^2 kernel as every consumer (it applies them): true for the BASELINE shape.
+// Two clips per call (sf_tile_fold_min_rows() <= M <= sf_tile_max_rows()): the narrow tile kernel stays the residual producer (it beats
+// the panel kernel there) but emits the row statistics, so that the folded consumers can run on the 256^2 kernel (which beats the wide tiles there)
+static bool ln_fold_tile_ok(const sf_encoder* e, int M) {
+  if (e->compute != SF_COMPUTE_BF16 || sf_sw(SW_DISABLE_LN_FOLD)) return false;
+  SfGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.ln_stats_wide = 1;
+  g.M = M; g.N = e->D; g.ldc = e->D; g.epi = SF_EPI_RESID_F32; g.out_f32 = (float*)1; g.resid = (const float*)1; g.out_hi = (bf16_t*)1;
+  g.ln_stats_out = (float*)1;
+  g.K = e->D;
+  if (!sf_gemm_tile_supported(g, false)) return false;
+  g.K = e->I;
+  if (!sf_gemm_tile_supported(g, false)) return false;
+  memset(&g, 0, sizeof(g));
+  g.ln_stats_wide = 1;
+  g.M = M; g.epi = SF_EPI_BF16; g.K = e->D; g.N = 3 * e->D;
+  if (!sf_gemm256_supported(g, false)) return false;
+  g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.act = e->cfg.hidden_act;
+  return sf_gemm256_supported(g, false);
+}
+
 static bool ln_fold_ok(const sf_encoder* e, int M) {
   if (e->compute != SF_COMPUTE_BF16) return false;
   if (sf_sw(SW_DISABLE_LN_FOLD)) return false;        // A/B switch for measurements
+  if (ln_fold_tile_ok(e, M)) return true;
   if (ln_fold_small_ok(e, M)) return false;              // the small-M fold (in-kernel statistics: skinny / 64 x 64 / tile kernels) takes these
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -769,7 +791,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // of the folded Linears; lo = res_lo) instead of fp32: every residual producer moves 154 MB instead of 192 (no separate bf16
   // copy).  Only for complete forwards without hidden_states (the fp32 tensor is the interface of the stage-wise entry points).
   const bool planes_off = sf_sw(SW_DISABLE_RESID_PLANES) != nullptr;
-  bool pm = !planes_off && !acc && !streaming && ws.res_lo && !hidden_states && (stages & 7) == 7 && ln_fold_ok(e, M) && ws.embed_tab &&
+  bool pm = !planes_off && !acc && !streaming && ws.res_lo && !hidden_states && (stages & 7) == 7 && ln_fold_ok(e, M) && !ln_fold_tile_ok(e, M) && ws.embed_tab &&
             ws.patch_buf && e->Kp % 32 == 0 && e->Kp >= 128 && D == 768 && !sf_sw(SW_EMBED_VIA_GEMM128);
   if (stages & 1) {
   SfRowIndex idx;
@@ -813,6 +835,14 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       gq.out_f32 = nullptr; gq.out_lo = ws.res_lo;
       if (embed_panel && sf_gemm_panel_supported(gq, false)) gp = gq; else pm = false;
     }
+    // two clips per call (ln_fold_tile_ok): the embedding GEMM on the statistics-producing narrow tile (table add in its epilogue)
+    SfGemmArgs gt = g;
+    gt.epi = SF_EPI_EMBED_F32; gt.pos = pos_dev ? pos_dev : e->pos; gt.time_rows = ws.te_rows; gt.Np = N; gt.Tn = T;
+    gt.out_hi = ws.xn_hi; gt.ln_stats_out = ws.ln_stats; gt.ln_stats_wide = 1;
+    if (!acc && !streaming && (stages & 2) && patches != ws.xn_hi && ln_fold_tile_ok(e, M) && sf_gemm_tile_supported(gt, false)) {      // (A must not alias out_hi)
+      HIP_TRY(sf_launch_gemm_tile(gt, s));
+      embed_emitted_stats = true;
+    } else
     if (embed_panel && sf_gemm_panel_supported(gp, false)) {
       HIP_TRY(sf_launch_pos_time_table(pos_dev ? pos_dev : e->pos, ws.te_rows, ws.embed_tab, T, N, D, s));
       HIP_TRY(sf_launch_gemm_panel(gp, s));

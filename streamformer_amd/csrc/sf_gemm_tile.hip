@@ -75,6 +75,8 @@ struct TlCfg {
   static constexpr int STAGE_BYTES = NI * TL_LOADERS * 16;
   static constexpr int STATS_OFF = STAGES * STAGE_BYTES;                      // the epilogue stages the C tile inside the idle ring
   static constexpr int LDS_BYTES = STATS_OFF + BM * 8;
+  static constexpr int PART_OFF = LDS_BYTES;                                  // statistics producers: [BM rows][BN / 8] partial pairs behind it
+  static constexpr int PART_BYTES = BM * (BN / 8) * 8;
   static_assert(BM % ROWS_PER_INST == 0, "A rows must fill whole DMA instructions");
   static_assert(WM * WN * 64 == TL_CONSUMERS, "8 consumer waves");
   static_assert(NI * (STAGES - 2) <= 63, "vmcnt is 6 bits");
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
   constexpr int MTP = MTP_FIT >= MT ? MT : (MTP_FIT >= 1 ? MTP_FIT : 1);      // m-tiles per pass
   static_assert(16 * WM * PITCH * MTP <= C::STATS_OFF, "staging must stay below the statistics block");
   constexpr int CH = BN / 8;                                     // 8-column chunks per row
+  float2* part = reinterpret_cast<float2*>(smem + C::PART_OFF);  // statistics producers only (the launch adds PART_BYTES of LDS)
   const float inv_k = 1.0f / (float)K;
 #pragma unroll
   for (int q0 = 0; q0 < MT; q0 += MTP) {
@@ -281,11 +284,32 @@ __global__ __launch_bounds__(TL_THREADS) void sf_gemm_tile_kernel(SfGemmArgs p, 
         }
         *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = x0;
         *reinterpret_cast<f32x4_t*>(p.out_f32 + o + 4) = x1;
+        if ((EPI == SF_EPI_RESID_F32 || EPI == SF_EPI_EMBED_F32) && p.ln_stats_out)      // row-statistics producer: this chunk's share of {sum x, sum x^2}
+          part[rr * CH + c8] = make_float2(((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3])),
+                                           ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+                                               ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3])));
         if (EPI != SF_EPI_F32 && p.out_hi)      // LayerNorm-fold producer: bf16 copy of the new residual rows
           *reinterpret_cast<u32x4_t*>(p.out_hi + o) =
               (u32x4_t){pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
       } else {
         *reinterpret_cast<u32x4_t*>(p.out_hi + o) = *reinterpret_cast<const u32x4_t*>(srow + c8 * 16);
+      }
+    }
+    if ((EPI == SF_EPI_RESID_F32 || EPI == SF_EPI_EMBED_F32) && p.ln_stats_out) {
+      // LayerNorm fold with a statistics buffer (the 256^2 kernel as consumer, M = 6272): one {sum x, sum x^2} pair per row and
+      // column tile (N / BN <= 4 pairs per row: SfGemmArgs::ln_stats_wide), the CH chunk partials of a row summed in a fixed order
+      tl_lds_barrier();
+      for (int rr = tid; rr < 16 * WM * mtp; rr += TL_THREADS) {
+        const int w_ = rr / (16 * mtp), qq = (rr >> 4) % mtp, l = rr & 15;
+        const int m = m0 + (w_ * MT + q0 + qq) * 16 + l;
+        if (m >= p.M) continue;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < CH; ++c) {
+          const float2 v = part[rr * CH + c];
+          s1 += v.x; s2 += v.y;
+        }
+        *reinterpret_cast<float2*>(p.ln_stats_out + (size_t)m * 8 + (size_t)(n0 / BN) * 2) = make_float2(s1, s2);
       }
     }
     if (q0 + MTP < MT) tl_lds_barrier();
@@ -319,16 +343,28 @@ int sf_tile_max_rows() {
   return m;
 }
 
+int sf_tile_fold_min_rows() {
+  // from here up to sf_tile_max_rows() the LayerNorm-folded consumers (qkv, MLP-up) run on the 256^2 kernel with a statistics buffer that
+  // the tile producers fill (two clips: 24 / 55 us against 31 / 63 us on the in-kernel-statistics tiles); below, the tiles win (M = 3136:
+  // 17 / 34 against 24 / 29).  Whole forward, one box: M = 3920 2.21 (tiles) / 2.30 ms, 4312 2.60 / 2.41, 4704 2.57 / 2.46, 5488 2.89 / 2.69,
+  // 6272 3.03 / 2.80 (profiles/r05_two_clips_ab.txt)
+  return sf_sw(SW_TILE_FOLD_MIN_M) ? atoi(sf_sw(SW_TILE_FOLD_MIN_M)) : 4312;
+}
+
 struct TlShape { int bm, bn, id; };
 // candidates in order of preference at equal cost; id selects the instantiation
 static const TlShape kShapes[] = {
     {128, 96, 0}, {256, 96, 1}, {256, 192, 2},      // N = 768 residual producers / embedding
     {128, 256, 3}, {128, 384, 4}, {256, 256, 5},    // wide consumers
+    {128, 192, 6},                                  // N = 768 residual producers that also emit the row statistics (four pairs per row)
 };
 static bool shape_takes(const TlShape& sh, const SfGemmArgs& a) {
   if (a.N % sh.bn) return false;
+  // statistics producers: the consumer sums four pairs per row, and the partial sums need BM x BN bytes of LDS behind the ring
+  if ((a.ln_stats_out != nullptr) != (sh.id == 6)) return false;
+  if (sh.id == 6 && ((a.epi != SF_EPI_RESID_F32 && a.epi != SF_EPI_EMBED_F32) || a.N / sh.bn > 4)) return false;
   const bool lnf = a.ln_inkernel != 0;
-  const bool wide = sh.id >= 3;
+  const bool wide = sh.id >= 3 && sh.id != 6;
   if (lnf && (!wide || sh.id == 5)) return false;                   // LayerNorm-folded epilogues: the 128-row wide tiles (256 x 256 would spill)
   if ((a.epi == SF_EPI_RESID_F32 || a.epi == SF_EPI_EMBED_F32 || a.epi == SF_EPI_F32) && wide) return false;
   return true;
@@ -354,7 +390,8 @@ static const TlShape* pick_shape(const SfGemmArgs& a) {
 
 bool sf_gemm_tile_supported(const SfGemmArgs& a, bool split) {
   const bool off = sf_sw(SW_DISABLE_GEMM_TILE) != nullptr;
-  if (off || split || a.a_lo || a.out_lo || a.aux_mode || a.ln_stats || a.ln_stats_out || a.resid_mod > 0) return false;
+  if (off || split || a.a_lo || a.out_lo || a.aux_mode || a.ln_stats || a.resid_mod > 0) return false;
+  if (a.ln_stats_out && (!a.ln_stats_wide || (a.epi != SF_EPI_RESID_F32 && a.epi != SF_EPI_EMBED_F32) || !a.out_hi || a.M < sf_tile_fold_min_rows())) return false;
   if (a.M <= sf_tile_min_rows() || a.M > sf_tile_max_rows()) return false;
   if (a.K < 128 || (a.K % 64) || (a.ldc % 8) || (a.N % 8)) return false;
   if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return false;
@@ -372,15 +409,20 @@ bool sf_gemm_tile_supported(const SfGemmArgs& a, bool split) {
 template <int MT, int NT, int WM, int WN, int BK, int STAGES, int EPI, bool LNF>
 static hipError_t tl_go(const SfGemmArgs& a, hipStream_t s) {
   using C = TlCfg<MT, NT, WM, WN, BK, STAGES>;
+  constexpr bool PRODUCER = EPI == SF_EPI_RESID_F32 || EPI == SF_EPI_EMBED_F32;
+  const bool stats = PRODUCER && a.ln_stats_out != nullptr;
+  constexpr int LDS_MAX = (PRODUCER && C::LDS_BYTES + C::PART_BYTES <= 160 * 1024) ? C::LDS_BYTES + C::PART_BYTES : C::LDS_BYTES;
+  const int lds = C::LDS_BYTES + (stats ? C::PART_BYTES : 0);
+  if (lds > LDS_MAX) return hipErrorInvalidValue;
   static SfPerDeviceOnce attr_set;
   if (attr_set.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_tile_kernel<MT, NT, WM, WN, BK, STAGES, EPI, LNF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
   const int tiles_n = a.N / C::BN, tiles_m = (a.M + C::BM - 1) / C::BM;
   const int ntiles = tiles_n * tiles_m;
   const int per_xcd = (ntiles + 7) / 8;
   static const int lab_env = SF_LAB_SWITCH("SF_TILE_LAB");      // lab builds only
-  hipLaunchKernelGGL((sf_gemm_tile_kernel<MT, NT, WM, WN, BK, STAGES, EPI, LNF>), dim3(per_xcd * 8), dim3(TL_THREADS), C::LDS_BYTES, s,
+  hipLaunchKernelGGL((sf_gemm_tile_kernel<MT, NT, WM, WN, BK, STAGES, EPI, LNF>), dim3(per_xcd * 8), dim3(TL_THREADS), lds, s,
                      a, tiles_n, ntiles, per_xcd, lab_env);
   return hipGetLastError();
 }
@@ -416,7 +458,7 @@ hipError_t sf_launch_gemm_tile(const SfGemmArgs& a, hipStream_t s) {
   const TlShape* sh = pick_shape(a);
   const int force = sf_sw(SW_TILE_SHAPE) ? atoi(sf_sw(SW_TILE_SHAPE)) : -1;      // lab switch: force a candidate id
   int id = sh->id;
-  if (force >= 0 && force < 6 && shape_takes(kShapes[force], a)) id = force;
+  if (force >= 0 && force < 7 && shape_takes(kShapes[force], a)) id = force;
   switch (id) {
     //                      MT NT WM WN BK STAGES          stage image                  LDS
     case 0: return tl_narrow<2, 3, 4, 2, 64, 5>(a, s);   // 128 x  96: 224 rows x 128 B = 28 KB  140 KB
@@ -424,6 +466,8 @@ hipError_t sf_launch_gemm_tile(const SfGemmArgs& a, hipStream_t s) {
     case 2: return tl_narrow<4, 6, 4, 2, 32, 5>(a, s);   // 256 x 192: 448 rows x 64 B  = 28 KB  140 KB
     case 3: return tl_wide<4, 4, 2, 4, 64, 3>(a, s);     // 128 x 256: 384 rows x 128 B = 48 KB  144 KB
     case 4: return tl_wide<4, 6, 2, 4, 32, 4>(a, s);     // 128 x 384: 512 rows x 64 B  = 32 KB  128 KB
+    case 6:                                              // 128 x 192: 320 rows x 128 B = 40 KB  120 KB + 24 KB of partial sums
+      return a.epi == SF_EPI_EMBED_F32 ? tl_go<2, 6, 4, 2, 64, 3, SF_EPI_EMBED_F32, false>(a, s) : tl_go<2, 6, 4, 2, 64, 3, SF_EPI_RESID_F32, false>(a, s);
     default: return tl_wide_plain<8, 4, 2, 4, 32, 4>(a, s);   // 256 x 256: 512 rows x 64 B = 32 KB  128 KB
   }
 }

@@ -45,6 +45,7 @@
   X(SPATIAL_PERS, "SF_SPATIAL_PERS", "lab library: persistent spatial attention kernel") \
   X(SPATIAL_TPW, "SF_SPATIAL_TPW", "spatial attention: query tiles per workgroup (tuning)") \
   X(STREAM_GRAPH_PER_POSITION, "SF_STREAM_GRAPH_PER_POSITION", "streaming: one graph per cache position instead of the position-free one (A/B)") \
+  X(TILE_FOLD_MIN_M, "SF_TILE_FOLD_MIN_M", "tile-GEMM family: smallest M whose LayerNorm fold uses a statistics buffer and the 256^2 consumers") \
   X(TILE_MAX_M, "SF_TILE_MAX_M", "tile-GEMM family: largest M") \
   X(TILE_MIN_M, "SF_TILE_MIN_M", "tile-GEMM family: smallest M") \
   X(TILE_SHAPE, "SF_TILE_SHAPE", "tile-GEMM family: force a tile shape (tools/tile_lab.py)") \

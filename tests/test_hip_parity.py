@@ -1076,6 +1076,37 @@ def test_plane_form_residual_stream_equals_the_fp32_one(sa, mode):
     assert maxabs(planes.pooler_output[2], want["pooler_output"][0]) <= pt
 
 
+def test_two_clips_run_statistics_producing_tiles(sa, switches):
+    """Two clips per call (M = 6 272; README.md:55-71 at B = 2): the residual producers stay on the narrow tile kernel but emit the
+    LayerNorm row statistics (128 x 192 tiles: four pairs per row), the folded consumers run on the 256^2 kernel.  Against the
+    oracle, against the in-kernel-statistics schedule it replaces (SF_TILE_FOLD_MIN_M above M), bit-reproducible, clips
+    independent, and the fp32 hidden_states route of the same schedule; a 24-frame clip (M = 4 704, ragged 128-row tiles) too."""
+    cfg = siglip_base()
+    sd = make_state_dict(cfg, seed=0)
+    m = build(sa, cfg, sd, "bf16")
+    xc = torch.randn(2, 16, 3, 224, 224, generator=torch.Generator().manual_seed(21))
+    out = m(xc.cuda())
+    want = O.forward(sd, cfg, xc[1:2])
+    assert maxabs(out.last_hidden_state[1], want["last_hidden_state"][0]) <= BF16_LHS
+    assert maxabs(out.pooler_output[1], want["pooler_output"][0]) <= BF16_POOL
+    again = m(xc.cuda())
+    assert torch.equal(again.last_hidden_state, out.last_hidden_state) and torch.equal(again.pooler_output, out.pooler_output)
+    x2 = xc.clone(); x2[0] = -x2[0]
+    assert torch.equal(m(x2.cuda()).last_hidden_state[1], out.last_hidden_state[1])
+    hs = m(xc.cuda(), output_hidden_states=True)
+    assert maxabs(hs.last_hidden_state[1], want["last_hidden_state"][0]) <= BF16_LHS
+    x24 = torch.randn(1, 24, 3, 224, 224, generator=torch.Generator().manual_seed(22))
+    o24 = m(x24.cuda())
+    w24 = O.forward(sd, cfg, x24)
+    assert maxabs(o24.last_hidden_state, w24["last_hidden_state"]) <= BF16_LHS
+    assert maxabs(o24.pooler_output, w24["pooler_output"]) <= BF16_POOL
+    switches("SF_TILE_FOLD_MIN_M", 1 << 30)              # the schedule it replaces: statistics inside the wide tile consumers
+    old = m(xc.cuda())
+    d = maxabs(old.last_hidden_state, out.last_hidden_state)
+    assert 0 < d <= 4e-2, d                              # two schedules, one operand rounding apart
+    assert maxabs(old.last_hidden_state[1], want["last_hidden_state"][0]) <= BF16_LHS
+
+
 def test_five_clips_run_the_folded_schedule(sa):
     """Five and six clips fill 59 % / 71 % of the panel kernel's MFMA rows; from five clips on the folded schedule (panel producers,
     plane-form residual, 256^2 consumers) is taken anyway (sf_gemm_panel.hip: panel_plan).  Against the oracle, clip by clip
