@@ -1527,7 +1527,7 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   // bf16 mode at BASELINE-sized M: the residual projections as the forward launches them — hi + lo planes in and out, LayerNorm
   // row sums of the next Linear (run_forward's `pm`); fp32 residual + bf16 copy otherwise
   const bool planes_off = sf_sw(SW_DISABLE_RESID_PLANES) != nullptr;
-  const bool pm = !planes_off && !acc && epi == SF_EPI_RESID_F32 && ln_fold_ok(e, M);
+  const bool pm = !planes_off && !acc && epi == SF_EPI_RESID_F32 && ln_fold_ok(e, M) && !ln_fold_tile_ok(e, M);
   float* st = pm ? c.take<float>((size_t)M * 8) : nullptr;
   if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
   if (st) HIP_TRY(hipMemsetAsync(st, 0, (size_t)M * 8 * sizeof(float), (hipStream_t)stream));
