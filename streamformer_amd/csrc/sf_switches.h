@@ -40,6 +40,7 @@
   X(PANEL_STAGGER_NS, "SF_PANEL_STAGGER_NS", "panel kernel: phase-stagger step in ns") \
   X(SKINNY_MAX_M, "SF_SKINNY_MAX_M", "skinny family: largest M") \
   X(SKINNY_NO_KG, "SF_SKINNY_NO_KG", "skinny family: no K-parallel variant") \
+  X(SKINNY_NB, "SF_SKINNY_NB", "streaming, folded skinny consumers: 1 = 32 x 32 tiles everywhere, 2 / 3 = force 32 x 64 / 32 x 96 tiles (A/B)") \
   X(SKINNY_NT, "SF_SKINNY_NT", "skinny family: non-temporal weight loads (A/B)") \
   X(SKINNY_TPS, "SF_SKINNY_TPS", "skinny family: tiles per slot (tuning)") \
   X(SPATIAL_PERS, "SF_SPATIAL_PERS", "lab library: persistent spatial attention kernel") \

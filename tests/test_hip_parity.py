@@ -296,7 +296,7 @@ def test_forward_small_vs_golden(sa, golden_dir, mode, fuse):
         assert maxabs(out.pooler_output, g[f"T{T}_pooler_output"]) <= pt
         hs = torch.stack([h.cpu() for h in out.hidden_states])            # patch-major like the reference
         assert hs.shape == (3, 2, 9 * T, 128)
-        assert maxabs(hs, g[f"T{T}_hidden_states"]) <= (ACC_CEIL if mode == "fp32" else 0.15)
+        assert maxabs(hs, g[f"T{T}_hidden_states"]) <= (ACC_CEIL if mode == "fp32" else 6e-2)      # pre-LayerNorm residual rows up to |7.4|: measured 3.9e-2 (tools/hs_err.py)
         tup = m(x.cuda(), return_dict=False)
         assert isinstance(tup, tuple) and torch.equal(tup[0], out.last_hidden_state)
 
