@@ -71,17 +71,160 @@ SF_DEVICE void sk_ln_finish(float s1, float s2, int K, float eps, float& mean, f
 // TPS = K-tiles consumed per barrier (1 or 2): the loop is a serial chain of wait -> barrier -> LDS reads -> MFMA, a few
 // hundred cycles per step with two MFMAs of work in it, so halving the step count (12 -> 6 at K = 768) is worth more than
 // the one stage of prefetch depth it costs (STAGES - TPS tiles in flight instead of STAGES - 1).
-// NB = 16-column MFMA tiles per wave (output tile 32 x 32 NB).  NB = 1 is the shape above.  NB = 2 / 3 (bf16 LayerNorm-folded
-// consumers of ONE streamed frame: qkv 7 x 36 = 252, MLP-up 7 x 32 = 224 workgroups): with 32 x 32 tiles those launches are 504 / 672
-// workgroups = two to three per CU, and what bounds them is the L2 -> LDS ingest of a CU (~50 GB/s: 2 x 98 KB per CU for qkv);
-// a wider tile re-uses the A fragment for NB MFMAs and moves (32 + 32 NB) rows per 32 x 32 NB outputs — 147 KB per CU instead
-// of 196 for qkv, 196 instead of 294 for MLP-up — at one workgroup per CU.
-template <bool SPLIT, int EPI, bool LNF = false, int TPS = 1, int NB = 1>
+template <bool SPLIT, int EPI, bool LNF = false, int TPS = 1>
 __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p) {
-  constexpr int ROWS = SK_BM + 32 * NB;                  // A rows then W rows in one stage image
-  constexpr int PLANE = ROWS * SK_BK * 2;
+  constexpr int STAGE = SK_PLANE * (SPLIT ? 2 : 1);     // hi plane (+ lo plane)
+  constexpr int LOADS = SK_ROWS * 8 / SK_THREADS;       // 16-byte chunks per thread per plane = 2
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
+
+  // per-thread DMA sources: chunk c of the stage image = (row, 16-byte slot); rows 0..31 = A, 32..63 = W
+  const bf16_t* src_hi[LOADS];
+  const bf16_t* src_lo[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int c = i * SK_THREADS + tid;
+    const int row = c >> 3, slot = c & 7;
+    const int kc = slot ^ ((row >> 1) & 7);
+    if (row < SK_BM) {
+      int gr = m0 + row;
+      gr = gr < p.M ? gr : p.M - 1;
+      src_hi[i] = p.a_hi + (size_t)gr * p.K + kc * 8;
+      src_lo[i] = SPLIT ? p.a_lo + (size_t)gr * p.K + kc * 8 : nullptr;
+    } else {
+      int gr = n0 + row - SK_BM;
+      gr = gr < p.N ? gr : p.N - 1;
+      src_hi[i] = p.w_hi + (size_t)gr * p.K + kc * 8;
+      src_lo[i] = SPLIT ? p.w_lo + (size_t)gr * p.K + kc * 8 : nullptr;
+    }
+  }
+  const bool w_nt = p.w_nt != 0;
+  auto issue = [&](int kt) {
+    char* dst = smem + (kt % SK_STAGES) * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      if (i == 1 && w_nt) __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 2);   // W rows, nt
+      else __builtin_amdgcn_global_load_lds((gptr_t)(src_hi[i] + kt * SK_BK), (lptr_t)(dst + i * 4096), 16, 0, 0);
+      if (SPLIT) __builtin_amdgcn_global_load_lds((gptr_t)(src_lo[i] + kt * SK_BK), (lptr_t)(dst + SK_PLANE + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float ln1 = 0.f, ln2 = 0.f;
+  const int nkt = p.K / SK_BK;
+  constexpr int PER = LOADS * (SPLIT ? 2 : 1);            // load instructions per stage per thread
+  const int mt = wave & 1, nt = wave >> 1;                // this wave's 16x16 output tile
+
+  for (int s = 0; s < SK_STAGES - TPS && s < nkt; ++s) issue(s);
+  // epilogue operands (bias, folded-LayerNorm column sums, residual row) requested NOW, behind the first DMA stages: at one
+  // frame the launch is a chain of memory latencies, and each of these loads used to add its own at the very end
+  const int n_e = n0 + nt * 16 + g * 4, m_e = m0 + mt * 16 + l15;
+  const bool live_e = n_e < p.N && m_e < p.M;
+  f32x4_t pre_bias = {0.f, 0.f, 0.f, 0.f}, pre_lns = {0.f, 0.f, 0.f, 0.f}, pre_res = {0.f, 0.f, 0.f, 0.f};
+  if (live_e) {
+    if (p.bias) pre_bias = *reinterpret_cast<const f32x4_t*>(p.bias + n_e);
+    if (LNF) pre_lns = *reinterpret_cast<const f32x4_t*>(p.ln_s + n_e);
+    if (EPI == SF_EPI_RESID_F32 && p.grp_rows <= 0) pre_res = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m_e * p.ldc + n_e);
+  }
+  for (int kt = 0; kt < nkt; kt += TPS) {
+    // tiles kt .. kt+TPS-1 complete: at most the later in-flight tiles may remain outstanding
+    switch (min(nkt - TPS - kt, SK_STAGES - 2 * TPS)) {
+      case 6: sk_wait<6 * PER>(); break;
+      case 5: sk_wait<5 * PER>(); break;
+      case 4: sk_wait<4 * PER>(); break;
+      case 3: sk_wait<3 * PER>(); break;
+      case 2: sk_wait<2 * PER>(); break;
+      case 1: sk_wait<PER>(); break;
+      default: sk_wait<0>(); break;
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int u = 0; u < TPS; ++u)                                  // overwrites the stages read in the previous step
+      if (kt + SK_STAGES - TPS + u < nkt) issue(kt + SK_STAGES - TPS + u);
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      const char* img = smem + ((kt + u) % SK_STAGES) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = ks * 4 + g;
+        const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
+        const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
+        if (LNF) sk_stats(af, ln1, ln2);
+        if (SPLIT) {
+          const char* lo = img + SK_PLANE;
+          const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
+          const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
+          acc = sk_mfma(wl, af, acc);
+          acc = sk_mfma(wf, al, acc);
+        }
+        acc = sk_mfma(wf, af, acc);
+      }
+    }
+  }
+  if (LNF) {       // the four k-groups of row l15 (all 64 lanes still active here)
+    ln1 += __shfl_xor(ln1, 16, 64); ln1 += __shfl_xor(ln1, 32, 64);
+    ln2 += __shfl_xor(ln2, 16, 64); ln2 += __shfl_xor(ln2, 32, 64);
+  }
+
+  // ---- epilogue: lane holds C[m = tile row l15][n = tile col 4g .. 4g+3] ----------------------------------
+  const int n = n0 + nt * 16 + g * 4;
+  const int m = m0 + mt * 16 + l15;
+  if (n >= p.N || m >= p.M) return;
+  const f32x4_t bias = pre_bias;
+  {
+    size_t orow = (size_t)m;
+    if (p.grp_rows > 0) orow = sf_out_row(p, m);
+    if (LNF) {
+      float mean, rstd;
+      sk_ln_finish(ln1, ln2, p.K, p.ln_eps, mean, rstd);
+      acc = rstd * (acc - mean * pre_lns);
+    }
+    f32x4_t v = acc + bias;
+    const size_t o = orow * (size_t)p.ldc + n;
+    if (EPI == SF_EPI_F32) {
+      *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+    } else if (EPI == SF_EPI_RESID_F32) {
+      const f32x4_t r = p.grp_rows <= 0 ? pre_res : *reinterpret_cast<const f32x4_t*>(p.resid + o);
+      v = r + p.alpha * v;
+      *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+      if (!SPLIT && p.out_hi)    // small-M LayerNorm fold producer: bf16 copy of the new residual rows
+        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else if (EPI == SF_EPI_EMBED_F32) {
+      const int pn = m % p.Np, tt = (m / p.Np) % p.Tn + (p.time_base_dev ? *p.time_base_dev : 0);
+      const f32x4_t pe = *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)pn * p.N + n);
+      const f32x4_t te = *reinterpret_cast<const f32x4_t*>(p.time_rows + (size_t)tt * p.N + n);
+      v = v + pe + te;
+      *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
+      if (!SPLIT && p.out_hi)      // small-M LayerNorm fold: bf16 copy of the embedded rows for layer 0's folded qkv
+        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+      if (EPI == SF_EPI_ACT_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = SPLIT ? apply_act(v[j], p.act) : apply_act_bf16(v[j], p.act);
+      }
+      unsigned int h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf(v[j], h[j], l[j]);
+      *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+      if (p.out_lo) *reinterpret_cast<u32x2_t*>(p.out_lo + o) = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    }
+  }
+}
+
+// The same kernel with NB 16-column MFMA tiles per wave (output tile 32 x 32 NB; NB = 2 / 3), for the bf16 LayerNorm-folded consumers of
+// ONE streamed frame.  With 32 x 32 tiles the MLP up-projection is 672 workgroups = three on the critical CUs, and what bounds the launch
+// is the L2 -> LDS ingest of a CU (~50 GB/s: 3 x 98 KB); a wider tile re-uses the A fragment for NB MFMAs and moves (32 + 32 NB) rows
+// per 32 x 32 NB outputs: 7 x 32 = 224 workgroups of 32 x 96, one per CU with 196 KB each.  (Kept apart from the kernel above: folded
+// into it as a template parameter, hipcc 7.2 put an s_waitcnt vmcnt(0) behind the epilogue-operand prefetch of the NB = 1 instances —
+// a whole memory latency in the prologue, 6.4 -> 6.75 us on the streamed qkv projection.)
+template <bool SPLIT, int EPI, bool LNF, int TPS, int NB>
+__global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_wide_kernel(SfGemmArgs p) {
+  constexpr int ROSK_STAGES = SK_BM + 32 * NB;                  // A rows then W rows in one stage image
+  constexpr int PLANE = ROSK_STAGES * SK_BK * 2;
   constexpr int STAGE = PLANE * (SPLIT ? 2 : 1);         // hi plane (+ lo plane)
-  constexpr int LOADS = ROWS * 8 / SK_THREADS;           // 16-byte chunks per thread per plane = 2 (NB = 1), 3, 4
+  constexpr int LOADS = ROSK_STAGES * 8 / SK_THREADS;           // 16-byte chunks per thread per plane = 2 (NB = 1), 3, 4
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -134,13 +277,16 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int n_e = n0 + (nt * NB + j) * 16 + g * 4;
-    pre_bias[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    pre_lns[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // (locals, then one assignment per array element: with the conditional loads written straight into the arrays hipcc 7.2 put an
+    //  s_waitcnt vmcnt(0) behind the first of them — a whole memory latency in the prologue of every launch)
+    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f}, l4 = {0.f, 0.f, 0.f, 0.f};
     if (n_e < p.N && m_e < p.M) {
-      if (p.bias) pre_bias[j] = *reinterpret_cast<const f32x4_t*>(p.bias + n_e);
-      if (LNF) pre_lns[j] = *reinterpret_cast<const f32x4_t*>(p.ln_s + n_e);
+      if (p.bias) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n_e);
+      if (LNF) l4 = *reinterpret_cast<const f32x4_t*>(p.ln_s + n_e);
       if (NB == 1 && EPI == SF_EPI_RESID_F32 && p.grp_rows <= 0) pre_res = *reinterpret_cast<const f32x4_t*>(p.resid + (size_t)m_e * p.ldc + n_e);
     }
+    pre_bias[j] = b4;
+    pre_lns[j] = l4;
   }
   for (int kt = 0; kt < nkt; kt += TPS) {
     // tiles kt .. kt+TPS-1 complete: at most the later in-flight tiles may remain outstanding
@@ -163,19 +309,21 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int kc = ks * 4 + g;
+        bf16x8_t wf[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) wf[j] = sk_frag(img, SK_BM + (nt * NB + j) * 16 + l15, kc);      // every fragment read issued before the first use
         const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
         if (LNF) sk_stats(af, ln1, ln2);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const bf16x8_t wf = sk_frag(img, SK_BM + (nt * NB + j) * 16 + l15, kc);
           if (SPLIT) {
             const char* lo = img + PLANE;
             const bf16x8_t wl = sk_frag(lo, SK_BM + (nt * NB + j) * 16 + l15, kc);
             const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
             acc[j] = sk_mfma(wl, af, acc[j]);
-            acc[j] = sk_mfma(wf, al, acc[j]);
+            acc[j] = sk_mfma(wf[j], al, acc[j]);
           }
-          acc[j] = sk_mfma(wf, af, acc[j]);
+          acc[j] = sk_mfma(wf[j], af, acc[j]);
         }
       }
     }
@@ -664,7 +812,7 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a_in, bool split, hipStream_t
   const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
   if (a.ln_inkernel && !split && a.M <= 256 && ((a.K / SK_BK) % 4) == 0 && (int)(grid.x * grid.y) > 512) {
     // one streamed frame, more than two 32 x 32 tiles per CU (MLP-up: 672): the narrowest wider tile that gives every workgroup its
-    // own CU (sf_gemm_skinny_kernel, NB) — 32 x 96 for MLP-up (224 workgroups): 10.2 -> 8.5 us per launch, p50 0.733 -> 0.716 ms
+    // own CU (sf_gemm_skinny_wide_kernel) — 32 x 96 for MLP-up (224 workgroups): 10.2 -> 8.5 us per launch, p50 0.733 -> 0.716 ms
     // (profiles/r05_skinny_wide_ab.txt).  qkv (504 tiles) stays on 32 x 32: its 32 x 64 instance measured 6.9 against 6.4 us on 4
     // waves (too few waves to issue a CU's ingest) and level on 16 waves with every K-tile in flight.
     const int nb_env = sf_sw(SW_SKINNY_NB) ? atoi(sf_sw(SW_SKINNY_NB)) : 0;      // A/B: 1 keeps the 32 x 32 tiles, 2 / 3 force a width
@@ -677,16 +825,16 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a_in, bool split, hipStream_t
       const dim3 gw(a.N / (32 * nb), grid.y);
       static SfPerDeviceOnce attr_w;
       if (attr_w.first()) {
-#define SK_WATTR(E, B) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<false, E, true, 4, B>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * (SK_BM + 32 * B) * SK_BK * 2);
+#define SK_WATTR(E, B) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_wide_kernel<false, E, true, 4, B>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * (SK_BM + 32 * B) * SK_BK * 2);
         SK_WATTR(SF_EPI_BF16, 2) SK_WATTR(SF_EPI_BF16, 3) SK_WATTR(SF_EPI_ACT_BF16, 2) SK_WATTR(SF_EPI_ACT_BF16, 3)
 #undef SK_WATTR
       }
       if (a.epi == SF_EPI_BF16) {
-        if (nb == 2) hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_BF16, true, 4, 2>), gw, dim3(SK_THREADS), ldw, s, a);
-        else hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_BF16, true, 4, 3>), gw, dim3(SK_THREADS), ldw, s, a);
+        if (nb == 2) hipLaunchKernelGGL((sf_gemm_skinny_wide_kernel<false, SF_EPI_BF16, true, 4, 2>), gw, dim3(SK_THREADS), ldw, s, a);
+        else hipLaunchKernelGGL((sf_gemm_skinny_wide_kernel<false, SF_EPI_BF16, true, 4, 3>), gw, dim3(SK_THREADS), ldw, s, a);
       } else {
-        if (nb == 2) hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true, 4, 2>), gw, dim3(SK_THREADS), ldw, s, a);
-        else hipLaunchKernelGGL((sf_gemm_skinny_kernel<false, SF_EPI_ACT_BF16, true, 4, 3>), gw, dim3(SK_THREADS), ldw, s, a);
+        if (nb == 2) hipLaunchKernelGGL((sf_gemm_skinny_wide_kernel<false, SF_EPI_ACT_BF16, true, 4, 2>), gw, dim3(SK_THREADS), ldw, s, a);
+        else hipLaunchKernelGGL((sf_gemm_skinny_wide_kernel<false, SF_EPI_ACT_BF16, true, 4, 3>), gw, dim3(SK_THREADS), ldw, s, a);
       }
       return hipGetLastError();
     }
