@@ -217,16 +217,38 @@ def dp_consistency_check(tr, task, x, ti, dist, world):
         tr.zero_grad()
         return g
 
-    local = one_backward(False)
-    reduced = one_backward(True)
-    want = all_gather_rows(local[None].contiguous(), group=tr.group, at_world_1=True).double().sum(0)
-    scale = float(want.abs().max())
-    err = float((reduced.double() - want).abs().max()) / max(scale, 1e-30)
+    # The comparison needs two backward passes of the same rank to agree bit for bit.  They do on a device of their own (150 of 150 passes,
+    # tools/train_det.py); with several ranks SHARING one device (the same-device dry runs of the test suite) about 3 % of the passes
+    # have shown a few frames of the pooling head's forward that do not repeat (open) — so a mismatch is re-measured,
+    # up to three attempts, every rank deciding on the all-reduced maximum; the first attempt's error is reported beside the last.
+    errs = []
+    for attempt in range(3):
+        local = one_backward(False)
+        reduced = one_backward(True)
+        want = all_gather_rows(local[None].contiguous(), group=tr.group, at_world_1=True).double().sum(0)
+        scale = float(want.abs().max())
+        diff = (reduced.double() - want).abs()
+        err = float(diff.max()) / max(scale, 1e-30)
+        errs.append(err)
+        if max_over_ranks(err, dist if world > 1 else None) <= 1e-5:
+            break
+    local2 = one_backward(False)                # (3) the backward itself repeats bit for bit
+    repeat_diff = (local2 - local).abs()
+
+    def owner(flat_index):                      # the trainable parameter a position of the gradient buffer belongs to
+        for name, e in tr.layout.items():
+            if e["trainable"] and e["offset"] <= flat_index < e["offset"] + e["numel"]:
+                return name
+        return "?"
+    worst = {"param": owner(int(idx[int(diff.argmax())])), "abs": float(diff.max())}
+    rep = {"max_abs": float(repeat_diff.max()), "elements": int((repeat_diff > 0).sum()),
+           "param": owner(int(idx[int(repeat_diff.argmax())])) if float(repeat_diff.max()) > 0 else None}
     # which buckets the sample touched
     touched = sorted({b for b, (_, off, n) in enumerate(tr.buckets) if bool(((idx >= off) & (idx < off + n)).any())})
     return {"params_identical_on_all_ranks": all(s == sums[0] for s in sums), "param_checksums_distinct": len(set(sums)),
             "reduced_equals_sum_of_local_rel_err": err, "sampled_elements": int(idx.numel()), "buckets_sampled": len(touched),
             "buckets": len(tr.buckets), "ways": world, "local_grad_absmax": float(local.abs().max()), "task": task,
+            "worst_element": worst, "local_backward_repeat": rep, "attempts": len(errs), "first_attempt_rel_err": errs[0],
             "how": "params: int64 checksums of the raw fp32 bits, all_gather_object; gradients: bucketed all-reduce result vs float64 sum "
                    "of the all-gathered local gradients on a strided sample"}
 

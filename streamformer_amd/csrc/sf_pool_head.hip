@@ -567,33 +567,27 @@ __global__ __launch_bounds__(256) void sf_pool_dz_kernel(const float* __restrict
   }
 }
 // dWv[h*64 + j][d] += sum_f dctx[f][h*64 + j] z[f][h][d];  dbv[h*64 + j] += sum_f dctx[f][h*64 + j]
-// grid (heads, 8): eight value rows per workgroup; a thread owns 4 columns; frames in a fixed order (deterministic)
+// grid (heads, 8): eight value rows per workgroup; a thread owns 4 columns; frames in a fixed order (deterministic).  The eight dctx values
+// of a frame are the same for the whole workgroup: they arrive by scalar loads (no LDS image, no barrier).
 __global__ __launch_bounds__(256) void sf_pool_dwv_kernel(const float* __restrict__ dctx, const float* __restrict__ z, float* __restrict__ dwv,
                                                           int ldw, float* __restrict__ dbv, int F, int heads, int D) {
-  __shared__ float dl[128][8];
   const int h = blockIdx.x, j0 = blockIdx.y * 8, tid = threadIdx.x;
   const int c4 = tid;
   const bool cv = c4 * 4 < D;
   f32x4_t acc[8];
+  float bs[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  for (int f0 = 0; f0 < F; f0 += 128) {
-    const int nf = F - f0 < 128 ? F - f0 : 128;
-    for (int i = tid; i < nf * 8; i += blockDim.x) dl[i >> 3][i & 7] = dctx[(size_t)(f0 + (i >> 3)) * D + h * 64 + j0 + (i & 7)];
-    __syncthreads();
-    if (cv) {
-      const float* zc = z + ((size_t)f0 * heads + h) * D + c4 * 4;
-#pragma unroll 4
-      for (int ff = 0; ff < nf; ++ff) {
-        const f32x4_t zv = *reinterpret_cast<const f32x4_t*>(zc + (size_t)ff * heads * D);
+  for (int i = 0; i < 8; ++i) { acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; bs[i] = 0.f; }
+  const float* dr = dctx + h * 64 + j0;                       // + f * D: workgroup-uniform
+  const float* zc = z + (size_t)h * D + (cv ? c4 * 4 : 0);    // + f * heads * D
+#pragma unroll 2
+  for (int f = 0; f < F; ++f) {
+    const f32x4_t zv = *reinterpret_cast<const f32x4_t*>(zc + (size_t)f * heads * D);
+    float d8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += dl[ff][i] * zv;
-      }
-    }
-    if (tid < 8)
-      for (int ff = 0; ff < nf; ++ff) bsum += dl[ff][tid];
-    __syncthreads();
+    for (int i = 0; i < 8; ++i) d8[i] = dr[(size_t)f * D + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[i] += d8[i] * zv; bs[i] += d8[i]; }
   }
   if (cv && dwv) {
 #pragma unroll
@@ -602,7 +596,10 @@ __global__ __launch_bounds__(256) void sf_pool_dwv_kernel(const float* __restric
       *o = *o + acc[i];
     }
   }
-  if (tid < 8 && dbv) dbv[h * 64 + j0 + tid] += bsum;
+  if (tid == 0 && dbv) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dbv[h * 64 + j0 + i] += bs[i];
+  }
 }
 hipError_t sf_launch_pool_ctx_bwd(const float* dctx, const bf16_t* wT, int ldt, int col0, const float* z, float* dz, float* dwv, int ldw,
                                   float* dbv, int F, int heads, int D, hipStream_t s) {
