@@ -218,9 +218,10 @@ def dp_consistency_check(tr, task, x, ti, dist, world):
         return g
 
     # The comparison needs two backward passes of the same rank to agree bit for bit.  They do on a device of their own (150 of 150 passes,
-    # tools/train_det.py); with several ranks SHARING one device (the same-device dry runs of the test suite) about 3 % of the passes
-    # have shown a few frames of the pooling head's forward that do not repeat ("Open") — so a mismatch is re-measured,
-    # up to three attempts, every rank deciding on the all-reduced maximum; the first attempt's error is reported beside the last.
+    # tools/train_det.py).  With several ranks SHARING one device (the same-device dry runs of the test suite) the pooling head's forward
+    # kernels were disturbed by another process's temporal attention backward on the same CU ("Device sharing"); they now keep
+    # their CUs to themselves, and as a belt to those braces a mismatch is still re-measured, up to three attempts, every rank deciding
+    # on the all-reduced maximum; the first attempt's error is reported beside the last.
     errs = []
     for attempt in range(3):
         local = one_backward(False)

@@ -40,12 +40,29 @@ SF_DEVICE int img_off(int row, int chunk) { return row * 128 + ((chunk ^ bswz(ro
 SF_DEVICE bf16x8_t row_frag(const char* img, int row, int chunk) {
   return *reinterpret_cast<const bf16x8_t*>(img + img_off(row, chunk));
 }
+#ifdef SF_LAB
+__device__ int g_tbwd_plain_reads;       // lab (SF_TBWD_LAB=6): plain 8-byte reads in place of the transposed ones (results invalid)
+#endif
 // token-major fragment: lane (l15 = column e of tile et, g) gets rows {r0+4g..+3} and {r0+16+4g..+3}
 template <bool TWO>
 SF_DEVICE bf16x8_t tr_frag(const char* img, int r0, int et, int lane) {
   const int t16 = lane & 15, g = lane >> 4;
   const int row = r0 + 4 * g + (t16 >> 2);
   const int off = img_off(row, 2 * et + ((t16 & 3) >> 1)) + ((t16 & 1) << 3);
+#ifdef SF_LAB
+  if (g_tbwd_plain_reads) {
+    const s16x4_t lo = *reinterpret_cast<const s16x4_t*>(img + off);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    if (TWO) {
+      const s16x4_t hi = *reinterpret_cast<const s16x4_t*>(img + off + 16 * 128);
+      f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    } else {
+      f[4] = f[5] = f[6] = f[7] = 0;
+    }
+    return f;
+  }
+#endif
   const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + off));
   bf16x8_t f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
@@ -287,6 +304,29 @@ SF_DEVICE void tiles_to_patch(char* patch, const f32x4_t (&t)[2][4], int lane) {
     for (int et = 0; et < 4; ++et)
 #pragma unroll
       for (int r = 0; r < 4; ++r) store_patch(patch, a * 16 + 4 * g + r, et * 16 + l15, t[a][et][r]);
+}
+
+// The same patch by 32-bit stores: the two lanes of a column pair exchange the rows the other one writes (even lane: rows 0 and 2 of
+// its four, odd lane: rows 1 and 3), so a lane stores two {column, column + 1} words per tile instead of four 16-bit values — half
+// the LDS store instructions, no sub-dword LDS writes.  Same conversion (v_cvt_pk_bf16_f32), bit-identical patch.
+template <bool TWO>
+SF_DEVICE void tiles_to_patch_pairs(char* patch, const f32x4_t (&t)[2][4], int lane) {
+  constexpr int NT2 = TWO ? 2 : 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const bool odd = l15 & 1;
+#pragma unroll
+  for (int a = 0; a < NT2; ++a)
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+      const f32x4_t v = t[a][et];
+      const float r0 = __shfl_xor(odd ? v[0] : v[1], 1, 64), r1 = __shfl_xor(odd ? v[2] : v[3], 1, 64);
+      const int col = et * 16 + (l15 & ~1);
+      const int row = a * 16 + 4 * g + (odd ? 1 : 0);
+      const unsigned w0 = odd ? pack_bf2(r0, v[1]) : pack_bf2(v[0], r0);
+      const unsigned w1 = odd ? pack_bf2(r1, v[3]) : pack_bf2(v[2], r1);
+      *reinterpret_cast<unsigned*>(patch + img_off(row, col >> 3) + ((col & 7) << 1)) = w0;
+      *reinterpret_cast<unsigned*>(patch + img_off(row + 2, col >> 3) + ((col & 7) << 1)) = w1;
+    }
 }
 
 // All five operand images of a problem in one pass: every global load of the pass is issued before the first LDS write, so a
@@ -535,8 +575,11 @@ hipError_t sf_launch_spatial_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 // temporal: one wave per (batch, patch, head) sequence; wave-private images of NP rows
 // ------------------------------------------------------------------------------------------------
+// `lab` (lab builds only, SF_TBWD_LAB; always 0 in the product library): the device-sharing experiment of DESIGN.md 4 —
+// 1 = no patch writes, 2 = return behind the operand staging, 3 = 64 KB of LDS, 5 = the patch by 32-bit pair stores,
+// 6 = plain reads in place of ds_read_b64_tr_b16, 7 = return behind phase A
 template <int NP>
-__global__ __launch_bounds__(256) void sf_temporal_attn_bwd_kernel(SfAttnBwdArgs a, int nprob) {
+__global__ __launch_bounds__(256) void sf_temporal_attn_bwd_kernel(SfAttnBwdArgs a, int nprob, int lab) {
   constexpr bool TWO = NP > 16;
   constexpr int IMG = NP * 128;
   constexpr int PER_WAVE = 4 * IMG + 2 * NP * 4 + IMG;      // images, lse2/delta, patch
@@ -563,6 +606,9 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_bwd_kernel(SfAttnBwdArgs
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef SF_LAB
+  if (lab == 2) return;
+#endif
 
   BwdView w;
   w.q = iq; w.k = ik; w.v = iv; w.d_o = ig; w.lse2 = lse2; w.delta = delta; w.patch = patch;
@@ -573,22 +619,31 @@ __global__ __launch_bounds__(256) void sf_temporal_attn_bwd_kernel(SfAttnBwdArgs
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef SF_LAB
+  if (lab == 7) return;               // phase A only (row fragments, MFMA, exp2, shuffles; no transposed reads)
+#endif
 
   bf16_t* dqkv = a.d_qkv + h * 64;
+#ifdef SF_LAB
+#define TBWD_PATCH(t) do { if (lab == 5) tiles_to_patch_pairs<TWO>(patch, t, lane); else if (lab != 1) tiles_to_patch<TWO>(patch, t, lane); } while (0)
+#else
+#define TBWD_PATCH(t) tiles_to_patch<TWO>(patch, t, lane)
+#endif
   {
     f32x4_t dk[2][4], dv[2][4];
     phase_b_block<TWO>(w, 0, 1, dk, dv, lane);
-    tiles_to_patch<TWO>(patch, dk, lane);
+    TBWD_PATCH(dk);
     patch_to_global(patch, dqkv + a.D, a.ld_qkv, row_base, row_step, 0, L, NP, lane);
-    tiles_to_patch<TWO>(patch, dv, lane);
+    TBWD_PATCH(dv);
     patch_to_global(patch, dqkv + 2 * a.D, a.ld_qkv, row_base, row_step, 0, L, NP, lane);
   }
   {
     f32x4_t dq[2][4];
     phase_c_block<TWO>(w, 0, 1, dq, lane);
-    tiles_to_patch<TWO>(patch, dq, lane);
+    TBWD_PATCH(dq);
     patch_to_global(patch, dqkv, a.ld_qkv, row_base, row_step, 0, L, NP, lane);
   }
+#undef TBWD_PATCH
 }
 
 hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t s) {
@@ -596,16 +651,21 @@ hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t 
   if ((a.ld_qkv % 8) || (a.ld_o % 8)) return hipErrorInvalidValue;
   const int nprob = a.nseq * a.heads;
   const dim3 grid((nprob + 3) / 4), block(256);
+  const int lab = SF_LAB_SWITCH("SF_TBWD_LAB");       // 0 in the product library
+#ifdef SF_LAB
+  { const int plain = lab == 6; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tbwd_plain_reads), &plain, sizeof(int), 0, hipMemcpyHostToDevice, s); }
+#endif
   if (a.L <= 16) {
-    const size_t lds = 4 * (size_t)(5 * 16 * 128 + 2 * 16 * 4);
-    hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<16>, grid, block, lds, s, a, nprob);
+    size_t lds = 4 * (size_t)(5 * 16 * 128 + 2 * 16 * 4);
+    if (lab == 3) lds = 64 * 1024;      // lab: an allocation that cannot share a CU with the 102 KB probe kernel
+    hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<16>, grid, block, lds, s, a, nprob, lab);
   } else {
     const size_t lds = 4 * (size_t)(5 * 32 * 128 + 2 * 32 * 4);
     static SfPerDeviceOnce attr_set;
     if (attr_set.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_temporal_attn_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<32>, grid, block, lds, s, a, nprob);
+    hipLaunchKernelGGL(sf_temporal_attn_bwd_kernel<32>, grid, block, lds, s, a, nprob, lab);
   }
   return hipGetLastError();
 }

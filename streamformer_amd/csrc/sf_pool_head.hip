@@ -20,6 +20,7 @@
 // GEMM over all token rows), dWk_h += q_h dU_h^T, dq_h = Wk_h dU_h; bk receives exactly zero (its term cancels in the softmax).
 #include "sf_common.h"
 #include "sf_pool_head.h"
+#include "sf_switches.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 v8bf_t;
 SF_DEVICE f32x4_t pmfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
@@ -250,6 +251,13 @@ __global__ __launch_bounds__(256) void sf_pool_probe_kernel(SfPoolArgs p) {
   }
 }
 
+// Both forward kernels request a CU's WHOLE LDS (160 KB), not the 17 - 102 KB they use: no other workgroup then shares their CU.
+// Measured reason ("Device sharing"): with a second process on the device, workgroups of its sf_temporal_attn_bwd_kernel
+// that landed on the same CU made these kernels' results differ in single registers of 16 lanes (about one forward in ten); with the
+// whole-CU request 0 of 900 forwards differed.  One process per GPU never co-schedules another kernel with them (same stream), and
+// the request costs the combine kernel a second round of workgroups (384 on 256 CUs) — SF_POOL_SHARE_CU=1 gives the exact sizes back.
+static size_t pool_lds(size_t used) { return sf_sw(SW_POOL_SHARE_CU) ? used : (size_t)160 * 1024; }
+
 int sf_pool_splits(int F, int N, int heads) {
   (void)heads;
   int S = 1;
@@ -263,7 +271,7 @@ hipError_t sf_launch_pool_probe(const SfPoolArgs& a, hipStream_t s) {
   if (a.heads > 16 || a.D != a.heads * 64 || a.D > 1024 || a.F <= 0 || a.N <= 0 || a.S < 1) return hipErrorInvalidValue;
   if ((a.normalize || (a.probs && !a.probs_raw)) && a.S != 1) return hipErrorInvalidValue;
   if (a.S > 1 && !a.ml) return hipErrorInvalidValue;
-  const size_t lds = ((size_t)PCH * (a.D + 4) + 4 * 64 * 4 + 16 * PCH + 96) * sizeof(float) + (size_t)2 * 16 * (a.D + 8) * sizeof(bf16_t);
+  const size_t lds = pool_lds(((size_t)PCH * (a.D + 4) + 4 * 64 * 4 + 16 * PCH + 96) * sizeof(float) + (size_t)2 * 16 * (a.D + 8) * sizeof(bf16_t));
   const dim3 grid(a.F * a.S);
 #define SF_POOL_CASE(NH, KI)                                                                                          \
   {                                                                                                                   \
@@ -421,13 +429,13 @@ __global__ __launch_bounds__(256) void sf_pool_ctx_kernel(SfPoolCtxArgs p) {
 }
 hipError_t sf_launch_pool_ctx(const SfPoolCtxArgs& a, hipStream_t s) {
   if (a.heads > 16 || a.D != a.heads * 64 || a.D > 1024 || a.F <= 0 || a.S < 1 || a.S > 8 || (a.S > 1 && !a.ml)) return hipErrorInvalidValue;
-  const size_t lds = ((size_t)4 * 64 * 4 + (a.S > 1 ? (size_t)16 * (a.D + 4) + 16 * 8 : 0)) * sizeof(float);
+  const size_t lds = pool_lds(((size_t)4 * 64 * 4 + (a.S > 1 ? (size_t)16 * (a.D + 4) + 16 * 8 : 0)) * sizeof(float));
   const dim3 grid((a.F + 15) / 16, a.heads * 4);
 #define SF_CTX_CASE(KI)                                                                                               \
   {                                                                                                                   \
     static SfPerDeviceOnce once;                                                                                      \
     if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_ctx_kernel<KI>),               \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);               \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
     hipLaunchKernelGGL(sf_pool_ctx_kernel<KI>, grid, dim3(256), lds, s, a);                                           \
   }
   if (a.heads <= 2) SF_CTX_CASE(1)

@@ -35,6 +35,7 @@
   X(G256_STAGGER_PCT, "SF_G256_STAGGER_PCT", "256-column kernel: stagger step as a percentage of the tile period") \
   X(GEMM_MID_MIN_M, "SF_GEMM_MID_MIN_M", "skinny family: first M of the 64 x 64 tiles") \
   X(LN_BWD_BLOCKS, "SF_LN_BWD_BLOCKS", "LayerNorm backward: workgroups (tuning)") \
+  X(POOL_SHARE_CU, "SF_POOL_SHARE_CU", "pooling head: the probe / combine kernels request only the LDS they use instead of a CU's whole 160 KB (A/B; with it other workgroups share their CUs, see DESIGN.md 4 on device sharing)") \
   X(PANEL_MIN_FILL_PCT, "SF_PANEL_MIN_FILL_PCT", "panel kernel: minimum last-round fill") \
   X(PANEL_PAD_CLAMP, "SF_PANEL_PAD_CLAMP", "panel kernel: clamp instead of zero-fill the padding rows (A/B)") \
   X(PANEL_STAGGER_NS, "SF_PANEL_STAGGER_NS", "panel kernel: phase-stagger step in ns") \
