@@ -344,6 +344,22 @@ def test_causal_property_hip(sa):
     assert not torch.equal(a[:, 9:], b[:, 9:])
 
 
+@pytest.mark.gpu
+def test_pool_head_lds_request_is_result_neutral(sa, switches):
+    """The pooling head's probe / combine kernels ask for a CU's whole LDS so that no other workgroup shares their CU (DESIGN.md 4,
+    "Device sharing"); SF_POOL_SHARE_CU=1 gives them their exact sizes back.  Same kernels, same arithmetic: bit-identical outputs
+    (the oracle comparison of this configuration is test_forward_small_vs_golden's)."""
+    cfg = small_cfg()
+    sd = make_state_dict(cfg, seed=4)
+    m = build(sa, cfg, sd, "bf16")
+    xc = frames(91, (2, 8, 3, 48, 48))
+    whole = m(xc.cuda())
+    switches("SF_POOL_SHARE_CU")
+    exact = m(xc.cuda())
+    assert torch.equal(whole.pooler_output, exact.pooler_output) and torch.equal(whole.last_hidden_state, exact.last_hidden_state)
+    assert bool(torch.isfinite(whole.pooler_output).all()) and float(whole.pooler_output.abs().max()) > 0
+
+
 # ------------------------------------------------------------------------------------------------
 # streaming with the KV-cache (golden F4)
 # ------------------------------------------------------------------------------------------------
