@@ -21,6 +21,7 @@
   X(DISABLE_STREAM_FOLD, "SF_DISABLE_STREAM_FOLD", "streaming: standalone LayerNorm launches (A/B)") \
   X(DISABLE_STREAM_GRAPH, "SF_DISABLE_STREAM_GRAPH", "streaming: eager launches instead of hipGraph replay") \
   X(DISABLE_TEMPORAL_DECODE, "SF_DISABLE_TEMPORAL_DECODE", "streaming: general temporal kernel instead of the single-query one") \
+  X(TBWD_OWN_CU, "SF_TBWD_OWN_CU", "training: temporal attention backward as 12-wave workgroups that own a CU instead of 4-wave workgroups with their exact LDS (bit-identical, 65 against 51 us per launch; for jobs that share a device, DESIGN.md 4)") \
   X(TEMPORAL_DECODE_LANE_KEY, "SF_TEMPORAL_DECODE_LANE_KEY", "streaming: single-query temporal kernel with one key per lane (A/B against whole-line loads)") \
   X(DISABLE_TEMPORAL_DMA, "SF_DISABLE_TEMPORAL_DMA", "temporal attention on the register-staged kernel") \
   X(DISABLE_TEMPORAL_DMA_ACC, "SF_DISABLE_TEMPORAL_DMA_ACC", "accurate mode: temporal attention on fp32 q / k / v (test coverage of that path)") \
