@@ -1,4 +1,4 @@
-"""Which buffer of the training forward's pooling head stops repeating under contention ("Open").
+"""Which buffer of the training forward's pooling head stops repeating under contention ("Device sharing").
 
 N passes of forward (+ localization loss + backward unless SF_DET_FWD_ONLY=1) on the same inputs; after every forward the head's saved
 buffers are copied out of the workspace (offsets restated from tcarve, sf_train.hip) and compared bit for bit with the first pass:
@@ -10,7 +10,8 @@ the first buffer in data-flow order that differs names the kernel.  Modes (envir
                     RCCL kernel would be to the pass: other kernels on the same CUs)
   SF_DET_TAG        label printed with every line
   SF_DET_SECONDS    stop after this many seconds;  SF_DET_TS=1: a heartbeat line with the wall clock every 200 passes
-Run two of them concurrently on one device for the cross-process case (tools/head_det.sh)."""
+Run two of them concurrently on one device for the cross-process case (tools/head_det.sh); SF_POOL_SHARE_CU=1 restores the state the finding
+was made in (the pooling-head kernels with their exact LDS sizes)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
