@@ -1,12 +1,15 @@
-"""F13: head widths other than 64, from the REFERENCE run here (needs /root/reference; never travels to the GPU box).
+"""F13 / F14: configurations the HIP path refuses, from the REFERENCE run here (needs /root/reference; never travels to the GPU box).
 
-    python oracle/make_golden_widths.py        # writes tests/golden/f13_widths.npz, asserts oracle == reference
+    python oracle/make_golden_variants.py      # writes tests/golden/f13_widths.npz and f14_attention_types.npz, asserts oracle == reference
 
 The HIP path refuses head_dim != 64 at construction; the reference's config schema
 (models/configuration_streamformer.py:90-135) takes any hidden_size / num_attention_heads, e.g. the SigLIP-so400m shape
 1152 / 16 = 72.  These fixtures pin the ORACLE on two such widths (test infrastructure for the kernels a later round writes):
   so400m-shaped tiny  hidden 144, 2 heads (head_dim 72), intermediate 304, patch 14 on 42 x 42 pixels (N = 9), 2 layers
   narrow heads        hidden 128, 4 heads (head_dim 32), intermediate 256, patch 16 on 48 x 48
+F14: the two attention_type values StreamFormer never instantiates (modeling:914-933): space_only (frame-major embeddings without time
+embedding, attention inside a frame — and the reference's tail then reads the result as patch-major, reproduced as is) and
+joint_space_time (attention over all tokens of a clip), small config, T = 4 and T = 3 of num_frames = 4.
 Inputs are regenerated from seeds; the stored tensors are the reference's own outputs."""
 from __future__ import annotations
 
@@ -52,6 +55,26 @@ def main():
         out[f"{tag}_sha"] = np.frombuffer(state_dict_sha256(sd).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "f13_widths.npz"), **out)
     print("wrote", os.path.join(OUT, "f13_widths.npz"))
+
+    from oracle.make_golden import small_cfg
+    f14 = {}
+    for at in ("space_only", "joint_space_time"):
+        cfg = small_cfg(attention_type=at, num_frames=4)
+        sd = make_state_dict(cfg, seed=14)
+        m = build_ref(ref_models, cfg, sd)
+        f14[f"{at}_sha"] = np.frombuffer(state_dict_sha256(sd).encode(), dtype=np.uint8)
+        for T in (4, 3):
+            x = frames(140 + T, (2, T, 3, 48, 48))
+            with torch.no_grad():
+                r = m(x)
+            o = O.forward(sd, cfg, x)
+            print(f"F14 {at} T={T}")
+            check(f"{at} T={T} last_hidden_state", o["last_hidden_state"], r.last_hidden_state)
+            check(f"{at} T={T} pooler_output", o["pooler_output"], r.pooler_output)
+            f14[f"{at}_T{T}_last_hidden_state"] = r.last_hidden_state.numpy()
+            f14[f"{at}_T{T}_pooler_output"] = r.pooler_output.numpy()
+    np.savez_compressed(os.path.join(OUT, "f14_attention_types.npz"), **f14)
+    print("wrote", os.path.join(OUT, "f14_attention_types.npz"))
 
 
 if __name__ == "__main__":

@@ -213,9 +213,28 @@ def layer_forward(sd, cfg, i: int, h: Tensor, kv: Optional[Dict[str, Tensor]] = 
     hmask = (lambda x, k: x * dropout_mask(x.shape, d_hid, d_seed, i * 8 + k, x.dtype)) if d_hid > 0 else (lambda x, k: x)
 
     if cfg.attention_type != "divided_space_time":
-        # StreamFormer only ever instantiates the divided branch (modeling:934-1004); the other two
-        # TimeSformer modes (modeling:914-933) are outside the hot path and not restated.
-        raise NotImplementedError(cfg.attention_type)
+        # The other two TimeSformer modes (modeling:914-933).  StreamFormer only ever instantiates the divided branch (modeling:934-1004)
+        # and the HIP path refuses these two; they are restated for the forward only (fixture F14), as the checker of a later round.
+        #   space_only: the embeddings stay [B*T, N, D] (no time embedding, modeling:424) -> attention over the N patches of a frame
+        #   joint_space_time: [B, N*T, D] -> attention over all tokens of a clip (their order does not matter to the result)
+        # both: h = h + attention(layernorm_before(h)); h = h + mlp(layernorm_after(h)); the temporal parameters are unused
+        if cfg.attention_type not in ("space_only", "joint_space_time"):
+            raise NotImplementedError(cfg.attention_type)
+        if kv is not None or drop_path is not None or dropout is not None:
+            raise NotImplementedError(f"{cfg.attention_type}: forward only (no cache, no drop rates)")
+        G, S = (B * T, N) if cfg.attention_type == "space_only" else (B, T * N)
+        xs = _ln(h, sd, p + "layernorm_before", eps).reshape(G, S, D)
+        qkv = _lora_lin(xs, sd, p + "attention.attention.qkv", p + "attention.attention.qkv")
+        q, k, v = qkv.split(D, dim=-1)
+        ctx, probs = _mha(q, k, v, heads, None, None)
+        xs = _lora_lin(ctx, sd, p + "attention.output.dense", p + "attention.output.dense").reshape(B, T, N, D)
+        h2 = h + xs
+        out = h2 + _lin(_act(cfg, _lin(_ln(h2, sd, p + "layernorm_after", eps), sd, p + "intermediate.dense")), sd, p + "output.dense")
+        if collect is not None:
+            collect.setdefault("h1", []).append(h)
+            collect.setdefault("h2", []).append(h2)
+            collect.setdefault("attentions", []).append(probs)
+        return out
 
     # ---- temporal attention over T for each (b, n): modeling:937-958 ------------------------
     xt = _ln(h, sd, p + "temporal_layernorm", eps)                  # [B,T,N,D]
@@ -346,6 +365,13 @@ def forward_graph(sd, cfg, pixels: Tensor, output_hidden_states: bool = False,
         hs.append(to_patch_major(h))
     B, T, N, D = h.shape
     seq = _ln(h, sd, "post_layernorm", cfg.layer_norm_eps)            # modeling:1330
+    if cfg.attention_type == "space_only":
+        # The reference's tail (modeling:1333-1347) reads the encoder output as patch-major (B, N, T, D) in every mode, but in this
+        # mode the encoder ran on the frame-major (B*T, N, D) embeddings: row (t, n) of a clip's output is its frame-major row number
+        # n*T + t.  Reproduced as is — both outputs of this (never instantiated) mode mix frames the same way the reference's do.
+        seq = seq.reshape(B, N, T, D).permute(0, 2, 1, 3).contiguous()
+        if output_hidden_states:
+            raise NotImplementedError("space_only: hidden_states are not restated")
     pooled = pooling_head(sd, cfg, seq.reshape(B * T, N, D)).reshape(B, T, D)
     out = {"last_hidden_state": seq, "pooler_output": pooled}
     if output_hidden_states:
