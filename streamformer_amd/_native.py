@@ -14,8 +14,8 @@ import torch  # noqa: F401  (must precede the CDLL below: shared HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstreamformer_hip.so")
-if os.environ.get("SF_LIB") == "lab":      # tools/ only: the -DSF_LAB measurement build (`python streamformer_amd/build.py --lab`)
-    LIB_PATH = os.path.join(_HERE, "libstreamformer_hip_lab.so")
+if os.environ.get("SF_LIB"):      # tools/ only: "lab" = the -DSF_LAB measurement build (`build.py --lab`), other names = A/B builds (`build.py --variant=name -D...`)
+    LIB_PATH = os.path.join(_HERE, "libstreamformer_hip_%s.so" % os.environ["SF_LIB"])
 
 SF_OK = 0
 SF_ERR_INVALID, SF_ERR_STATE, SF_ERR_HIP, SF_ERR_WORKSPACE, SF_ERR_UNKNOWN_KEY, SF_ERR_CAPACITY = -1, -2, -3, -4, -5, -6

@@ -40,13 +40,18 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
-    """lab=True: the measurement variant libstreamformer_hip_lab.so (-DSF_LAB: result-discarding timing switches compiled in),
+def build(force: bool = False, verbose: bool = True, lab: bool = False, variant: str = "", variant_flags=()) -> str:
+    """variant="x" (tools/ only, A/B builds): the product sources with extra -D flags into libstreamformer_hip_x.so, loaded with SF_LIB=x.
+    lab=True: the measurement variant libstreamformer_hip_lab.so (-DSF_LAB: result-discarding timing switches compiled in),
     loaded by tools/ through SF_LIB=lab; never by the package's default path, bench.py or the tests."""
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build_lab" if lab else "build")
     lib_path = os.path.join(HERE, "libstreamformer_hip_lab.so") if lab else LIB
     flags = FLAGS + (["-DSF_LAB", "-I" + CSRC] if lab else [])
+    if variant:
+        objdir = os.path.join(CSRC, "build_" + variant)
+        lib_path = os.path.join(HERE, "libstreamformer_hip_%s.so" % variant)
+        flags = flags + list(variant_flags)
     sources = SOURCES + (LAB_SOURCES if lab else [])
     os.makedirs(objdir, exist_ok=True)
     if lab and not os.path.isdir(LAB_DIR):
@@ -71,7 +76,7 @@ def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    if lab:
+    if lab or variant:
         return lib_path
     # the C++ host example of the C ABI (no Python / torch in that process); tests/test_c_host.py runs it on a GPU
     ex_src = os.path.join(os.path.dirname(HERE), "examples", "host_forward.cpp")
@@ -86,4 +91,5 @@ def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, lab="--lab" in sys.argv))
+    _variant = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")      # --variant=name -DFLAG ...
+    print(build(force="--force" in sys.argv, lab="--lab" in sys.argv, variant=_variant, variant_flags=[a for a in sys.argv[1:] if a.startswith("-D")]))

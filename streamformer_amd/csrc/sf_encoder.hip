@@ -806,7 +806,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     memset(&gt, 0, sizeof(gt));
     gt.a_hi = ws.xn_hi; gt.a_lo = acc ? ws.xn_lo : nullptr; gt.w_hi = e->patch.w_hi; gt.w_lo = acc ? e->patch.w_lo : nullptr;
     gt.M = M; gt.N = D; gt.K = e->Kp; gt.ldc = D; gt.epi = SF_EPI_EMBED_F32; gt.out_f32 = ws.resid;
-    time_folded = sf_gemm_skinny_supported(gt, acc) && !ln_fold_ok(e, M);
+    time_folded = sf_gemm_skinny_supported(gt, acc) && !sf_sw(SW_DISABLE_SKINNY) && !ln_fold_ok(e, M);      // exactly when sf_launch_gemm takes the skinny kernel
   }
   if (!time_folded) HIP_TRY(sf_launch_gather_rows(e->time_tab, ws.te_rows, idx, D, s, sp ? &sp->t_row : nullptr));
   // LN folding (decided here because the folded path lets the embedding GEMM emit bf16(x) + row statistics itself:

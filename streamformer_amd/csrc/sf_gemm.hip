@@ -29,7 +29,7 @@ SF_DEVICE int swz(int row) {
   // 16-byte slot XOR so the 16 rows one ds_read_b128 lane-group touches land on 16 distinct
   // slots of the 256-byte bank row.
   if (BK == 64) return (row >> 1) & 7;
-  return (row >> 2) & 3;
+  return sf_swz64(row);
 }
 
 // stage a [128 x BK] bf16 tile of X (row-major, leading dim K) into linear LDS at `lds`

@@ -36,9 +36,9 @@ SF_DEVICE f32x4_t mfma16b(bf16x8_t a, bf16x8_t b, f32x4_t c) {
 SF_DEVICE bf16x8_t rd_frag(const char* piece, int row, int kc) {
   return *reinterpret_cast<const bf16x8_t*>(piece + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 }
-// bf16x3 (SPLIT) piece: [hi plane | lo plane], each [128 rows][32 k] = 64-byte rows, 16-byte slot XOR (row>>2)&3
+// bf16x3 (SPLIT) piece: [hi plane | lo plane], each [128 rows][32 k] = 64-byte rows, 16-byte slot XOR sf_swz64(row)
 SF_DEVICE bf16x8_t rd_frag_s(const char* piece, int plane, int row, int g) {
-  return *reinterpret_cast<const bf16x8_t*>(piece + plane * 8192 + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+  return *reinterpret_cast<const bf16x8_t*>(piece + plane * 8192 + row * 64 + ((g ^ sf_swz64(row)) << 4));
 }
 
 #ifdef SF_G256_TRACE
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
       const int c = i * G_THREADS + tid_p;
       // SPLIT: one 16-byte chunk per lane and plane, the same offset in the hi and the lo array
       const int prow = SPLIT ? (c >> 2) : (c >> 3), slot = SPLIT ? (c & 3) : (c & 7);
-      const int kc = SPLIT ? (slot ^ ((prow >> 2) & 3)) : (slot ^ ((prow >> 1) & 7));
+      const int kc = SPLIT ? (slot ^ sf_swz64(prow)) : (slot ^ ((prow >> 1) & 7));
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         int rr = prow & 63;

@@ -34,7 +34,7 @@ SF_DEVICE void wait_vmp() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 SF_DEVICE bf16x8_t rd32(const char* piece, int row, int kc) {
-  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
+  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ sf_swz64(row)) << 4));
 }
 
 // SF_PANEL_TRACE (tools/panel_trace_lab.hip only): shader-clock stamps around the segments of the epilogue, summed over waves into
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(P_THREADS) void sf_gemm_panel_kernel(SfGemmArgs p, 
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = i * P_THREADS + tid;
-    const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
+    const int row = c >> 2, kc = (c & 3) ^ sf_swz64(row);
     if (i < 2) {
       // rows past the tile: an offset beyond the buffer's num_records — the DMA returns zeros without touching memory, and the MFMAs of the
       // padding rows (12 of 208 at 196-row panels) run on zero operands (SF_PANEL_PAD_CLAMP=1: round 1-3 behaviour, re-reads of the last row)

@@ -41,10 +41,10 @@ SF_DEVICE void tl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrie
 template <int N>
 SF_DEVICE void tl_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// stage image row = BK bf16; 16-byte slot XOR: BK = 64 (8 slots): (row >> 1) & 7, BK = 32 (4 slots): (row >> 2) & 3 —
+// stage image row = BK bf16; 16-byte slot XOR: BK = 64 (8 slots): (row >> 1) & 7, BK = 32 (4 slots): sf_swz64(row) —
 // conflict-free for the 16-lane groups of ds_read_b128 (same images as sk_frag / rd32)
 template <int BK>
-SF_DEVICE int tl_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+SF_DEVICE int tl_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : sf_swz64(row); }
 template <int BK>
 SF_DEVICE bf16x8_t tl_frag(const char* img, int row, int kc) {
   return *reinterpret_cast<const bf16x8_t*>(img + row * (BK * 2) + ((kc ^ tl_swz<BK>(row)) << 4));

@@ -519,6 +519,7 @@ static TWs tcarve(const sf_trainer* t, void* base, int B, int T) {
     size_t ws2 = 0;
     ws2 = max_sz(ws2, sf_wgrad_partial_floats(Mi, 3 * Di, kRank)); ws2 = max_sz(ws2, sf_wgrad_partial_floats(Mi, kRank, Di));
     ws2 = max_sz(ws2, sf_wgrad_partial_floats(Mi, Di, kRank));
+    ws2 = max_sz(ws2, sf_wgrad_partial_floats(Di, Di, Di));      // temporal_fused_grads on the side stream: dW_o = (tanh(g) W_d)^T G1, M = D
     w.wg_partial_side = c.take<float>(ws2);
   }
   w.dw_scratch = c.take<float>((size_t)3 * D * D);
@@ -907,7 +908,10 @@ static bool side_stream_ready(sf_trainer* t) {
 // far (its operands are complete there); the caller joins at the end of the layer (side_join)
 static hipError_t lin_wgrad_side(const BwdCtx& c, const TLin& l, const bf16_t* dy, const bf16_t* x, int M, bool* forked) {
   sf_trainer* t = const_cast<sf_trainer*>(c.t);
-  if (l.pla < 0 || !side_stream_ready(t)) return lin_wgrad(c, l, dy, x, M);
+  // only the rank-32 factor gradients go to the side stream: ws.wg_partial_side is sized for those shapes.  A LoRA-adapted Linear whose
+  // base weight is NOT frozen (add_lora_spatial without frozen_spatial: scripts/pretrain_streamformer.sh:32-33) also needs the full
+  // [N, K] gradient and stays on the caller's stream with the full-size scratch.
+  if (l.pla < 0 || GG(c.t, c.grads, l.pw, l.pw_off) != nullptr || !side_stream_ready(t)) return lin_wgrad(c, l, dy, x, M);
   hipError_t e;
   if ((e = hipEventRecord(t->ev_fork, c.s)) != hipSuccess) return e;
   if ((e = hipStreamWaitEvent(t->side, t->ev_fork, 0)) != hipSuccess) return e;

@@ -193,7 +193,10 @@ class StreamformerTrainer:
         self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
         # non-finite guard (tools/finetune_tools.py:533-541, utils.py:515-551): checked ON THE DEVICE inside the optimizer
         # kernel — {sticky flag, skipped steps}; the host looks at it only in check_finite() / at checkpoints
-        self._guard = torch.zeros(2, dtype=torch.int32, device=dev) if nonfinite_guard else None
+        # non-finite guard: one {sticky flag, skipped steps} pair PER SET OF HEADS that stepped together (row 0 = "every head" / no heads),
+        # so that reset_nonfinite() can take a skipped step back out of exactly the heads it involved; 32 rows, views of one tensor
+        self._guard = torch.zeros(32, 2, dtype=torch.int32, device=dev) if nonfinite_guard else None
+        self._guard_rows = {}               # frozenset(active heads) -> row of self._guard
         self._last_loss: Optional[torch.Tensor] = None
         # sum of the losses of the current accumulation window (update_freq > 1) — a non-finite micro-step loss stays visible to the
         # guard of the optimizer step that closes the window; with world > 1 it is all-reduced next to the gradients so that every
@@ -412,6 +415,11 @@ class StreamformerTrainer:
         With world > 1 call :meth:`save_checkpoint` (every rank) rather than this method on rank 0 alone: the finite check and the
         per-rank generator states are collectives."""
         self.check_finite(collective=False)
+        if self.world > 1 and stochastic_states is None:
+            import warnings
+            warnings.warn("StreamformerTrainer.checkpoint() on one rank of a world > 1 job stores no per-rank generator states and runs a "
+                          "non-collective finite check: a resumed run will not continue the drop_path / dropout draws. Call "
+                          "save_checkpoint() on every rank instead.", RuntimeWarning, stacklevel=2)
         model = OrderedDict()
         model["logit_scale"] = torch.tensor(math.log(10.0))        # the wrapper's own pair (modeling:1363-1364): never trained,
         model["logit_bias"] = torch.tensor(-2.0)                   # kept so that the reference's load_state_dict finds its keys
@@ -470,16 +478,29 @@ class StreamformerTrainer:
     # ---- guards ------------------------------------------------------------------------------------------
     def nonfinite_steps(self) -> int:
         """Optimizer steps the device-side guard has skipped so far (reads the flag: synchronises with the GPU)."""
-        return 0 if self._guard is None else int(self._guard[1].item())
+        return 0 if self._guard is None else int(self._guard[:, 1].sum().item())
+
+    def _guard_row(self, active) -> torch.Tensor:
+        key = frozenset(active)
+        if key not in self._guard_rows:
+            if len(self._guard_rows) >= self._guard.shape[0] - 1:          # more distinct head sets than rows: share the last row
+                return self._guard[-1]
+            self._guard_rows[key] = len(self._guard_rows)
+        return self._guard[self._guard_rows[key]]
 
     def reset_nonfinite(self) -> int:
         """Acknowledge skipped steps and continue: clears the sticky flag and takes the skipped steps back out of the host-side step
         counts (the device skipped the update, the host had already counted it).  Returns the number of steps that had been skipped."""
         n = self.nonfinite_steps()
         if n:
+            counts = self._guard[:, 1].cpu().tolist()
             self.step_count = max(0, self.step_count - n)
-            for t in self.head_steps:
-                self.head_steps[t] = max(0, self.head_steps[t] - n)
+            for key, row in self._guard_rows.items():        # a head's own step count rewinds only by the skipped steps it took part in
+                for t in key:
+                    self.head_steps[t] = max(0, self.head_steps[t] - counts[row])
+            if counts[-1] and len(self._guard_rows) >= self._guard.shape[0] - 1:      # shared overflow row: heads unknown, rewind all (as before)
+                for t in self.head_steps:
+                    self.head_steps[t] = max(0, self.head_steps[t] - counts[-1])
             self._guard.zero_()
         return n
 
@@ -713,6 +734,7 @@ class StreamformerTrainer:
         self.step_count += 1
         scale = 1.0 / self.world                                  # all-reduce summed; DDP averages
         sumsq = 0
+        active = ()
         if self.task_heads:
             # heads that received a gradient since the last step (micro_step records them; a caller that adds head
             # gradients by hand and never says which gets the plain behaviour: every head steps)
@@ -728,7 +750,7 @@ class StreamformerTrainer:
             if self._guard is not None:
                 ll = self._loss_acc if self._loss_acc_used else self._last_loss
                 nat.check(nat.lib.sf_trainer_set_nonfinite_guard(
-                    self._h, self._guard.data_ptr(), ll.data_ptr() if (ll is not None and ll.dtype == torch.float32 and ll.is_cuda) else None))
+                    self._h, self._guard_row(active).data_ptr(), ll.data_ptr() if (ll is not None and ll.dtype == torch.float32 and ll.is_cuda) else None))
             if clip_grad is not None:
                 nat.check(nat.lib.sf_trainer_grad_sumsq(self._h, self.grads.data_ptr(), self._scratch.data_ptr(), self._stream()))
                 sumsq = self._scratch.data_ptr()

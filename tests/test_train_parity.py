@@ -208,7 +208,7 @@ def _compare_grads(tr, orc, floor=1e-3, scalar_rel=SCALAR_REL):
 
 
 @pytest.mark.parametrize("task_idx", [0, 1])
-@pytest.mark.parametrize("lora,freeze", [(True, True), (False, False)])
+@pytest.mark.parametrize("lora,freeze", [(True, True), (False, False), (True, False)])
 def test_small_model_gradients_match_oracle(task_idx, lora, freeze):
     from oracle import train_oracle as TO
     cfg = small_cfg(add_lora_spatial=lora)
@@ -372,11 +372,11 @@ def test_base_model_gradients_match_oracle():
     _compare_grads(tr, orc)
 
 
-def _base_grad_case(B, T, task, seed):
+def _base_grad_case(B, T, task, seed, freeze=True):
     from oracle import train_oracle as TO
     from streamformer_amd.configuration import siglip_base
     cfg = siglip_base(add_lora_spatial=True)
-    tr, orc = _trainer_and_oracle(cfg, True, seed=seed, lora=True)
+    tr, orc = _trainer_and_oracle(cfg, freeze, seed=seed, lora=True)
     g = torch.Generator().manual_seed(seed + 2)
     x = torch.randn(B, T, 3, 224, 224, generator=g)
     if task == "localization":
@@ -403,6 +403,15 @@ def test_base_model_gradients_match_oracle_at_sixteen_frames():
     """the T = 16 temporal backward at D = 768 / 12 heads — SigLIP-base (LoRA recipe), ONE clip of the
     16 frames the bench times, every trainable tensor's gradient vs CPU autograd (M = 3136 token rows)."""
     _base_grad_case(1, 16, "retrieval", seed=4)
+
+
+def test_base_model_gradients_lora_with_unfrozen_base():
+    """the shipped pretraining recipe passes --enable_lora_spatial WITHOUT --frozen_spatial
+    (scripts/pretrain_streamformer.sh:32-33): the LoRA-adapted spatial Linears then need the rank-32 factor gradients AND the full
+    [3D, D] / [D, D] base-weight gradients.  The side stream's scratch is sized for the rank-32 shapes only, so these Linears must stay
+    on the caller's stream (lin_wgrad_side).  SigLIP-base, one clip of 16 frames (M = 3136: groupable weight-gradient shapes), every
+    trainable tensor against CPU autograd."""
+    _base_grad_case(1, 16, "localization", seed=7, freeze=False)
 
 
 @pytest.mark.skipif(os.environ.get("SF_TEST_BIG_TILES_INNER") != "1", reason="run by test_base_model_gradients_on_the_big_tile_kernels in a child process")
@@ -904,6 +913,9 @@ def test_nonfinite_step_is_skipped_on_the_device_and_reported():
     tr, _ = _trainer_and_oracle(cfg, True, seed=8, lora=True, lr=1e-3, wd=0.05)
     dev = tr.device
     task, x, ti, _ = TO.schedule(cfg, B=2)[0]
+    other, xo, tio, _ = TO.schedule(cfg, B=2)[1]
+    assert other != task
+    tr.micro_step(other, xo.to(dev), _to_dev(tio, dev))        # the other head takes one clean step of its own
     tr.micro_step(task, x.to(dev), _to_dev(ti, dev))
     tr.check_finite()                                          # a finite step raises nothing
     assert tr.nonfinite_steps() == 0
@@ -923,7 +935,8 @@ def test_nonfinite_step_is_skipped_on_the_device_and_reported():
     # micro_step() in between does not re-check the stale NaN loss
     before, hb = tr.step_count, dict(tr.head_steps)
     assert tr.reset_nonfinite() == 1 and tr.step_count == before - 1 and tr.nonfinite_steps() == 0
-    assert all(tr.head_steps[k] == max(0, hb[k] - 1) for k in hb)
+    # only the head the skipped step involved is rewound; the other head's AdamW step count (bias correction) stays
+    assert tr.head_steps[task] == hb[task] - 1 and tr.head_steps[other] == hb[other] == 1
     tr.check_finite()
     tr.optimizer_step()
     assert tr.nonfinite_steps() == 0 and tr._last_loss is None

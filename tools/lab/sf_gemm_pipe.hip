@@ -54,7 +54,7 @@ SF_DEVICE void wait_vmi() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 SF_DEVICE bf16x8_t rd32i(const char* piece, int row, int kc) {
-  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
+  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ sf_swz64(row)) << 4));
 }
 SF_DEVICE float half_sum_dpp_i(float v) {      // sums over lanes 0..31 / 32..63, totals in lanes 31 and 63; all lanes active
   v = dpp_add<0x111, 0xf>(v);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(PI_THREADS) void sf_gemm_pipe_kernel(SfGemmArgs p, 
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
           const int c = i * 64 + lane;
-          const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
+          const int row = c >> 2, kc = (c & 3) ^ sf_swz64(row);
           int ar = m0 + row;
           ar = ar < m_end ? ar : m_end - 1;
           off[i] = ((unsigned)ar * (unsigned)K + kc * 8) * 2u;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(PI_THREADS) void sf_gemm_pipe_kernel(SfGemmArgs p, 
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int c = i * 64 + lane;
-      const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
+      const int row = c >> 2, kc = (c & 3) ^ sf_swz64(row);
       off[i] = ((unsigned)row * (unsigned)K + kc * 8) * 2u;
     }
     auto issue = [&](int u) {

@@ -44,7 +44,7 @@ SF_DEVICE void wait_vmq() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 SF_DEVICE bf16x8_t rd32q(const char* piece, int row, int kc) {
-  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
+  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ sf_swz64(row)) << 4));
 }
 // sum over each half-wave (lanes 0..31 / 32..63) on the DPP path; the totals sit in lanes 31 and 63.  All lanes active.
 SF_DEVICE float half_sum_dpp(float v) {
@@ -113,12 +113,12 @@ __global__ __launch_bounds__(Q_THREADS, 2) void sf_gemm_pp_kernel(SfGemmArgs p, 
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = i * Q_THREADS + tid;
-    const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
+    const int row = c >> 2, kc = (c & 3) ^ sf_swz64(row);
     offW[i] = ((unsigned)(n0 + row) * (unsigned)K + kc * 8) * 2u;
     dstW[i] = Q_A_BYTES + i * 4096 + wave * 1024;
     if (i < 2) {
       const int ci = (i == 1 && wave == 3) ? tid : c;
-      const int rowa = ci >> 2, kca = (ci & 3) ^ ((rowa >> 2) & 3);
+      const int rowa = ci >> 2, kca = (ci & 3) ^ sf_swz64(rowa);
       int ar = m0 + rowa;
       ar = ar < m_end ? ar : m_end - 1;
       offA[i] = ((unsigned)ar * (unsigned)K + kca * 8) * 2u;

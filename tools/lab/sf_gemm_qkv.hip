@@ -45,7 +45,7 @@ SF_DEVICE void q_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 SF_DEVICE bf16x8_t q_rd32(const char* piece, int row, int kc) {
-  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4));
+  return *reinterpret_cast<const bf16x8_t*>(piece + row * 64 + ((kc ^ sf_swz64(row)) << 4));
 }
 // head-block swizzle (same as sf_attention.hip): row fragments of 16 rows and the 8 rows of a half-wave transposed read are conflict-free
 SF_DEVICE int q_bswz(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(Q_THREADS) void sf_gemm_qkv_kernel(SfQkvArgs p, int
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = i * Q_THREADS + tid;
-    const int row = c >> 2, kc = (c & 3) ^ ((row >> 2) & 3);
+    const int row = c >> 2, kc = (c & 3) ^ sf_swz64(row);
     if (i < 2) offA[i] = ((unsigned)src_row(row) * (unsigned)K + kc * 8) * 2u;
     offW[i] = ((unsigned)(n0 + row) * (unsigned)K + kc * 8) * 2u;
   }
