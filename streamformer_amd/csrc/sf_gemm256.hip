@@ -88,6 +88,18 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
   const __amdgpu_buffer_rsrc_t rsrc_wl = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? p.w_lo : p.w_hi), 0, (unsigned)p.N * (unsigned)K * 2u, 0x00020000);
   const int cpx = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+  // walk (bits 8-11 of the fourth argument = column-group width cg in tiles, 0 = the row-major walk above; bit 12 = write-through stores):
+  // row-major, an XCD round is 32/tiles_n row panels x ALL column tiles, so every XCD re-fetches the whole W in every round (r05 counters:
+  // 1.9-2.1x the algorithmic bytes at the fabric).  With cg > 0 the tile order is column-group-major — group j = columns [c0_j, c0_j + w_j),
+  // inside it row panels, inside a panel the group's columns — and XCD x owns the CONTIGUOUS eighth [x * per, (x + 1) * per) of that
+  // order, walked 32 tiles a round: its W slice (w_j x 256 x K) stays the same for all its rounds (one switch at a group boundary) and
+  // an A row panel is fetched once per column group.  Which tile a workgroup computes changes, nothing inside a tile does: bit-identical.
+  const int walk_cg = (stagger_groups >> 8) & 15;
+  const bool store_wt = (stagger_groups >> 12) & 1;
+  stagger_groups &= 255;
+  const int walk_ngrp = walk_cg ? (tiles_n + walk_cg - 1) / walk_cg : 1;
+  const int walk_per = (ntiles + 7) >> 3;
+  const int walk_panels = ntiles / tiles_n;
 
   // Phase stagger: every CU runs the same tile sequence, so without it all 256 CUs hit their HBM-bound
   // C-tile store phase at the same instant (32 MB bursts at the HBM write rate, nobody computing) and then
@@ -110,9 +122,35 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
 #ifdef SF_G256_TRACE
     tr_read = tr_bar1 = tr_mma = tr_bar2 = 0;
 #endif
-    const int tile = (round * 8 + xcd) * cpx + slot_in_xcd;
-    if (tile >= ntiles) break;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
+    int tile = (round * 8 + xcd) * cpx + slot_in_xcd;
+    int m0, n0;
+    if (walk_cg == 15) {
+      // row-major, but every (XCD, stagger group) walks its OWN contiguous run of tiles: the workgroups of one stagger group are the ones in
+      // phase with each other, so only they share an A row panel through the L2 while it is hot (with slot % groups the nine column tiles of a
+      // panel sit in three different phases, 7-14 us apart, and the panel is fetched once per phase)
+      const int sg = stagger_groups, grp = slot_in_xcd % sg, ig = slot_in_xcd / sg;
+      const int n_g = (cpx - grp + sg - 1) / sg;                       // slots of this group
+      const int before = grp * (cpx / sg) + min(grp, cpx % sg);        // slots of the groups in front of it
+      const int x0 = xcd * walk_per, x1 = min(x0 + walk_per, ntiles);
+      const int lo = x0 + (int)((long)(x1 - x0) * before / cpx), hi = x0 + (int)((long)(x1 - x0) * (before + n_g) / cpx);
+      tile = lo + round * n_g + ig;
+      if (tile >= hi) break;
+      m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) << 8;
+    } else if (walk_cg) {
+      const int tloc = round * cpx + slot_in_xcd;
+      tile = xcd * walk_per + tloc;
+      if (tloc >= walk_per || tile >= ntiles) break;
+      int rest = tile, c0 = 0, w = 0;
+      for (int j = 0; j < walk_ngrp; ++j) {                 // balanced widths: the first tiles_n % ngrp groups are one column wider
+        w = tiles_n / walk_ngrp + (j < tiles_n % walk_ngrp ? 1 : 0);
+        if (rest < walk_panels * w) break;
+        rest -= walk_panels * w; c0 += w;
+      }
+      m0 = (rest / w) * BM; n0 = (c0 + rest % w) << 8;
+    } else {
+      if (tile >= ntiles) break;
+      m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) << 8;
+    }
 
     // ---- per-lane DMA source offsets (elements), two 16-byte chunks per piece --------------------
     unsigned offA[2][2], offB[2][2];
@@ -381,7 +419,8 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
               v[j] = pack_bf2(bf2f(v[j] & 0xffffu) * gelu_grad_fast(bf2f(a[j] & 0xffffu)),
                               bf2f(v[j] >> 16) * gelu_grad_fast(bf2f(a[j] >> 16)));
           }
-          *reinterpret_cast<u32x4_t*>(p.out_hi + o) = v;
+          if (store_wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p.out_hi + o), "v"(v) : "memory");     // leaves the XCD's L2 to the operands
+          else *reinterpret_cast<u32x4_t*>(p.out_hi + o) = v;
         }
       }
       __syncthreads();   // staging reads retired before the next tile's DMA lands in the ring
@@ -597,6 +636,12 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
   }
   if (const char* only = sf_sw(SW_G256_STAGGER_ONLY)) {      // A/B: "2" = only the GELU up-projection, "1" = only bf16 outputs
     if (a.epi != atoi(only)) stagger = 0;
+  }
+  {      // tile walk (see the kernel).  SF_G256_WALK = column-group width in tiles (0 = row-major), SF_G256_STORE_WT=1 = sc1 stores of bf16 outputs
+    int cg = 0;
+    if (const char* we = sf_sw(SW_G256_WALK)) cg = atoi(we);
+    if (cg < 0 || cg > 15 || (cg != 15 && cg >= a.N / 256)) cg = 0;      // 15 = row-major with per-stagger-group runs
+    sgroups = (sgroups & 255) | (cg << 8) | (sf_sw(SW_G256_STORE_WT) ? 1 << 12 : 0);
   }
 #define SF_LAUNCH256(E, L, SP) hipLaunchKernelGGL((sf_gemm256_kernel<E, L, BM, SP>), grid, block, lds, s, a, tiles, stagger, sgroups)
   if (a.a_lo && a.w_lo) {      // fp32-accurate mode: hi + lo planes of both operands, three products per fragment pair

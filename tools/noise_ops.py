@@ -68,6 +68,7 @@ for mode in MODES:
     torch.cuda.synchronize()
     t0 = time.time()
     n = 0
+    print(f"[noise] {mode} starting", flush=True)
     while time.time() - t0 < SEC:
         for _ in range(8): one(mode)
         torch.cuda.synchronize()
