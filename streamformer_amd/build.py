@@ -19,10 +19,11 @@ LIB = os.path.join(HERE, "libstreamformer_hip.so")
 SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_switches.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_pool_head.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
 # lab library only (build.py --lab): round-4 kernels that were built to parity and did not beat the product path on the wall clock —
-# the two epilogue-overlap variants of the panel kernel, and the qkv projection with the temporal attention as its epilogue.
+# the two epilogue-overlap variants of the panel kernel, the qkv projection with the temporal attention as its epilogue (clip form, round 4;
+# streamed-frame form, round 6).
 # They live in tools/lab/ (not in the package) and are never part of libstreamformer_hip.so.
 LAB_DIR = os.path.join(os.path.dirname(HERE), "tools", "lab")
-LAB_SOURCES = ["sf_gemm_pp.hip", "sf_gemm_pipe.hip", "sf_gemm_qkv.hip"]
+LAB_SOURCES = ["sf_gemm_pp.hip", "sf_gemm_pipe.hip", "sf_gemm_qkv.hip", "sf_stream_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -56,6 +56,35 @@ SF_DEVICE void split_bf(float x, unsigned int& hi, unsigned int& lo) {
   lo = f2bf(x - bf2f(hi));
 }
 
+// LayerNorm folded into the consumer at small M (LNF): A = bf16(x) of the residual stream, W' = W * gamma.  The wave adds
+// up sum x and sum x^2 of its 16 rows from the very A fragments it feeds to the MFMAs (v_dot2c_f32_bf16: two VALU ops
+// per 4 products; lane (l15, g) sees the k-chunks g, g+4 of row l15), the four k-groups meet by two xor-shuffles, and the
+// epilogue finishes y = rstd (acc - mean s_n) + b'.  No statistics buffer, no extra pass over the rows: the 36 LayerNorm
+// launches of a streamed frame disappear.  The statistics are those of the bf16-rounded rows (what the products see).
+SF_DEVICE void sf_lnf_stats(const bf16x8_t& f, float& s1, float& s2) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  const v8bf h = __builtin_bit_cast(v8bf, f);
+  const v2bf one = {(__bf16)1.0f, (__bf16)1.0f};
+  // pairs taken with shufflevector: indexing a bit-cast u32x4 copy of the fragment (u[j]) made hipcc 7.2 feed dword 0 to
+  // all four dot products (seen in the ISA as four v_dot2c on the same VGPR)
+  const v2bf x0 = __builtin_shufflevector(h, h, 0, 1), x1 = __builtin_shufflevector(h, h, 2, 3);
+  const v2bf x2 = __builtin_shufflevector(h, h, 4, 5), x3 = __builtin_shufflevector(h, h, 6, 7);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x0, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x0, x0, s2, false);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x1, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x1, x1, s2, false);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x2, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x2, x2, s2, false);
+  s1 = __builtin_amdgcn_fdot2_f32_bf16(x3, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2_f32_bf16(x3, x3, s2, false);
+}
+SF_DEVICE void sf_lnf_finish(float s1, float s2, int K, float eps, float& mean, float& rstd) {
+  const float inv_k = 1.0f / (float)K;
+  mean = s1 * inv_k;
+  rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * inv_k - mean * mean, 0.f) + eps);
+}
+
 // hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) is a per-DEVICE setting: run the set-up once for every device a
 // process launches on, not once per process.
 struct SfPerDeviceOnce {
@@ -257,6 +286,21 @@ struct SfQkvArgs {
 };
 bool sf_gemm_qkv_supported(const SfQkvArgs& a, bool fused);                        // sf_gemm_qkv.hip
 hipError_t sf_launch_gemm_qkv(const SfQkvArgs& a, bool fused, hipStream_t s);
+// Streamed frame, bf16 mode: temporal qkv projection (LayerNorm folded, statistics in the kernel) + cache append + single-query temporal
+// attention in one launch (tools/lab/sf_stream_fused.hip, lab library only; vqa_enc:491-560).  Rows m = b * N + n of ONE new frame per stream.
+struct SfStreamQkvArgs {
+  const bf16_t* a;                          // [M, K] bf16(x) of the residual stream
+  const bf16_t* w_frag;                     // W' = W * gamma [3D, K] in MFMA-fragment order: [n-tile][k-step][lane 16 g + l15][8] = W'[16 t + l15][32 j + 8 g ..]
+  const float* bias; const float* ln_s; float ln_eps;      // [3D] b' = b + W beta, s_n = sum_k bf16(W')[n, k]
+  int M, K, D, heads, N;                    // N = patches per frame, M = streams * N, D = heads * 64
+  bf16_t* cache;                            // temporal qkv rows [(b * cap + t) * N + n][3D]: the frame's row is written, rows t < keys are read
+  int cap, slot, Tk;                        // slot = the frame's row, Tk = keys visible (<= 64) when pos_dev == nullptr
+  const int* pos_dev;                       // {slot, tk} in device memory (position-free graph)
+  bf16_t* ctx;                              // [M, D]
+  float scale;
+};
+bool sf_stream_qkv_decode_supported(const SfStreamQkvArgs& a);
+hipError_t sf_launch_stream_qkv_decode(const SfStreamQkvArgs& a, hipStream_t s);
 bool sf_gemm_panel_supported(const SfGemmArgs& a, bool split);                   // sf_gemm_panel.hip
 hipError_t sf_launch_gemm_panel(const SfGemmArgs& a, hipStream_t s);
 bool sf_gemm_pp_supported(const SfGemmArgs& a, bool split);                      // sf_gemm_pp.hip: two workgroups per CU, epilogue beside main loop

@@ -58,6 +58,7 @@ struct DevLinear {          // y = x W^T + b ; W [N,K]
   bf16_t* w_lo = nullptr;
   float* bias = nullptr;
   float* ln_s = nullptr;    // LN-folded variants only: s_n = sum_k bf16(W'[n,k])
+  bf16_t* w_frag = nullptr; // t_qkv_f, bf16 mode: w_hi in MFMA-fragment order for sf_stream_fused.hip (SfStreamQkvArgs::w_frag)
   int N = 0, K = 0;
 };
 struct DevLN { float* g = nullptr; float* b = nullptr; };
@@ -341,7 +342,7 @@ static int upload_linear(sf_encoder* e, const std::vector<float>& w, const std::
 // with W' = W * gamma (per input column), b' = b + W beta, s_n = sum_k W'[n,k] (of the ROUNDED W').
 static int upload_folded_linear(sf_encoder* e, const std::vector<float>& w, const std::vector<float>* bias,
                                 const std::vector<float>& gamma, const std::vector<float>& beta, int N, int K,
-                                DevLinear* out) {
+                                DevLinear* out, bool frag_copy = false) {
   std::vector<float> wf(w.size()), bf(N), sn(N);
   const bool split = e->compute == SF_COMPUTE_BF16X3;      // the MFMAs then see hi + lo planes of W'
   for (int n = 0; n < N; ++n) {
@@ -359,6 +360,16 @@ static int upload_folded_linear(sf_encoder* e, const std::vector<float>& w, cons
   }
   int rc = upload_linear(e, wf, &bf, N, K, out);
   if (rc) return rc;
+  if (frag_copy && !split && N % 16 == 0 && K % 32 == 0) {
+    // fragment-major copy: [n-tile t][k-step j][lane = 16 g + l15][8] = W'[16 t + l15][32 j + 8 g ..]: the 64 lanes of a wave read ONE
+    // contiguous KiB per MFMA operand (the row-major matrix gives every 16-lane group 16 different lines of 16 bytes each)
+    const int NK = K / 32;
+    std::vector<uint16_t> fr((size_t)N * K);
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k)
+        fr[((((size_t)(n / 16) * NK + k / 32) * 64) + ((k % 32) / 8) * 16 + n % 16) * 8 + k % 8] = h_f2bf(wf[(size_t)n * K + k]);
+    if ((rc = dev_upload<uint16_t>(e, fr, &out->w_frag))) return rc;
+  }
   return dev_upload<float>(e, sn, &out->ln_s);
 }
 
@@ -408,7 +419,8 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     TRY(upload_ln(e, p + "layernorm_after", &l.ln_a));
     TRY(upload_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"), 3 * D, D, &l.t_qkv));
     TRY(upload_folded_linear(e, H(p + "temporal_attention.attention.qkv.weight"), Hopt(p + "temporal_attention.attention.qkv.bias"),
-                             H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_f));
+                             H(p + "temporal_layernorm.weight"), H(p + "temporal_layernorm.bias"), 3 * D, D, &l.t_qkv_f,
+                             SF_LAB_SWITCH("SF_STREAM_QKV_FUSE") && e->compute == SF_COMPUTE_BF16 && D % 128 == 0 && D <= 768));
 #ifdef SF_LAB      // lab library only: the permuted copy for sf_gemm_qkv.hip's fused tile (profiles/r04_qkv_fused_ab.txt)
     if (e->compute == SF_COMPUTE_BF16 && D % 128 == 0 && SF_LAB_SWITCH("SF_QKV_FUSED")) {
       // row 384 j + 64 i + c of the permuted matrix = row (i / 2) D + (2 j + (i & 1)) 64 + c of the original (i = 0..5: q0 q1 k0 k1 v0 v1)
@@ -901,6 +913,22 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       q.M = M; q.K = D; q.D = D; q.B = B; q.T = T; q.NP = N; q.out = ws.ctx_hi; q.scale = scale; q.causal = c.enable_causal_temporal;
       if (sf_gemm_qkv_supported(q, true)) {
         HIP_TRY(prof_span(e, 3, s, [&]() { return sf_launch_gemm_qkv(q, true, s); }));
+        t_fused_attn = true;
+      }
+    }
+#endif
+#ifdef SF_LAB
+    // lab library, SF_STREAM_QKV_FUSE=1 (one streamed frame per stream, bf16 mode, cache of <= 64 frames): projection + cache append +
+    // single-query attention in one launch (tools/lab/sf_stream_fused.hip; bit-identical, 15.0 against 6.1 + 7.4 us: a CU's ingest)
+    if (!t_fused_attn && sfold && !acc && T == 1 && layer_tqkv && l.t_qkv_f.ln_s) {
+      SfStreamQkvArgs q;
+      memset(&q, 0, sizeof(q));
+      q.a = ln_in; q.w_frag = l.t_qkv_f.w_frag; q.bias = l.t_qkv_f.bias; q.ln_s = l.t_qkv_f.ln_s; q.ln_eps = c.layer_norm_eps;
+      q.M = M; q.K = l.t_qkv_f.K; q.D = D; q.heads = heads; q.N = N;
+      q.cache = (bf16_t*)tq; q.cap = cap; q.slot = slot; q.Tk = tk; q.pos_dev = sp ? &sp->slot : nullptr;
+      q.ctx = ws.ctx_hi; q.scale = scale;
+      if (l.t_qkv_f.N == 3 * D && sf_stream_qkv_decode_supported(q)) {
+        HIP_TRY(prof_span(e, 3, s, [&]() { return sf_launch_stream_qkv_decode(q, s); }));
         t_fused_attn = true;
       }
     }

@@ -39,34 +39,9 @@ SF_DEVICE bf16x8_t sk_frag(const char* img, int row, int kc) {
 template <int N>
 SF_DEVICE void sk_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// LayerNorm folded into the consumer at small M (LNF): A = bf16(x) of the residual stream, W' = W * gamma.  The wave adds
-// up sum x and sum x^2 of its 16 rows from the very A fragments it feeds to the MFMAs (v_dot2c_f32_bf16: two VALU ops
-// per 4 products; lane (l15, g) sees the k-chunks g, g+4 of row l15), the four k-groups meet by two xor-shuffles, and the
-// epilogue finishes y = rstd (acc - mean s_n) + b'.  No statistics buffer, no extra pass over the rows: the 36 LayerNorm
-// launches of a streamed frame disappear.  The statistics are those of the bf16-rounded rows (what the products see).
-SF_DEVICE void sk_stats(const bf16x8_t& f, float& s1, float& s2) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
-  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
-  const v8bf h = __builtin_bit_cast(v8bf, f);
-  const v2bf one = {(__bf16)1.0f, (__bf16)1.0f};
-  // pairs taken with shufflevector: indexing a bit-cast u32x4 copy of the fragment (u[j]) made hipcc 7.2 feed dword 0 to
-  // all four dot products (seen in the ISA as four v_dot2c on the same VGPR)
-  const v2bf x0 = __builtin_shufflevector(h, h, 0, 1), x1 = __builtin_shufflevector(h, h, 2, 3);
-  const v2bf x2 = __builtin_shufflevector(h, h, 4, 5), x3 = __builtin_shufflevector(h, h, 6, 7);
-  s1 = __builtin_amdgcn_fdot2_f32_bf16(x0, one, s1, false);
-  s2 = __builtin_amdgcn_fdot2_f32_bf16(x0, x0, s2, false);
-  s1 = __builtin_amdgcn_fdot2_f32_bf16(x1, one, s1, false);
-  s2 = __builtin_amdgcn_fdot2_f32_bf16(x1, x1, s2, false);
-  s1 = __builtin_amdgcn_fdot2_f32_bf16(x2, one, s1, false);
-  s2 = __builtin_amdgcn_fdot2_f32_bf16(x2, x2, s2, false);
-  s1 = __builtin_amdgcn_fdot2_f32_bf16(x3, one, s1, false);
-  s2 = __builtin_amdgcn_fdot2_f32_bf16(x3, x3, s2, false);
-}
-SF_DEVICE void sk_ln_finish(float s1, float s2, int K, float eps, float& mean, float& rstd) {
-  const float inv_k = 1.0f / (float)K;
-  mean = s1 * inv_k;
-  rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * inv_k - mean * mean, 0.f) + eps);
-}
+// LayerNorm folded into the consumer at small M (LNF): sf_lnf_stats / sf_lnf_finish in sf_common.h (shared with sf_stream_fused.hip)
+SF_DEVICE void sk_stats(const bf16x8_t& f, float& s1, float& s2) { sf_lnf_stats(f, s1, s2); }
+SF_DEVICE void sk_ln_finish(float s1, float s2, int K, float eps, float& mean, float& rstd) { sf_lnf_finish(s1, s2, K, eps, mean, rstd); }
 
 // TPS = K-tiles consumed per barrier (1 or 2): the loop is a serial chain of wait -> barrier -> LDS reads -> MFMA, a few
 // hundred cycles per step with two MFMAs of work in it, so halving the step count (12 -> 6 at K = 768) is worth more than

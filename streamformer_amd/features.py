@@ -136,7 +136,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--fps", type=float, default=24.0, help="fps of entries that do not state their own")
     ap.add_argument("--start_idx", type=float, default=None)
     ap.add_argument("--end_idx", type=float, default=None)
-    ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--compute_dtype", default="fp32", choices=["bf16", "fp32"])
     ap.add_argument("--batch_windows", type=int, default=64)
     args = ap.parse_args(argv)
     from .modeling import TimesformerMultiTaskingModelSigLIP

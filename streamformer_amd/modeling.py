@@ -379,7 +379,7 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
     base_model_prefix = "timesformer"      # modeling:1073
     main_input_name = "pixel_values"       # modeling:1074
 
-    def __init__(self, config: StreamformerConfig, compute_dtype: Any = "bf16", device: Any = None,
+    def __init__(self, config: StreamformerConfig, compute_dtype: Any = "fp32", device: Any = None,
                  fuse_temporal_proj: bool = True):
         super().__init__()
         if config.attention_type != "divided_space_time":
@@ -501,7 +501,7 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args, config: Optional[StreamformerConfig] = None,
-                        compute_dtype: Any = "bf16", device: Any = None, device_map: Any = None,
+                        compute_dtype: Any = "fp32", device: Any = None, device_map: Any = None,
                         torch_dtype: Any = None, **kwargs):
         path = str(pretrained_model_name_or_path)
         if not os.path.isdir(path):
@@ -907,7 +907,7 @@ class TimesformerVisionTower(nn.Module):
     window that can still be returned is kept (the reference keeps every frame it has ever seen)."""
 
     def __init__(self, vision_tower, vision_tower_cfg: Any = None, delay_load: bool = False, *, context_length: Optional[int] = None,
-                 streaming_mode: Optional[bool] = None, max_frames: Optional[int] = None, compute_dtype: Any = "bf16",
+                 streaming_mode: Optional[bool] = None, max_frames: Optional[int] = None, compute_dtype: Any = "fp32",
                  cache_policy: str = "stop"):
         super().__init__()
         self.is_loaded = False

@@ -142,7 +142,7 @@ class TimesformerUniversalLocalizationHead(_TaskHead):
 class StreamformerForMultiTaskingSigLIP(nn.Module):
     """modeling:1356-1536 without the text tower: ``timesformer`` + per-task heads, one task per call."""
 
-    def __init__(self, config: StreamformerConfig, multi_task_config: Optional[dict] = None, compute_dtype="bf16"):
+    def __init__(self, config: StreamformerConfig, multi_task_config: Optional[dict] = None, compute_dtype="fp32"):
         super().__init__()
         self.config = config
         self.timesformer = TimesformerMultiTaskingModelSigLIP(config, compute_dtype=compute_dtype)

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, streamformer_amd as sa
 cfg = sa.siglip_base()
-m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
 m.load_state_dict(sa.make_state_dict(cfg, 0)); m.to("cuda").eval()
 x = torch.randn(8, 16, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
 with torch.no_grad():

@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, streamformer_amd as sa
 cfg = sa.siglip_base()
-m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
 m.load_state_dict(sa.make_state_dict(cfg, 0)); m.to("cuda").eval()
 for B in (3, 5, 6, 7):
     x = torch.randn(B, 16, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()

@@ -7,7 +7,7 @@ import torch, streamformer_amd as sa
 from oracle import streamformer_oracle as O
 cfg = sa.siglip_base()
 sd = sa.make_state_dict(cfg, 0)
-mb = sa.TimesformerMultiTaskingModelSigLIP(cfg); mb.load_state_dict(sd); mb.to("cuda").eval()
+mb = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16"); mb.load_state_dict(sd); mb.to("cuda").eval()
 ma = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="fp32"); ma.load_state_dict(sd); ma.to("cuda").eval()
 x = torch.randn(1, 16, 3, 224, 224, generator=torch.Generator().manual_seed(1))
 want = O.forward(sd, cfg, x)

@@ -6,7 +6,7 @@ import torch, streamformer_amd as sa
 from streamformer_amd import _native as nat
 cfg = sa.siglip_base()
 sd = sa.make_state_dict(cfg, 0)
-m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
 m.load_state_dict(sd); m.to("cuda").eval()
 x = torch.randn(8, 16, 3, 224, 224, generator=torch.Generator().manual_seed(1))
 xc = x.cuda()

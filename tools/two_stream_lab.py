@@ -8,7 +8,7 @@ cfg = sa.siglip_base()
 sd = sa.make_state_dict(cfg, 0)
 ms = []
 for _ in range(2):
-    m = sa.TimesformerMultiTaskingModelSigLIP(cfg)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
     m.load_state_dict(sd); m.to("cuda").eval()
     ms.append(m)
 x = torch.randn(8, 16, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
