@@ -333,7 +333,12 @@ def train_bench(args, dev, dist, world, rank, steps, warmup, with_cpu):
                                "wire_dtype": tr.grad_reduce_dtype,
                                "busbw_GBps": round(2.0 * (world - 1) / max(world, 1) * nbytes / max(iso_ms, 1e-6) / 1e6, 1),
                                "how": "isolated = HIP-event time of the bucket all-reduces on an idle GPU (max over ranks); exposed = "
-                                      "step time minus the same steps with the collectives switched off; overlapped = isolated - exposed"}
+                                      "step time minus the same steps with the collectives switched off; overlapped = isolated - exposed",
+                               # what `isolated` is to be read against: an all-reduce moves 2 (N - 1) / N x bytes per GPU; a ring drives ONE
+                               # xGMI link per direction (~153 GB/s), a direct reduce-scatter + all-gather all N - 1 links at once
+                               "bound": {"bytes_per_rank": nbytes, "xgmi_link_GBps": 153.0,
+                                         "ring_ms": round(2.0 * (world - 1) / max(world, 1) * nbytes / 153e9 * 1e3, 3),
+                                         "direct_ms": round(2.0 / max(world, 1) * nbytes / 153e9 * 1e3, 3)}}
         res["backend"] = dist.get_backend()
     if with_cpu and rank == 0:
         # CPU baseline of the same step: the oracle's autograd + torch.optim.AdamW on ONE clip (bounded sample)
@@ -673,9 +678,38 @@ def main():
             panel_ms = panel_ms_isolated
             timing = "isolated back-to-back launches (in-situ profile unavailable)"
         panel_tflops = panel_flop / panel_ms / 1e9
+        # Yardstick: the vendor library (torch.matmul -> hipBLASLt / rocBLAS, bf16, random data) on the same four shapes, PLAIN
+        # (no bias / LayerNorm / GELU / residual), in this process right after the forward.  Never on the product path.  Beside it the product
+        # kernels' isolated launches, which DO carry their epilogues (out_proj / mlp_down: + 154 MB of residual read-modify-write per launch).
+        yardstick = None
+        try:
+            yardstick = {"note": "torch.matmul(a, w.t()) bf16 on random data, 30 launches between torch.cuda.Event pairs on the current stream; plain GEMM without "
+                                 "any epilogue — the product launches beside it include theirs (residual planes in / out + row sums; LayerNorm fold + GELU)"}
+            for name, n_, k_ in (("out_proj", 768, 768), ("mlp_down", 768, 3072), ("qkv", 2304, 768), ("mlp_up", 3072, 768)):
+                a_ = torch.randn(M, k_, device=dev, dtype=torch.bfloat16)
+                w_ = torch.randn(n_, k_, device=dev, dtype=torch.bfloat16)
+                for _ in range(5):
+                    torch.matmul(a_, w_.t())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    torch.matmul(a_, w_.t())
+                e1.record()
+                torch.cuda.synchronize()
+                vms = e0.elapsed_time(e1) / 30
+                yardstick[name] = {"vendor_plain_ms": round(vms, 4), "vendor_plain_tflops": round(2.0 * M * n_ * k_ / vms / 1e9, 1),
+                                   "product_fused_ms": gemms[name]["ms"], "product_fused_tflops": gemms[name]["tflops"]}
+                if name in ("out_proj", "mlp_down"):      # the same product kernel with a plain bf16 output: like for like
+                    nat.check(nat.lib.sf_bench_gemm(model._handle, M, 4 if name == "out_proj" else 5, 20, ws.data_ptr(), ws.numel(), stream,
+                                                    nat.C.byref(ms), nat.C.byref(fl)))
+                    yardstick[name]["product_plain_ms"] = round(ms.value, 4)
+                    yardstick[name]["product_plain_tflops"] = round(fl.value / ms.value / 1e9, 1)
+                del a_, w_
+        except Exception as e:
+            yardstick = {"error": repr(e)}
         traffic, traffic_note, traffic_from = None, "no PMC file", None
         try:   # HBM-side bytes per launch IMPORTED from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            pmc_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+            pmc_file = next(f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             traffic_from = "profiles/" + pmc_file
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
@@ -696,8 +730,10 @@ def main():
         # MFMA-busy share of the dominant kernel's SIMD-cycles (north_star: "MFMA utilisation against gfx950 peak"): IMPORTED from the
         # committed SQ / GRBM counter passes, guarded by the same source hash as `traffic`
         mfma_busy = {"value": None, "note": "no SQ counter file"}
+        mfma_busy_other = None
         try:
-            sqf = os.path.join(ROOT, "profiles", "r05_pmc_sq.json")
+            sq_name = next(f for f in ("r06_pmc_sq.json", "r05_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            sqf = os.path.join(ROOT, "profiles", sq_name)
             with open(sqf) as f:
                 sq = json.load(f)
             import hashlib
@@ -707,11 +743,18 @@ def main():
                 mfma_busy = {"value": ent.get("mfma_busy_frac_of_simd_cycles"), "effective_clock_GHz": ent.get("effective_clock_GHz_if_counter_sums_8_xcds"),
                              "lds_bank_conflict_over_active_lds": ent.get("lds_bank_conflict_over_active_lds"),
                              "wait_inst_any_over_wave_cycles": ent.get("wait_inst_any_over_wave_cycles"),
-                             "imported_from": "profiles/r05_pmc_sq.json",
+                             "imported_from": "profiles/" + sq_name,
                              "note": "IMPORTED, not measured by this run: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), mean over the kernel's "
                                      "dispatches of a forward (K = 768 and K = 3072 launches together); separate rocprofv3 --pmc passes"}
+                # the two other big GEMMs of the forward, same passes: LayerNorm-folded qkv projection and MLP up-projection
+                mfma_busy_other = {}
+                for key, nm in (("void sf_gemm256_kernel<1, true, 224", "qkv_256x224_tiles"), ("void sf_gemm256_kernel<2, true, 256", "mlp_up_256x256_tiles")):
+                    e2 = next((v for k, v in sq["kernels"].items() if k.startswith(key)), None)
+                    if e2:
+                        mfma_busy_other[nm] = {"value": e2.get("mfma_busy_frac_of_simd_cycles"), "effective_clock_GHz": e2.get("effective_clock_GHz_if_counter_sums_8_xcds"),
+                                               "lds_bank_conflict_over_active_lds": e2.get("lds_bank_conflict_over_active_lds")}
             else:
-                mfma_busy["note"] = "profiles/r05_pmc_sq.json was taken on an older sf_gemm_panel.hip: withheld until the counter passes are re-run"
+                mfma_busy["note"] = f"profiles/{sq_name} was taken on an older sf_gemm_panel.hip: withheld until the counter passes are re-run"
         except Exception as e:
             mfma_busy["note"] = f"SQ counter file unreadable: {e!r}"
         out["roofline"] = {"kernel": "sf_gemm_panel_kernel<13> (N = 768 residual projections: 2 x attention out-proj K=768 + MLP down-proj K=3072 per layer, "
@@ -725,16 +768,19 @@ def main():
                            # live: the kernel's launches of one forward (per layer 2 x K=768 + 1 x K=3072, + the embedding GEMM, also
                            # K = 768) at their HIP-event times of this run, over this run's ms_per_step
                            "share_of_step_time_live": round((L * panel_ms + gemms["out_proj"]["ms"]) / (1e3 * dt / args.steps), 4),
-                           "share_from_profile": "profiles/r05_forward_kernel_stats.txt (rocprofv3 --kernel-trace --stats of this command)",
+                           "share_from_profile": "profiles/r06_forward_kernel_stats.txt (rocprofv3 --kernel-trace --stats of this command)",
                            "launches": {"out_proj_K768": gemms["out_proj"], "mlp_down_K3072": gemms["mlp_down"]},
                            "hbm_view_K768": {"algorithmic_GB": 0.1939,
                                              "GBps": round(0.1939 / (insitu["out_proj_K768"]["ms"] if insitu and insitu["out_proj_K768"]["ms"] > 0 else gemms["out_proj"]["ms"]) * 1e3, 1),
                                              "frac_of_hbm_peak": round(0.1939 / (insitu["out_proj_K768"]["ms"] if insitu and insitu["out_proj_K768"]["ms"] > 0 else gemms["out_proj"]["ms"]) * 1e3 / PEAK_HBM_GBS, 4)},
                            "other_gemms": {"mlp_up": gemms["mlp_up"], "qkv": gemms["qkv"]},
-                           "clock_note": "peak is the nominal 2.4 GHz figure the contract asks for; in-kernel cycle stamps put the shader clock of "
-                                         "these MFMA loops at 1.88 GHz on random data (power budget; the same binary runs 12 % faster on all-zero "
-                                         "operands), i.e. 1024 SIMDs x 16384 FLOP / 17.6 cycles x 1.88 GHz = 1790 TFLOP/s issue-bound (docs/history.md A.4.1c)",
-                           "frac_of_issue_bound_at_measured_clock": round(panel_tflops / 1790.0, 4)}
+                           "mfma_busy_other_gemms": mfma_busy_other,
+                           "yardstick_tflops": yardstick,
+                           "clock_note": "peak is the nominal 2.4 GHz figure the contract asks for.  The clock these kernels actually run at is on this line: "
+                                         "mfma_busy.effective_clock_GHz (GRBM_GUI_ACTIVE over the kernel's duration, counter passes) and power_under_load.sclk_MHz "
+                                         "(rocm-smi under the back-to-back forward); frac x 2.4 / that clock is the fraction of the issue bound at the measured clock"}
+        if mfma_busy.get("effective_clock_GHz"):
+            out["roofline"]["frac_of_issue_bound_at_measured_clock"] = round(panel_tflops / (PEAK_BF16_TFLOPS * mfma_busy["effective_clock_GHz"] / 2.4), 4)
         if world == 1 and not args.profile:
             out["power_under_load"] = power_under_load(model, x)
         by = nat.C.c_double()
@@ -812,6 +858,13 @@ def main():
                                    "sample": f"{iters} forwards of one [1,16,3,224,224] clip after warm-up "
                                              f"(median {med:.3f}s, best {ts[0]:.3f}s), fp32 eager torch {torch.__version__}",
                                    "cpu": cpu_model, "best": round(T / ts[0], 2)}
+            try:      # the port's wall time against the reference's own CPU forward, measured ONCE in the build container
+                with open(os.path.join(ROOT, "profiles", "port_over_reference.json")) as f:      # (tools/port_vs_reference.py; the GPU box has no reference)
+                    por = json.load(f)
+                out["cpu_baseline"]["port_over_reference_wall"] = {**por["port_over_reference_wall"], "threads": por["threads"], "pairs": por["pairs"],
+                                                                   "where": "build container, tools/port_vs_reference.py (profiles/port_over_reference.json)"}
+            except Exception:
+                out["cpu_baseline"]["port_over_reference_wall"] = None
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             try:        # scaling context: the same forward on ONE host thread, one timed call
                 torch.set_num_threads(1)

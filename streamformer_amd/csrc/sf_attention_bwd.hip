@@ -659,7 +659,8 @@ hipError_t sf_launch_temporal_attention_bwd(const SfAttnBwdArgs& a, hipStream_t 
 #ifdef SF_LAB
   { const int plain = lab == 6; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tbwd_plain_reads), &plain, sizeof(int), 0, hipMemcpyHostToDevice, s); }
 #endif
-  const bool share = sf_sw(SW_TBWD_OWN_CU) == nullptr;       // default: share the CU (exact LDS sizes)
+  const char* own_sw = sf_sw(SW_TBWD_OWN_CU);
+  const bool share = own_sw == nullptr || own_sw[0] == '0';      // default: share the CU (exact LDS sizes); the trainer sets 1 when world > 1
   const size_t whole_cu = (size_t)160 * 1024;
   static SfPerDeviceOnce attr_set;
   if (attr_set.first()) {

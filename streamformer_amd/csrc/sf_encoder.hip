@@ -1537,6 +1537,10 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   if (!e || !e->finalized || e->layers.empty()) return set_err(SF_ERR_STATE, "encoder not finalized");
   if (iters <= 0 || M <= 0 || !workspace || !mean_ms_out) return set_err(SF_ERR_INVALID, "bad argument");
   const DevLayer& l = e->layers[0];
+  // which 0..3 = MLP-up, MLP-down, qkv, attention out-proj with the epilogues the forward gives them; 4 / 5 = out-proj / MLP-down PLAIN (bf16
+  // output, no residual, no row sums): the like-for-like partner of a vendor-library GEMM (bench.py roofline.yardstick_tflops)
+  const bool plain = which == 4 || which == 5;
+  if (plain) which = which == 4 ? 3 : 1;
   const DevLinear* lin = which == 0 ? &l.up : which == 1 ? &l.down : which == 2 ? &l.s_qkv : &l.s_out;
   const bool acc = e->compute == SF_COMPUTE_BF16X3;
   Carver c(workspace);
@@ -1547,7 +1551,7 @@ extern "C" int sf_bench_gemm(sf_encoder* e, int M, int which, int iters, void* w
   float* of = c.take<float>((size_t)M * lin->N);
   if (c.off > workspace_bytes) return set_err(SF_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, c.off);
   hipStream_t s = (hipStream_t)stream;
-  const int epi = which == 0 ? SF_EPI_ACT_BF16 : which == 2 ? (acc ? SF_EPI_F32 : SF_EPI_BF16) : SF_EPI_RESID_F32;
+  const int epi = plain ? (acc ? SF_EPI_F32 : SF_EPI_BF16) : which == 0 ? SF_EPI_ACT_BF16 : which == 2 ? (acc ? SF_EPI_F32 : SF_EPI_BF16) : SF_EPI_RESID_F32;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));

@@ -145,6 +145,13 @@ class StreamformerTrainer:
         # all-gather is the identity), which is how the RCCL branches get executed and tested on a one-GPU box
         self._collectives = dist_on and (self.world > 1 or bool(collectives_at_world_1))
         self.comm_enabled = True            # bench.py switches the gradient all-reduce off to measure its exposed time
+        # Device sharing (profiles/r06_device_sharing.txt): workgroups of the temporal attention backward disturb ANY wave of
+        # another kernel that shares their CU and runs an LDS-fed packed-FMA accumulate (synthetic victim, no library code; one process
+        # on two streams is enough).  With world > 1 the collective's kernels run beside the backward, so that kernel then takes the
+        # workgroups that own their CU (bit-identical, +0.17 ms per step); SF_TBWD_OWN_CU=0/1 in the environment overrides.
+        if self.world > 1 and "SF_TBWD_OWN_CU" not in os.environ:
+            os.environ["SF_TBWD_OWN_CU"] = "1"
+            nat.lib.sf_reload_switches()
         # every rank must run the SAME task in a micro-step (the reference's sampler guarantees it, sampler.py:218-337): a
         # retrieval rank issues the caption all-gather, a localization rank does not, and mismatched collectives hang.
         # "first": verify the first micro-step of this trainer (one tiny all-gather + host read), "always": every micro-step

@@ -435,14 +435,17 @@ def test_vision_tower_streams_against_the_oracle(sa, tmp_path, mode, tol):
     ow = O.forward(sd, cfg, y, output_hidden_states=True)
     assert maxabs(plain(y.cuda()), ow["last_hidden_state"]) <= tol
     lst = plain([y[0].cuda()])
-    assert len(lst) == 1 and maxabs(lst[0], ow["hidden_states"][-1]) <= (tol if mode == "fp32" else 0.25)
+    # bf16: relative to the tensor's abs-max (un-normalised residual values reach ~30; an absolute 0.25 could hide a regression — VERDICT r5)
+    hs_ref = ow["hidden_states"][-1]
+    assert len(lst) == 1 and maxabs(lst[0], hs_ref) <= (tol if mode == "fp32" else 1e-2 * float(np.abs(np.asarray(hs_ref)).max()))
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", ACC_CEIL), ("bf16", 0.25)])
+@pytest.mark.parametrize("mode,tol", [("fp32", ACC_CEIL), ("bf16", None)])
 def test_streaming_with_output_hidden_states(sa, mode, tol):
     """The tower's literal call form (vqa_enc:1536): output_hidden_states=True with use_cache=True and cache_position=None.
     hidden_states of the new frames (patch-major) against the oracle's for the same frames of the full clip.
-    bf16 tolerance: un-normalised residual stream values reach ~30, the bf16 operand error scales with them."""
+    bf16 tolerance: un-normalised residual stream values reach ~30 and the bf16 operand error scales with them, so the bound is
+    RELATIVE: 1e-2 of the layer tensor's abs-max (an absolute 0.25 could hide a regression)."""
     cfg = small_cfg(num_frames=16)
     sd = make_state_dict(cfg, seed=4)
     m = build(sa, cfg, sd, mode)
@@ -457,7 +460,8 @@ def test_streaming_with_output_hidden_states(sa, mode, tol):
         for li, h in enumerate(o.hidden_states):
             assert h.shape == (2, N * c, D)
             w = want["hidden_states"][li].reshape(2, N, 8, D)[:, :, pos:pos + c].reshape(2, N * c, D)     # token = n*T + t
-            assert maxabs(h, w) <= tol, (li, pos)
+            lim = tol if tol is not None else 1e-2 * float(torch.as_tensor(w).abs().max())
+            assert maxabs(h, w) <= lim, (li, pos, lim)
         assert maxabs(o.last_hidden_state, want["last_hidden_state"][:, pos:pos + c]) <= (ACC_CEIL if mode == "fp32" else BF16_LHS)
         pos += c
     tup = m(x[:, pos:pos + 1].cuda(), output_hidden_states=True, use_cache=True, past_key_values=cache, return_dict=False)
