@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamformer_hip.so")
-SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_switches.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_pool_head.hip", "sf_loss.hip", "sf_encoder.hip",
+SOURCES = ["sf_gemm.hip", "sf_gemm256.hip", "sf_gemm_panel.hip", "sf_gemm_skinny.hip", "sf_gemm_tile.hip", "sf_switches.hip", "sf_rowwise.hip", "sf_attention.hip", "sf_attention_generic.hip", "sf_pool_head.hip", "sf_loss.hip", "sf_encoder.hip",
            "sf_train_kernels.hip", "sf_wgrad.hip", "sf_attention_bwd.hip", "sf_train.hip"]
 # lab library only (build.py --lab): round-4 kernels that were built to parity and did not beat the product path on the wall clock —
 # the two epilogue-overlap variants of the panel kernel, the qkv projection with the temporal attention as its epilogue (clip form, round 4;

@@ -831,6 +831,7 @@ bool sf_spatial_planes_ok(int N, bool probs) {
 }
 
 hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
+  if (a.head_dim && a.head_dim != HD) return sf_launch_attention_generic(a, a.head_dim, false, s);      // sf_attention_generic.hip
   if (a.D != a.heads * HD || a.N <= 0 || a.frames <= 0) return hipErrorInvalidValue;
   if (a.drop.on && (accurate || a.probs || a.N > 224 || sf_sw(SW_DISABLE_SPATIAL_DMA) || (a.row_pitch_kv % 8))) return hipErrorInvalidValue;   // dropout: DMA kernel only
   const int nkp = (a.N + 31) & ~31;
@@ -1508,6 +1509,7 @@ bool sf_temporal_planes_ok(int Tq, int Tk) {
 }
 
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s) {
+  if (a.head_dim && a.head_dim != HD) return sf_launch_attention_generic(a, a.head_dim, true, s);       // sf_attention_generic.hip
   if (a.D != a.heads * HD || a.Tq <= 0 || a.Tk <= 0 || a.B <= 0 || a.N <= 0) return hipErrorInvalidValue;
   // dropout on the probabilities (training forward): the DMA-staged whole-clip kernel only
   if (a.drop.on && (accurate || a.Tq == 1 || a.Tq > 16 || a.Tk > 32 || (a.row_pitch_kv % 8) || sf_sw(SW_DISABLE_TEMPORAL_DMA))) return hipErrorInvalidValue;

@@ -331,7 +331,8 @@ hipError_t sf_launch_stream_params(SfStreamParams* dst, const SfStreamParams& v,
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
                               int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* norm = nullptr,
                               const SfStreamParams* sp = nullptr,      // sp != nullptr: pixels = sp->pixels (device read)
-                              SfStreamParams* sp_write = nullptr, const SfStreamParams* sp_value = nullptr);
+                              SfStreamParams* sp_write = nullptr, const SfStreamParams* sp_value = nullptr,
+                              int Kpad = 0);       // > C * P * P: row pitch of the patch matrix, zero-filled past the patch vector
                               // sp_write: the launch also stores *sp_value there (the streamed frame's parameter block rides on the
                               // patch extraction instead of a launch of its own)
 // fp32 [n] -> bf16 hi (+lo)
@@ -395,6 +396,7 @@ struct SfAttnArgs {
                                       // tk keys, all of them visible
   bf16_t* ctx_hi; bf16_t* ctx_lo;     // [rows, D] output (lo only in accurate mode)
   int D;
+  int head_dim;                       // 0 or 64: the tuned kernels of sf_attention.hip; any other multiple of 8 up to 128: sf_attention_generic.hip
   float* lse2_out;                    // spatial only, optional: base-2 log-sum-exp of the scaled scores per query,
                                       // [frames, heads, N] fp32 (kept by the training forward for the backward kernel)
   float* probs;                       // spatial only, optional: softmax probabilities [frames, heads, N, N] fp32
@@ -406,6 +408,8 @@ hipError_t sf_launch_spatial_attention(const SfAttnArgs& a, bool accurate, hipSt
 bool sf_spatial_planes_ok(int N, bool probs);
 bool sf_temporal_planes_ok(int Tq, int Tk);
 hipError_t sf_launch_temporal_attention(const SfAttnArgs& a, bool accurate, hipStream_t s);
+bool sf_attention_generic_supported(const SfAttnArgs& a, int head_dim);            // sf_attention_generic.hip: head_dim % 8 == 0, <= 128
+hipError_t sf_launch_attention_generic(const SfAttnArgs& a, int head_dim, bool temporal, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // loss heads

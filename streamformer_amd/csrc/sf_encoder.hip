@@ -73,7 +73,7 @@ struct DevLayer {
 struct sf_encoder {
   sf_config cfg;
   int device = 0;
-  int N = 0, D = 0, I = 0, L = 0, Kp = 0;
+  int N = 0, D = 0, I = 0, L = 0, Kp = 0, hd = 64;      // I, Kp: padded to multiples of 64 (see sf_create)
   std::map<std::string, HostTensor> host;   // staged fp32 copies until finalize
   std::map<std::string, std::vector<int64_t>> expected;
   bool finalized = false;
@@ -90,6 +90,7 @@ struct sf_encoder {
   // pooling head with the k / v projections of the tokens folded away (sf_pool_head.hip): U_h = Wk_h^T q_h as hi + lo bf16
   // planes [16, D] (q = the projected, scaled probe), the value projection and its bias in fp32
   bf16_t* head_u_hi = nullptr; bf16_t* head_u_lo = nullptr;
+  float* head_u = nullptr;    // [16, D] fp32
   float* head_wv = nullptr;   // [D, D]
   float* head_bv = nullptr;   // [D]
   size_t weight_bytes = 0;
@@ -200,15 +201,17 @@ extern "C" int sf_create(const sf_config* cfg, int device, sf_encoder** out) {
   const sf_config& c = *cfg;
   if (c.hidden_size <= 0 || c.num_attention_heads <= 0 || c.hidden_size % c.num_attention_heads)
     return set_err(SF_ERR_INVALID, "hidden_size %d not divisible by heads %d", c.hidden_size, c.num_attention_heads);
-  if (c.hidden_size / c.num_attention_heads != 64)
-    return set_err(SF_ERR_INVALID, "head_dim %d unsupported: the gfx950 attention kernels are built for head_dim 64",
-                   c.hidden_size / c.num_attention_heads);
+  {   // head_dim 64: the tuned attention kernels; any other multiple of 8 up to 128 (SigLIP-so400m: 72): sf_attention_generic.hip
+    const int hd = c.hidden_size / c.num_attention_heads;
+    if (hd < 8 || hd > 128 || hd % 8)
+      return set_err(SF_ERR_INVALID, "head_dim %d unsupported: multiples of 8 from 8 to 128 (64 runs on the tuned kernels, the others on the generic fp32 attention kernel)", hd);
+  }
   if (c.num_attention_heads > 16)
     return set_err(SF_ERR_INVALID, "%d attention heads unsupported: the pooling-head kernels hold at most 16 heads per MFMA tile", c.num_attention_heads);
-  if (c.hidden_size % 64 || c.intermediate_size % 64)
-    return set_err(SF_ERR_INVALID, "hidden_size and intermediate_size must be multiples of 64");
-  if (c.patch_size % 8 || (c.num_channels * c.patch_size * c.patch_size) % 64)
-    return set_err(SF_ERR_INVALID, "patch_size must be a multiple of 8 and C*P*P a multiple of 64");
+  // intermediate_size and C*P*P need no alignment: the weights are zero-padded to multiples of 64 at upload (gelu(0) = 0 and zero
+  // weight columns make the padding exact): SigLIP-so400m has I = 4304 and 14 x 14 patches (K = 588)
+  if (c.hidden_size % 64 || c.intermediate_size <= 0 || c.patch_size <= 0 || c.num_channels <= 0)
+    return set_err(SF_ERR_INVALID, "hidden_size must be a multiple of 64; intermediate_size, patch_size, num_channels positive");
   if (c.image_size % c.patch_size) return set_err(SF_ERR_INVALID, "image_size not a multiple of patch_size");
   if (c.hidden_act < 0 || c.hidden_act > 2) return set_err(SF_ERR_INVALID, "unsupported hidden_act code %d", c.hidden_act);
   if (c.num_frames <= 0 || c.num_frames > 256) return set_err(SF_ERR_INVALID, "num_frames must be in 1..256");
@@ -216,10 +219,11 @@ extern "C" int sf_create(const sf_config* cfg, int device, sf_encoder** out) {
   e->cfg = c;
   e->device = device;
   e->D = c.hidden_size;
-  e->I = c.intermediate_size;
+  e->I = (c.intermediate_size + 63) / 64 * 64;          // padded: rows / columns past cfg.intermediate_size are zero weights
   e->L = c.num_hidden_layers;
   e->N = (c.image_size / c.patch_size) * (c.image_size / c.patch_size);
-  e->Kp = c.num_channels * c.patch_size * c.patch_size;
+  e->Kp = (c.num_channels * c.patch_size * c.patch_size + 63) / 64 * 64;      // padded patch-vector length (zero columns)
+  e->hd = c.hidden_size / c.num_attention_heads;
   build_expected(e);
   *out = e;
   return SF_OK;
@@ -401,12 +405,28 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
   e->weight_bytes = 0;
   e->compute = compute;
   e->fused_temporal = fuse_temporal_proj != 0;
-  const int D = e->D, I = e->I;
+  const int D = e->D, I = e->I, Ir = e->cfg.intermediate_size;
   auto H = [&](const std::string& k) -> std::vector<float>& { return e->host[k].data; };
   auto Hopt = [&](const std::string& k) -> std::vector<float>* { return e->host.count(k) ? &e->host[k].data : nullptr; };
+  // zero padding of a [rows, cols] matrix to [rows_p, cols_p] (intermediate_size -> I, C*P*P -> Kp); a no-op copy when nothing changes
+  auto pad2 = [](const std::vector<float>& w, int rows, int cols, int rows_p, int cols_p) {
+    if (rows == rows_p && cols == cols_p) return w;
+    std::vector<float> o((size_t)rows_p * cols_p, 0.f);
+    for (int r = 0; r < rows; ++r) std::copy(w.begin() + (size_t)r * cols, w.begin() + (size_t)(r + 1) * cols, o.begin() + (size_t)r * cols_p);
+    return o;
+  };
+  auto pad1 = [](const std::vector<float>* b, int n, int n_p) {
+    std::vector<float> o((size_t)n_p, 0.f);
+    if (b) std::copy(b->begin(), b->begin() + n, o.begin());
+    return o;
+  };
   int rc;
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
-  TRY(upload_linear(e, H("embeddings.patch_embeddings.projection.weight"), Hopt("embeddings.patch_embeddings.projection.bias"), D, e->Kp, &e->patch));
+  {
+    const int Kr = e->cfg.num_channels * e->cfg.patch_size * e->cfg.patch_size;
+    const std::vector<float> wp = pad2(H("embeddings.patch_embeddings.projection.weight"), D, Kr, D, e->Kp);
+    TRY(upload_linear(e, wp, Hopt("embeddings.patch_embeddings.projection.bias"), D, e->Kp, &e->patch));
+  }
   TRY(dev_upload<float>(e, H("embeddings.position_embeddings"), &e->pos));
   TRY(dev_upload<float>(e, H("embeddings.time_embeddings"), &e->time_tab));
   e->layers.assign(e->L, DevLayer());
@@ -470,11 +490,15 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     TRY(upload_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), 3 * D, D, &l.s_qkv));
     TRY(upload_folded_linear(e, wq, Hopt(p + "attention.attention.qkv.bias"), H(p + "layernorm_before.weight"),
                              H(p + "layernorm_before.bias"), 3 * D, D, &l.s_qkv_f));
-    TRY(upload_folded_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"),
-                             H(p + "layernorm_after.weight"), H(p + "layernorm_after.bias"), I, D, &l.up_f));
-    TRY(upload_linear(e, wo, Hopt(p + "attention.output.dense.bias"), D, D, &l.s_out));
-    TRY(upload_linear(e, H(p + "intermediate.dense.weight"), Hopt(p + "intermediate.dense.bias"), I, D, &l.up));
-    TRY(upload_linear(e, H(p + "output.dense.weight"), Hopt(p + "output.dense.bias"), D, I, &l.down));
+    {
+      const std::vector<float> wu = pad2(H(p + "intermediate.dense.weight"), Ir, D, I, D);
+      const std::vector<float> bu = pad1(Hopt(p + "intermediate.dense.bias"), Ir, I);
+      const std::vector<float> wd = pad2(H(p + "output.dense.weight"), D, Ir, D, I);
+      TRY(upload_folded_linear(e, wu, &bu, H(p + "layernorm_after.weight"), H(p + "layernorm_after.bias"), I, D, &l.up_f));
+      TRY(upload_linear(e, wo, Hopt(p + "attention.output.dense.bias"), D, D, &l.s_out));
+      TRY(upload_linear(e, wu, &bu, I, D, &l.up));
+      TRY(upload_linear(e, wd, Hopt(p + "output.dense.bias"), D, I, &l.down));
+    }
   }
   TRY(upload_ln(e, "post_layernorm", &e->post_ln));
   TRY(upload_ln(e, "head.layernorm", &e->head_ln));
@@ -485,7 +509,8 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     const std::vector<float>& b = H("head.attention.in_proj_bias");
     const std::vector<float>& probe = H("head.probe");
     std::vector<double> q(D);
-    const double sc = 1.0 / std::sqrt(64.0);
+    const int hd = e->hd;
+    const double sc = 1.0 / std::sqrt((double)hd);
     for (int o = 0; o < D; ++o) {
       double acc = b[o];
       for (int k = 0; k < D; ++k) acc += (double)w[(size_t)o * D + k] * probe[k];
@@ -496,24 +521,32 @@ extern "C" int sf_finalize_weights(sf_encoder* e, int compute, int merge_lora, i
     // the tokens either: ctx_h = Wv_h (sum_n p_hn x_n) + bv_h.
     const int heads = e->cfg.num_attention_heads;
     std::vector<uint16_t> uh((size_t)16 * D, 0), ul((size_t)16 * D, 0);
+    std::vector<float> uf((size_t)16 * D, 0.f);
     for (int h = 0; h < heads; ++h)
       for (int d = 0; d < D; ++d) {
         double acc = 0.0;
-        for (int j = 0; j < 64; ++j) acc += (double)w[((size_t)D + h * 64 + j) * D + d] * q[h * 64 + j];
+        for (int j = 0; j < hd; ++j) acc += (double)w[((size_t)D + h * hd + j) * D + d] * q[h * hd + j];
         const float v = (float)acc;
+        uf[(size_t)h * D + d] = v;
         uh[(size_t)h * D + d] = h_f2bf(v);
         ul[(size_t)h * D + d] = h_f2bf(v - h_bf2f(uh[(size_t)h * D + d]));
       }
     TRY(dev_upload<uint16_t>(e, uh, &e->head_u_hi));
     TRY(dev_upload<uint16_t>(e, ul, &e->head_u_lo));
+    TRY(dev_upload<float>(e, uf, &e->head_u));          // fp32 copy for the generic-width kernel (sf_launch_pool_generic)
     std::vector<float> wv(w.begin() + (size_t)2 * D * D, w.end());
     std::vector<float> bv(b.begin() + 2 * D, b.end());
     TRY(dev_upload<float>(e, wv, &e->head_wv));
     TRY(dev_upload<float>(e, bv, &e->head_bv));
   }
   TRY(upload_linear(e, H("head.attention.out_proj.weight"), Hopt("head.attention.out_proj.bias"), D, D, &e->head_out, true));
-  TRY(upload_linear(e, H("head.mlp.fc1.weight"), Hopt("head.mlp.fc1.bias"), I, D, &e->head_fc1, true));
-  TRY(upload_linear(e, H("head.mlp.fc2.weight"), Hopt("head.mlp.fc2.bias"), D, I, &e->head_fc2, true));
+  {
+    const std::vector<float> w1 = pad2(H("head.mlp.fc1.weight"), Ir, D, I, D);
+    const std::vector<float> b1 = pad1(Hopt("head.mlp.fc1.bias"), Ir, I);
+    const std::vector<float> w2 = pad2(H("head.mlp.fc2.weight"), D, Ir, D, I);
+    TRY(upload_linear(e, w1, &b1, I, D, &e->head_fc1, true));
+    TRY(upload_linear(e, w2, Hopt("head.mlp.fc2.bias"), D, I, &e->head_fc2, true));
+  }
 #undef TRY
   e->finalized = true;
   e->generation = next_generation();   // caches created against an earlier packing are refused from here on
@@ -793,7 +826,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   const bool acc = e->compute == SF_COMPUTE_BF16X3;
   const int qkv_epi = acc ? SF_EPI_F32 : SF_EPI_BF16;
   const size_t esz = acc ? 4 : 2;
-  const float scale = 1.0f / sqrtf(64.0f);
+  const float scale = 1.0f / sqrtf((float)e->hd);
 
   bool embed_emitted_stats = false;
   // statistics rows of the bf16 fold are 8 floats = four pairs; the 384-column panel kernel fills pairs 0 and 2 only
@@ -830,7 +863,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   bf16_t* patches = embed_panel ? ws.patch_buf : ws.xn_hi;
   if (!patches_ready)
     HIP_TRY(sf_launch_patchify(pixels, pixel_dtype == SF_U8 ? 2 : (pixel_dtype == SF_BF16 ? 1 : 0), patches, ws.xn_lo, F, c.num_channels, H, W, P, s,
-                               &e->pixel_norm));
+                               &e->pixel_norm, nullptr, nullptr, nullptr, e->Kp));
   {
     SfGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -942,7 +975,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       memset(&a, 0, sizeof(a));
       a.q = tq; a.k = (char*)tq + (size_t)D * tsz; a.v = (char*)tq + (size_t)2 * D * tsz;
       a.in_is_f32 = acc && !tplanes; a.lo_plane_off = tplanes ? (long long)M * 3 * D : 0;
-      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale; a.head_dim = e->hd;
       a.N = N; a.B = B; a.Tq = T; a.Tk = tk; a.Tcap = cap; a.t_past = tk - T;
       a.causal = c.enable_causal_temporal; a.Tq_cap = cap; a.q_t0 = slot;
       a.pos_dev = sp ? &sp->slot : nullptr;
@@ -987,7 +1020,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       memset(&a, 0, sizeof(a));
       a.q = ws.qkv; a.k = (char*)ws.qkv + (size_t)D * sesz; a.v = (char*)ws.qkv + (size_t)2 * D * sesz;
       a.in_is_f32 = acc && !planes; a.lo_plane_off = planes ? (long long)M * 3 * D : 0;
-      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale;
+      a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = scale; a.head_dim = e->hd;
       a.N = N; a.frames = F; a.ctx_hi = ws.ctx_hi; a.ctx_lo = ws.ctx_lo; a.D = D;
       a.probs = attentions ? attentions + (size_t)(li - la) * F * heads * N * N : nullptr;
       HIP_TRY(prof_span(e, 2, s, [&]() { return sf_launch_spatial_attention(a, acc, s); }));
@@ -1018,6 +1051,16 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     const bool hacc = !acc;          // the head's one-row-per-frame tensors keep hi + lo planes in both modes (force_split in bf16 mode)
     {
       const float* tok = (stages & 4) ? last_hidden : ws.resid;
+      const bool rows = sf_head_rows_ok(e, F);
+      if (e->hd != 64 || D > 1024) {      // widths the MFMA probe kernels do not cover: the whole probe attention of a frame in one fp32 workgroup
+        SfPoolGenArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.x = tok; ga.x_ind = (sp && (stages & 4)) ? reinterpret_cast<const float* const*>(&sp->lhs) : nullptr;
+        ga.u = e->head_u; ga.wv = e->head_wv; ga.ldw = D; ga.bv = e->head_bv;
+        ga.F = F; ga.N = N; ga.heads = heads; ga.hd = e->hd; ga.D = D;
+        if (rows) ga.ctx_f32 = ws.head_ctx; else { ga.ctx_hi = ws.pc_hi; ga.ctx_lo = ws.pc_lo; }
+        HIP_TRY(sf_launch_pool_generic(ga, s));
+      } else {
       SfPoolArgs pa;
       memset(&pa, 0, sizeof(pa));
       pa.x = tok; pa.x_ind = (sp && (stages & 4)) ? reinterpret_cast<const float* const*>(&sp->lhs) : nullptr;
@@ -1028,9 +1071,9 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       memset(&ca, 0, sizeof(ca));
       ca.zpart = ws.pool_z; ca.ml = ws.pool_ml; ca.wv = e->head_wv; ca.ldw = D; ca.bv = e->head_bv;
       ca.ctx_hi = ws.pc_hi; ca.ctx_lo = ws.pc_lo; ca.F = F; ca.heads = heads; ca.D = D; ca.S = pa.S;
-      const bool rows = sf_head_rows_ok(e, F);
       if (rows) { ca.ctx_hi = ca.ctx_lo = nullptr; ca.ctx_f32 = ws.head_ctx; }
       HIP_TRY(sf_launch_pool_ctx(ca, s));
+      }
       if (rows) {
         // One to four rows (streamed frames): the per-frame tail as three row-vector launches with fp32 activations — out_proj,
         // LayerNorm + fc1 + GELU, fc2 + residual (written straight into the caller's pooler_output inside the position-free graph)
@@ -1332,7 +1375,8 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
   // patch extraction reads the caller's frames: outside the graphs.  For the position-free graph the same launch stores the call's
   // parameter block {pixels, outputs, position} that the graph's kernels read (it used to be a launch of its own)
   if (!posfree)
-    HIP_TRY(sf_launch_patchify(pixels, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm));
+    HIP_TRY(sf_launch_patchify(pixels, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm, nullptr, nullptr, nullptr,
+                               e->Kp));
   if (!g.exec) {
     hipGraph_t graph = nullptr;
     if (!c->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
@@ -1374,7 +1418,7 @@ static int forward_stream_impl(sf_encoder* e, sf_cache* c, const void* pixels, i
     SfStreamParams v;
     v.pixels = pixels; v.lhs = last_hidden; v.pooler = pooler; v.t_row = pos3[0]; v.slot = pos3[1]; v.tk = pos3[2];
     HIP_TRY(sf_launch_patchify(pixels, pk, ws.xn_hi, ws.xn_lo, F, e->cfg.num_channels, c->H, c->W, e->cfg.patch_size, s, &e->pixel_norm, nullptr,
-                               c->dparams, &v));
+                               c->dparams, &v, e->Kp));
     HIP_TRY(hipGraphLaunch(g.exec, s));
   } else {
     // (Launching the embedding + first layers eagerly to cover the replay's host-side submit time measured no gain: 0.78 vs 0.77 ms.)
@@ -1455,7 +1499,7 @@ extern "C" size_t sf_op_attention_workspace_bytes(int groups, int L, int heads, 
 extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, int heads, int head_dim, int causal,
                                int temporal_layout, int N_tokens, int compute, void* workspace, size_t workspace_bytes,
                                sf_stream stream) {
-  if (head_dim != 64) return set_err(SF_ERR_INVALID, "head_dim must be 64");
+  if (head_dim < 8 || head_dim > 128 || head_dim % 8) return set_err(SF_ERR_INVALID, "head_dim must be a multiple of 8 in 8..128");
   if (workspace_bytes < sf_op_attention_workspace_bytes(groups, L, heads, head_dim)) return set_err(SF_ERR_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const bool acc = compute == SF_COMPUTE_BF16X3;
@@ -1467,7 +1511,7 @@ extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, 
   bf16_t* qb = c.take<bf16_t>(rows * 3 * D);
   const void* base = qkv;
   size_t esz = 4;
-  const bool planes = acc && (temporal_layout ? sf_temporal_planes_ok(L, L) : sf_spatial_planes_ok(L, false));
+  const bool planes = acc && head_dim == 64 && (temporal_layout ? sf_temporal_planes_ok(L, L) : sf_spatial_planes_ok(L, false));
   bf16_t* ql = nullptr;
   if (!acc || planes) {
     if (planes) ql = c.take<bf16_t>(rows * 3 * D);
@@ -1480,7 +1524,7 @@ extern "C" int sf_op_attention(const float* qkv, float* ctx, int groups, int L, 
   a.q = base; a.k = (const char*)base + (size_t)D * esz; a.v = (const char*)base + (size_t)2 * D * esz;
   a.in_is_f32 = acc && !planes; a.lo_plane_off = planes ? (long long)(ql - qb) : 0;
   a.row_pitch_q = 3 * D; a.row_pitch_kv = 3 * D; a.heads = heads; a.scale = 1.0f / sqrtf((float)head_dim);
-  a.ctx_hi = ch; a.ctx_lo = cl; a.D = D;
+  a.ctx_hi = ch; a.ctx_lo = cl; a.D = D; a.head_dim = head_dim;
   if (temporal_layout) {
     // rows are [B, L, N_tokens, 3D] with groups = B * N_tokens sequences of length L
     if (N_tokens <= 0 || groups % N_tokens) return set_err(SF_ERR_INVALID, "groups must be a multiple of N_tokens");

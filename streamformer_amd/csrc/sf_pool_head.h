@@ -31,6 +31,17 @@ struct SfPoolCtxArgs {
 };
 hipError_t sf_launch_pool_ctx(const SfPoolCtxArgs& a, hipStream_t s);
 
+// Generic widths (head_dim != 64 or D > 1024): the whole probe attention of a frame in one fp32 workgroup (sf_pool_head.hip, bottom)
+struct SfPoolGenArgs {
+  const float* x; const float* const* x_ind;     // as SfPoolArgs
+  const float* u;                                // [heads, D] fp32 U_h = Wk_h^T q_h (q scaled by 1 / sqrt(head_dim))
+  const float* wv; int ldw; const float* bv;     // value projection rows [D][ldw], bias [D]
+  float* ctx_f32; bf16_t* ctx_hi; bf16_t* ctx_lo;  // [F, D] outputs (any subset)
+  int F, N, heads, hd, D;
+};
+bool sf_pool_generic_supported(int N, int heads, int D);
+hipError_t sf_launch_pool_generic(const SfPoolGenArgs& a, hipStream_t s);
+
 // One-to-four-row Linear of the head's per-frame tail (a streamed frame: F = streams <= 4): y = act(LN?(x) W^T + b) (+ resid) with fp32
 // activations and hi + lo bf16 weights multiplied out in fp32 FMAs; one wave per output column, the whole K range in flight.
 struct SfRowLinArgs {

@@ -155,15 +155,62 @@ __global__ __launch_bounds__(256) void sf_patchify_kernel(const void* __restrict
   }
 }
 
+// Any patch size / padded patch vectors (14 x 14 patches: K = 588 -> 640): one thread per 8 output columns, element by element;
+// columns past C * P * P are zeros (the patch-embedding weight is zero-padded to the same width at upload).
+template <int IN>
+__global__ __launch_bounds__(256) void sf_patchify_generic_kernel(const void* __restrict__ pixels, bf16_t* __restrict__ out_hi,
+                                                                  bf16_t* __restrict__ out_lo, int F, int C, int H, int W, int P, int gh, int gw,
+                                                                  int Kpad, SfPixelNorm norm, const SfStreamParams* __restrict__ sp,
+                                                                  SfStreamParams* sp_write, SfStreamParams sp_value) {
+  if (sp) pixels = sp->pixels;
+  if (sp_write && blockIdx.x == 0 && threadIdx.x == 0) *sp_write = sp_value;
+  const int Kr = C * P * P, chunks_per_row = Kpad >> 3;
+  const size_t total = (size_t)F * gh * gw * chunks_per_row;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % chunks_per_row);
+    const size_t prow = i / chunks_per_row;
+    const int n = (int)(prow % (gh * gw)), f = (int)(prow / (gh * gw));
+    unsigned int h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = ck * 8 + j;
+      float v = 0.f;
+      if (col < Kr) {
+        const int c = col / (P * P), rem = col % (P * P);
+        const size_t src = (((size_t)f * C + c) * H + (n / gw) * P + rem / P) * W + (n % gw) * P + rem % P;
+        if (IN == 2) v = fmaf((float)reinterpret_cast<const unsigned char*>(pixels)[src], norm.scale[c & 3], norm.shift[c & 3]);
+        else if (IN == 1) v = bf2f(reinterpret_cast<const bf16_t*>(pixels)[src]);
+        else v = reinterpret_cast<const float*>(pixels)[src];
+      }
+      split_bf(v, h[j], l[j]);
+    }
+    const size_t o = prow * Kpad + (size_t)ck * 8;
+    *reinterpret_cast<u32x4_t*>(out_hi + o) = (u32x4_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    if (out_lo) *reinterpret_cast<u32x4_t*>(out_lo + o) = (u32x4_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+  }
+}
+
 hipError_t sf_launch_patchify(const void* pixels, int pixel_kind, bf16_t* out_hi, bf16_t* out_lo,
                               int F, int C, int H, int W, int P, hipStream_t s, const SfPixelNorm* pnorm, const SfStreamParams* sp,
-                              SfStreamParams* sp_write, const SfStreamParams* sp_value) {
-  if (P % 8 || (pixel_kind == 2 && (W % 8 || C > 4))) return hipErrorInvalidValue;
+                              SfStreamParams* sp_write, const SfStreamParams* sp_value, int Kpad) {
   SfStreamParams spv = {};
   if (sp_write) { if (!sp_value) return hipErrorInvalidValue; spv = *sp_value; }
   SfPixelNorm norm;
   for (int i = 0; i < 4; ++i) { norm.scale[i] = 1.0f / 127.5f; norm.shift[i] = -1.0f; }    // mean = std = 0.5, rescale 1/255
   if (pnorm) norm = *pnorm;
+  if (Kpad <= 0) Kpad = C * P * P;
+  if (P % 8 || Kpad != C * P * P || (pixel_kind == 2 && W % 8)) {      // generic path
+    if (Kpad % 8 || Kpad < C * P * P || (pixel_kind == 2 && C > 4)) return hipErrorInvalidValue;
+    const int gh = H / P, gw = W / P;
+    const size_t total = (size_t)F * gh * gw * (Kpad / 8);
+    if (!total) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (pixel_kind == 2) hipLaunchKernelGGL(sf_patchify_generic_kernel<2>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, Kpad, norm, sp, sp_write, spv);
+    else if (pixel_kind == 1) hipLaunchKernelGGL(sf_patchify_generic_kernel<1>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, Kpad, norm, sp, sp_write, spv);
+    else hipLaunchKernelGGL(sf_patchify_generic_kernel<0>, dim3(blocks), dim3(256), 0, s, pixels, out_hi, out_lo, F, C, H, W, P, gh, gw, Kpad, norm, sp, sp_write, spv);
+    return hipGetLastError();
+  }
+  if (pixel_kind == 2 && C > 4) return hipErrorInvalidValue;
   const int gh = H / P, gw = W / P;
   const size_t total = (size_t)F * gh * gw * (C * P * P / 8);
   if (!total) return hipSuccess;

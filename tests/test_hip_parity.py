@@ -159,14 +159,14 @@ def test_op_linear_shape_sweep(sa):
                 assert err <= tol + (1e-5 if mode else 2e-2), (M, N, K, mode, err)
 
 
-def _attention(sa, qkv, groups, L, heads, causal, temporal, ntok, mode):
+def _attention(sa, qkv, groups, L, heads, causal, temporal, ntok, mode, head_dim=64):
     nat = sa._native
-    D = heads * 64
+    D = heads * head_dim
     q = qkv.cuda().contiguous()
     ctx = torch.empty(groups * L, D, device="cuda")
-    nb = nat.lib.sf_op_attention_workspace_bytes(groups, L, heads, 64)
+    nb = nat.lib.sf_op_attention_workspace_bytes(groups, L, heads, head_dim)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    nat.check(nat.lib.sf_op_attention(q.data_ptr(), ctx.data_ptr(), groups, L, heads, 64, int(causal), int(temporal), ntok,
+    nat.check(nat.lib.sf_op_attention(q.data_ptr(), ctx.data_ptr(), groups, L, heads, head_dim, int(causal), int(temporal), ntok,
                                       mode, ws.data_ptr(), nb, nat.current_stream_handle(q.device)))
     torch.cuda.synchronize()
     return ctx.cpu()
@@ -239,14 +239,31 @@ def test_compile_time_tile_count_is_bit_identical(sa):
     assert digests[0] == digests[1], digests
 
 
-def _spatial_attention_case(sa, frames_, N, heads, mode):
+def _spatial_attention_case(sa, frames_, N, heads, mode, head_dim=64):
     g = torch.Generator().manual_seed(N * 13 + heads)
-    qkv = torch.randn(frames_, N, 3 * heads * 64, generator=g) * 1.5
+    qkv = torch.randn(frames_, N, 3 * heads * head_dim, generator=g) * 1.5
     qkv[..., 5] += 6.0                                   # a spiky column: exercises the max-subtraction
     src = qkv if mode == 1 else qkv.bfloat16().float()
     want = _attn_ref(src, heads).reshape(frames_ * N, -1)
-    got = _attention(sa, qkv.reshape(frames_ * N, -1), frames_, N, heads, False, False, 0, mode)
+    got = _attention(sa, qkv.reshape(frames_ * N, -1), frames_, N, heads, False, False, 0, mode, head_dim)
     assert maxabs(got, want) <= (2e-4 if mode == 1 else 3e-2)
+
+
+@pytest.mark.parametrize("head_dim", [72, 32, 8, 96, 128])
+@pytest.mark.parametrize("frames_,N,heads", [(2, 256, 2), (3, 9, 3), (1, 37, 16), (1, 729, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_op_spatial_attention_any_head_dim(sa, frames_, N, heads, mode, head_dim):
+    """Head widths other than 64 (configuration_streamformer.py:90-135 takes any hidden_size / heads; SigLIP-so400m = 72) run on
+    sf_attention_generic.hip: fp32 products on the f32 matrix pipe in both modes, against the fp64 reference on the operands the mode
+    sees (bf16-rounded q / k / v in bf16 mode; the output is then rounded to bf16 once more)."""
+    _spatial_attention_case(sa, frames_, N, heads, mode, head_dim)
+
+
+@pytest.mark.parametrize("head_dim", [72, 32, 128])
+@pytest.mark.parametrize("B,L,Nt,heads,causal", [(2, 16, 9, 2, 1), (1, 5, 4, 3, 1), (1, 1, 3, 2, 1), (1, 64, 2, 2, 1), (2, 16, 5, 3, 0), (1, 33, 2, 1, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_op_temporal_attention_any_head_dim(sa, B, L, Nt, heads, causal, mode, head_dim):
+    _temporal_attention_case(sa, B, L, Nt, heads, causal, mode, head_dim)
 
 
 @pytest.mark.parametrize("B,L,Nt,heads,causal", [(2, 16, 9, 2, 1), (1, 5, 4, 12, 1), (1, 1, 3, 2, 1), (1, 64, 2, 2, 1),
@@ -264,15 +281,15 @@ def test_op_temporal_attention_accurate_fp32_inputs(sa, B, L, Nt, heads, causal,
     _temporal_attention_case(sa, B, L, Nt, heads, causal, 1)
 
 
-def _temporal_attention_case(sa, B, L, Nt, heads, causal, mode):
+def _temporal_attention_case(sa, B, L, Nt, heads, causal, mode, head_dim=64):
     g = torch.Generator().manual_seed(L * 17 + Nt)
-    D = heads * 64
+    D = heads * head_dim
     qkv = torch.randn(B, L, Nt, 3 * D, generator=g) * 1.5          # the encoder's [B,T,N,3D] layout
     src = qkv if mode == 1 else qkv.bfloat16().float()
     seq = src.permute(0, 2, 1, 3).reshape(B * Nt, L, 3 * D)
     mask = torch.tril(torch.ones(L, L, dtype=torch.bool)) if causal else None
     want = _attn_ref(seq, heads, mask).reshape(B, Nt, L, D).permute(0, 2, 1, 3).reshape(B * L * Nt, D)
-    got = _attention(sa, qkv.reshape(B * L * Nt, 3 * D), B * Nt, L, heads, causal, True, Nt, mode)
+    got = _attention(sa, qkv.reshape(B * L * Nt, 3 * D), B * Nt, L, heads, causal, True, Nt, mode, head_dim)
     assert maxabs(got, want) <= (2e-4 if mode == 1 else 3e-2)
 
 
@@ -1020,19 +1037,81 @@ def test_forward_three_heads_vs_oracle(mode, tol_l, tol_p):
 
 @pytest.mark.gpu
 def test_unsupported_widths_are_refused_with_a_message():
-    """head_dim != 64 (a SigLIP-so400m-shaped 1152 / 16 = 72) and more than 16 heads are refused at construction with SF_ERR_INVALID
-    and a message that names the limit — not a wrong answer, not a crash at the first forward."""
+    """What the HIP path still cannot run is refused at construction with SF_ERR_INVALID and a message that names the limit — not a wrong
+    answer, not a crash at the first forward: more than 16 heads, a head_dim that is not a multiple of 8 or above 128, a hidden_size that
+    is not a multiple of 64.  (Round 6: head_dim 72 / intermediate 4304 / 14 x 14 patches — the SigLIP-so400m shape — are no longer here.)"""
     import streamformer_amd as sa
     import streamformer_amd._native as nat
     from streamformer_amd.configuration import StreamformerConfig
-    for kw, word in ((dict(hidden_size=1152, num_attention_heads=16, intermediate_size=4304), "head_dim"),
-                     (dict(hidden_size=1280, num_attention_heads=20, intermediate_size=5120), "heads")):
+    for kw, word in ((dict(hidden_size=1280, num_attention_heads=20, intermediate_size=5120), "heads"),
+                     (dict(hidden_size=320, num_attention_heads=2, intermediate_size=640), "head_dim"),          # 160 > 128
+                     (dict(hidden_size=192, num_attention_heads=16, intermediate_size=384), "head_dim"),         # 12: not a multiple of 8
+                     (dict(hidden_size=144, num_attention_heads=2, intermediate_size=304), "hidden_size")):      # F13's 72-wide heads at 144
         cfg = StreamformerConfig(image_size=224, patch_size=16, num_frames=16, num_hidden_layers=1, enable_causal_temporal=True, **kw)
         with pytest.raises(nat.NativeError) as ei:
             m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype="bf16")
             m.load_state_dict(make_state_dict(cfg, seed=1))
             m.to("cuda").eval()(frames(1, (1, 1, 3, 224, 224)).cuda())
         assert word in str(ei.value)
+
+
+HD72W = dict(image_size=42, patch_size=14, num_frames=8, hidden_size=576, num_hidden_layers=2, num_attention_heads=8, intermediate_size=1072)
+HD32 = dict(image_size=48, patch_size=16, num_frames=8, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol_l,tol_p", [("fp32", ACC_TOL, ACC_TOL), ("bf16", BF16_LHS, BF16_POOL)])
+@pytest.mark.parametrize("fixture,tag,kw,wseed,xseed", [("f15_hd72_hip.npz", "hd72w", HD72W, 15, 150), ("f13_widths.npz", "hd32", HD32, 13, 131)])
+def test_forward_head_widths_other_than_64_vs_reference_fixture(golden_dir, mode, tol_l, tol_p, fixture, tag, kw, wseed, xseed):
+    """configuration_streamformer.py:90-135 takes any hidden_size / heads.  head_dim 72 with intermediate 1072 (not a multiple of 64) and
+    14 x 14 patches (C P P = 588) — SigLIP-so400m's shape in small — and head_dim 32, against the REFERENCE's outputs (F15 / F13, made by
+    oracle/make_golden_widths_hip.py / make_golden_variants.py): generic-width attention + pooling-head kernels, zero-padded MLP and
+    patch-embedding weights, generic patch extraction.  Streamed frame by frame through the KV-cache the same frames must agree with
+    the full clip, bit-reproducibly."""
+    import streamformer_amd as sa
+    from streamformer_amd.configuration import StreamformerConfig
+    g = load_npz(os.path.join(golden_dir, fixture))
+    cfg = StreamformerConfig(enable_causal_temporal=True, **kw)
+    sd = make_state_dict(cfg, seed=wseed)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    x = frames(xseed, (2, cfg.num_frames, 3, cfg.image_size, cfg.image_size)).cuda()
+    out = m(x)
+    assert maxabs(out.last_hidden_state, g[f"{tag}_last_hidden_state"]) <= tol_l
+    assert maxabs(out.pooler_output, g[f"{tag}_pooler_output"]) <= tol_p
+    again = m(x)
+    assert torch.equal(out.last_hidden_state, again.last_hidden_state) and torch.equal(out.pooler_output, again.pooler_output)
+    cache = m.new_cache(2, cfg.num_frames)
+    outs = [m(x[:, t:t + 1], use_cache=True, past_key_values=cache) for t in range(cfg.num_frames)]
+    lhs = torch.cat([o.last_hidden_state for o in outs], 1)
+    pool = torch.cat([o.pooler_output for o in outs], 1)
+    assert maxabs(lhs, g[f"{tag}_last_hidden_state"]) <= tol_l and maxabs(pool, g[f"{tag}_pooler_output"]) <= tol_p
+    # uint8 frames through the generic patch extraction (rescale + normalise fused), against the same frames as floats
+    u8 = (x[:1].clamp(-1, 1) * 127.5 + 127.5).round().to(torch.uint8)
+    a = m(u8)
+    b = m((u8.float() / 127.5 - 1.0))
+    assert maxabs(a.last_hidden_state, b.last_hidden_state) <= (2e-4 if mode == "fp32" else tol_l)
+
+
+@pytest.mark.gpu
+def test_so400m_shaped_layer_runs_and_matches_the_oracle():
+    """The real SigLIP-so400m widths (hidden 1152, 16 heads of 72, intermediate 4304, patch 14 at 224 x 224 = 256 tokens) on ONE layer and a
+    4-frame clip: the generic kernels at full width against the CPU oracle, both modes."""
+    import streamformer_amd as sa
+    from streamformer_amd.configuration import StreamformerConfig
+    cfg = StreamformerConfig(image_size=224, patch_size=14, num_frames=4, hidden_size=1152, num_hidden_layers=1, num_attention_heads=16,
+                             intermediate_size=4304, enable_causal_temporal=True)
+    sd = make_state_dict(cfg, seed=16)
+    x = frames(16, (1, 4, 3, 224, 224))
+    want = O.forward(sd, cfg, x)
+    for mode, tl, tp in (("fp32", ACC_TOL, ACC_TOL), ("bf16", BF16_LHS, BF16_POOL)):
+        m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+        m.load_state_dict(sd)
+        m.to("cuda").eval()
+        out = m(x.cuda())
+        assert maxabs(out.last_hidden_state, want["last_hidden_state"]) <= tl, mode
+        assert maxabs(out.pooler_output, want["pooler_output"]) <= tp, mode
 
 
 @pytest.mark.gpu
