@@ -5,8 +5,9 @@
 //
 // One wave = one (sequence, head, 16-query tile), flash style over 16-key tiles, everything in fp32 on the f32 matrix pipe
 // (v_mfma_f32_16x16x4_f32: exact fp32 products, 1/16 of the bf16 rate — attention is a few percent of the encoder's FLOPs, and one
-// kernel then serves both compute modes with no operand rounding at all).  No LDS, no transposes: the two products are arranged so
-// that every operand is something a lane can load straight from the token rows, and the query index of a lane is l15 in BOTH results:
+// kernel then serves both compute modes with no operand rounding at all).  No transposes and no workgroup barriers: the two products are
+// arranged so that every operand is a single float at (row, slot) of the K / V tile — staged once per tile in a wave-private fp32 LDS
+// image by 16-byte row loads — and the query index of a lane is l15 in BOTH results:
 //   S^T[key][query] = sum_d K[key][d] Q[query][d]          A = K: lane (key l15, slot g), B = Q: lane (query l15, slot g); the k-slot g of
 //                                                          MFMA step s stands for d = g * (HD / 4) + s (any bijection does: it is a sum),
 //                                                          so a lane's K / Q elements are HD / 4 CONTIGUOUS values of its row
@@ -38,9 +39,36 @@ struct SfGenAttn {
   int nseq, Lq, qtiles;
 };
 
+// eight consecutive elements starting at element i (i % 8 == 0: 16-byte aligned for bf16, 32 for fp32)
+template <int KIND>
+SF_DEVICE void ga_ld8(const void* base, size_t i, long long lo_off, float* out) {
+  if (KIND == 1) {
+    const gf4_t v0 = *reinterpret_cast<const gf4_t*>(reinterpret_cast<const float*>(base) + i);
+    const gf4_t v1 = *reinterpret_cast<const gf4_t*>(reinterpret_cast<const float*>(base) + i + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[j] = v0[j]; out[4 + j] = v1[j]; }
+  } else {
+    const u32x4_t h = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(base) + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[2 * j] = bf2f(h[j] & 0xffffu); out[2 * j + 1] = __uint_as_float(h[j] & 0xffff0000u); }
+    if (KIND == 2) {
+      const u32x4_t l = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(base) + i + lo_off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { out[2 * j] += bf2f(l[j] & 0xffffu); out[2 * j + 1] += __uint_as_float(l[j] & 0xffff0000u); }
+    }
+  }
+}
+
 template <int KIND, int HDQ>      // HDQ = head_dim / 4 <= 32
 __global__ __launch_bounds__(256) void sf_attention_generic_kernel(SfGenAttn p) {
   const SfAttnArgs& a = p.a;
+  // wave-private fp32 images of the current K and V tiles ([16 keys][HD + 4]): the rows arrive by 16-byte loads (a key row of one head is
+  // contiguous) and the MFMA operands — single floats at (row l15, slot) — are LDS reads.  (First version: every operand element
+  // loaded from global memory by its lane, 2 bytes per lane and instruction: 520 us per so400m-shaped spatial launch, load-bound.)
+  extern __shared__ __attribute__((aligned(16))) float ga_smem[];
+  constexpr int GA_LD = HDQ * 4 + 4;
+  float* kt = ga_smem + (threadIdx.x >> 6) * (2 * 16 * GA_LD);
+  float* vt = kt + 16 * GA_LD;
   const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int total = p.nseq * a.heads * p.qtiles;
@@ -77,13 +105,32 @@ __global__ __launch_bounds__(256) void sf_attention_generic_kernel(SfGenAttn p) 
   const int last_q = min(qt * 16 + 15, p.Lq - 1);
   const int k_end = (p.temporal && a.causal) ? min(Lk, t_past + last_q + 1) : Lk;
   for (int k0 = 0; k0 < k_end; k0 += 16) {
+    // ---- stage the tile's K and V rows (keys past the end: the last key again; they are masked below) ----------------------------
+    {
+      constexpr int CH = HD / 8;                     // 8-element chunks per row
+#pragma unroll
+      for (int it = 0; it < (16 * CH + 63) / 64; ++it) {
+        const int c = it * 64 + lane;
+        if (c < 16 * CH) {
+          const int row = c / CH, cc = c % CH;
+          const size_t o = krow(min(k0 + row, Lk - 1)) * a.row_pitch_kv + h * HD + cc * 8;
+          float e[8];
+          ga_ld8<KIND>(a.k, o, a.lo_plane_off, e);
+          *reinterpret_cast<gf4_t*>(kt + row * GA_LD + cc * 8) = (gf4_t){e[0], e[1], e[2], e[3]};
+          *reinterpret_cast<gf4_t*>(kt + row * GA_LD + cc * 8 + 4) = (gf4_t){e[4], e[5], e[6], e[7]};
+          ga_ld8<KIND>(a.v, o, a.lo_plane_off, e);
+          *reinterpret_cast<gf4_t*>(vt + row * GA_LD + cc * 8) = (gf4_t){e[0], e[1], e[2], e[3]};
+          *reinterpret_cast<gf4_t*>(vt + row * GA_LD + cc * 8 + 4) = (gf4_t){e[4], e[5], e[6], e[7]};
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes, read below by other lanes of the same wave
+    }
     // ---- S^T tile: keys k0 + l15 (A operand), HDQ steps --------------------------------------------------------------------------
-    const int kj = min(k0 + l15, Lk - 1);
     gf4_t s4 = {0.f, 0.f, 0.f, 0.f};
     {
-      const size_t o = krow(kj) * a.row_pitch_kv + h * HD + g * HDQ;
+      const float* kr = kt + l15 * GA_LD + g * HDQ;
 #pragma unroll
-      for (int s = 0; s < HDQ; ++s) s4 = ga_mfma(ga_ld<KIND>(a.k, o + s, a.lo_plane_off), qreg[s], s4);
+      for (int s = 0; s < HDQ; ++s) s4 = ga_mfma(kr[s], qreg[s], s4);
     }
     // lane (query l15, g): keys k0 + 4 g + r
     float mx = -INFINITY;
@@ -116,11 +163,11 @@ __global__ __launch_bounds__(256) void sf_attention_generic_kernel(SfGenAttn p) 
       const int d = t * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = min(k0 + 4 * g + r, Lk - 1);          // masked keys carry p = 0
-        const float v = d < HD ? ga_ld<KIND>(a.v, krow(key) * a.row_pitch_kv + h * HD + d, a.lo_plane_off) : 0.f;
+        const float v = d < HD ? vt[(4 * g + r) * GA_LD + d] : 0.f;          // masked keys carry p = 0
         o_acc[t] = ga_mfma(v, s4[r], o_acc[t]);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every read of the images retired before the next tile overwrites them
   }
   if (qi >= p.Lq) return;
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -146,8 +193,15 @@ template <int KIND>
 static hipError_t ga_launch(const SfGenAttn& p, hipStream_t s) {
   const int total = p.nseq * p.a.heads * p.qtiles;
   const dim3 grid((total + 3) / 4), block(256);
+  const size_t lds = (size_t)4 * 2 * 16 * (p.hd + 4) * sizeof(float);      // <= 67.6 KB at head_dim 128
+  static SfPerDeviceOnce attr_set[3];
+  if (attr_set[KIND].first()) {
+#define GA_ATTR(E) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_attention_generic_kernel<KIND, 2 * E>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    GA_ATTR(13) GA_ATTR(14) GA_ATTR(15) GA_ATTR(16)
+#undef GA_ATTR
+  }
   switch (p.hd / 8) {
-#define GA_CASE(E) case E: hipLaunchKernelGGL((sf_attention_generic_kernel<KIND, 2 * E>), grid, block, 0, s, p); break;
+#define GA_CASE(E) case E: hipLaunchKernelGGL((sf_attention_generic_kernel<KIND, 2 * E>), grid, block, lds, s, p); break;
     GA_CASE(1) GA_CASE(2) GA_CASE(3) GA_CASE(4) GA_CASE(5) GA_CASE(6) GA_CASE(7) GA_CASE(8)
     GA_CASE(9) GA_CASE(10) GA_CASE(11) GA_CASE(12) GA_CASE(13) GA_CASE(14) GA_CASE(15) GA_CASE(16)
 #undef GA_CASE

@@ -616,7 +616,11 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.attn_out = c.take<float>(F * D);
   w.head_ctx = c.take<float>(F * D);
   w.head_mid = c.take<float>(F * I);
-  w.pool_z = c.take<float>(sf_pool_z_floats((int)F, N, e->cfg.num_attention_heads, (int)D));
+  {
+    size_t pz = sf_pool_z_floats((int)F, N, e->cfg.num_attention_heads, (int)D);
+    const size_t pgen = sf_pool_generic_scratch_floats((int)F, N, e->cfg.num_attention_heads, (int)D);      // generic widths: scores + z
+    w.pool_z = c.take<float>(pz > pgen ? pz : pgen);
+  }
   w.pool_ml = c.take<float>(sf_pool_ml_floats((int)F, N, e->cfg.num_attention_heads));
   w.pc_hi = c.take<bf16_t>(F * D);          // the pooling head's one-row-per-frame tensors keep hi + lo planes in both modes
   w.pc_lo = c.take<bf16_t>(F * D);
@@ -1058,6 +1062,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
         ga.x = tok; ga.x_ind = (sp && (stages & 4)) ? reinterpret_cast<const float* const*>(&sp->lhs) : nullptr;
         ga.u = e->head_u; ga.wv = e->head_wv; ga.ldw = D; ga.bv = e->head_bv;
         ga.F = F; ga.N = N; ga.heads = heads; ga.hd = e->hd; ga.D = D;
+        ga.scratch = ws.pool_z;
         if (rows) ga.ctx_f32 = ws.head_ctx; else { ga.ctx_hi = ws.pc_hi; ga.ctx_lo = ws.pc_lo; }
         HIP_TRY(sf_launch_pool_generic(ga, s));
       } else {

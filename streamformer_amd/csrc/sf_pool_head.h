@@ -37,9 +37,12 @@ struct SfPoolGenArgs {
   const float* u;                                // [heads, D] fp32 U_h = Wk_h^T q_h (q scaled by 1 / sqrt(head_dim))
   const float* wv; int ldw; const float* bv;     // value projection rows [D][ldw], bias [D]
   float* ctx_f32; bf16_t* ctx_hi; bf16_t* ctx_lo;  // [F, D] outputs (any subset)
+  float* scratch;                                // sf_pool_generic_scratch_floats(F, N, heads, D) floats: scores [F, heads, N] + z [F, heads, D]
+  float* scores; float* z;                       // set by the launcher
   int F, N, heads, hd, D;
 };
 bool sf_pool_generic_supported(int N, int heads, int D);
+size_t sf_pool_generic_scratch_floats(int F, int N, int heads, int D);
 hipError_t sf_launch_pool_generic(const SfPoolGenArgs& a, hipStream_t s);
 
 // One-to-four-row Linear of the head's per-frame tail (a streamed frame: F = streams <= 4): y = act(LN?(x) W^T + b) (+ resid) with fp32

@@ -820,63 +820,66 @@ hipError_t sf_launch_pool_u_bwd(const float* du, const float* wk, const float* q
 // ------------------------------------------------------------------------------------------------------------------------------
 // Generic widths (round 6): head_dim != 64 or D > 1024 (SigLIP-so400m: 1152 / 16 = 72; configuration_streamformer.py:90-135 takes any
 // hidden_size / heads).  The same algebra as above — scores = x . U_h, z_h = sum_n p_hn x_n, ctx_h = Wv_h z_h + bv_h
-// (modeling:1141-1154 with the key / value projections folded away) — as plain fp32 FMAs, one workgroup per frame:
-//   1. scores[h][n]: a wave per token, lanes over D, one wave reduction per head          (x read once, coalesced)
-//   2. softmax over the N tokens of each head, a wave per head
-//   3. z[h][d]: a thread per d, every head's accumulator in registers, p from LDS        (x read a second time)
-//   4. ctx[c] = bv[c] + Wv[c] . z[c / head_dim]: a wave per output column, lanes over D
-// A fallback, not a tuned kernel: ~0.1 ms per forward at 128 frames.
+// (modeling:1141-1154 with the key / value projections folded away) — as plain fp32 FMAs in three small launches, scratch in global memory:
+//   1. scores[f][h][n] = x[f, n] . U_h             grid (token chunks, F): a wave per token, lanes over D, one wave reduction per head
+//   2. z[f][h][d] = sum_n softmax(scores)[h][n] x[f, n][d]     grid (D / 256, F): the frame's softmax recomputed per workgroup (heads x N
+//                                                   exps), a thread per d with every head's accumulator in registers
+//   3. ctx[f][c] = bv[c] + Wv[c] . z[f][c / head_dim]          grid (D / 64, F): a wave per output column, lanes over D
+// A fallback, not a tuned kernel (first version: one workgroup per frame for everything, 5.0 ms per call at 64 frames of 256 tokens).
 // ------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sf_pool_generic_kernel(SfPoolGenArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float pg_smem[];
-  float* sc = pg_smem;                              // [heads][N]
-  float* zs = pg_smem + (size_t)p.heads * p.N;      // [heads][D]
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* x = (p.x_ind ? *p.x_ind : p.x) + (size_t)f * p.N * p.D;
-  const int D = p.D, N = p.N, H = p.heads;
-  for (int n = wave; n < N; n += 4) {
-    const float* xr = x + (size_t)n * D;
-    for (int h = 0; h < H; ++h) {
-      const float* ur = p.u + (size_t)h * D;
-      float t = 0.f;
-      for (int d = lane; d < D; d += 64) t = fmaf(xr[d], ur[d], t);
-      t = wave_sum(t);
-      if (lane == 0) sc[h * N + n] = t;
-    }
+__global__ __launch_bounds__(256) void sf_pool_gen_scores_kernel(SfPoolGenArgs p) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= p.N) return;
+  const float* xr = (p.x_ind ? *p.x_ind : p.x) + ((size_t)f * p.N + n) * p.D;
+  for (int h = 0; h < p.heads; ++h) {
+    const float* ur = p.u + (size_t)h * p.D;
+    float t = 0.f;
+    for (int d = lane; d < p.D; d += 64) t = fmaf(xr[d], ur[d], t);
+    t = wave_sum(t);
+    if (lane == 0) p.scores[((size_t)f * p.heads + h) * p.N + n] = t;
   }
-  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void sf_pool_gen_z_kernel(SfPoolGenArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float pg_smem[];      // [heads][N] probabilities of the frame
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N, H = p.heads, D = p.D;
+  const float* scg = p.scores + (size_t)f * H * N;
   for (int h = wave; h < H; h += 4) {               // U already carries the 1 / sqrt(head_dim) of the query
     float m = -INFINITY;
-    for (int n = lane; n < N; n += 64) m = fmaxf(m, sc[h * N + n]);
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, scg[h * N + n]);
     m = wave_max(m);
     float su = 0.f;
-    for (int n = lane; n < N; n += 64) { const float e = expf(sc[h * N + n] - m); sc[h * N + n] = e; su += e; }
+    for (int n = lane; n < N; n += 64) { const float e = expf(scg[h * N + n] - m); pg_smem[h * N + n] = e; su += e; }
     su = wave_sum(su);
     const float inv = 1.0f / su;
-    for (int n = lane; n < N; n += 64) sc[h * N + n] *= inv;
+    for (int n = lane; n < N; n += 64) pg_smem[h * N + n] *= inv;
   }
   __syncthreads();
-  for (int d0 = 0; d0 < D; d0 += 256) {
-    const int d = d0 + tid;
-    float acc[16];
+  const int d = blockIdx.x * 256 + tid;
+  if (d >= D) return;
+  const float* x = (p.x_ind ? *p.x_ind : p.x) + (size_t)f * N * D;
+  float acc[16];
 #pragma unroll
-    for (int h = 0; h < 16; ++h) acc[h] = 0.f;
-    if (d < D)
-      for (int n = 0; n < N; ++n) {
-        const float xv = x[(size_t)n * D + d];
+  for (int h = 0; h < 16; ++h) acc[h] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float xv = x[(size_t)n * D + d];
 #pragma unroll
-        for (int h = 0; h < 16; ++h)
-          if (h < H) acc[h] = fmaf(sc[h * N + n], xv, acc[h]);
-      }
-    if (d < D)
-#pragma unroll
-      for (int h = 0; h < 16; ++h)
-        if (h < H) zs[h * D + d] = acc[h];
+    for (int h = 0; h < 16; ++h)
+      if (h < H) acc[h] = fmaf(pg_smem[h * N + n], xv, acc[h]);
   }
-  __syncthreads();
-  for (int c = wave; c < D; c += 4) {
+#pragma unroll
+  for (int h = 0; h < 16; ++h)
+    if (h < H) p.z[((size_t)f * H + h) * D + d] = acc[h];
+}
+
+__global__ __launch_bounds__(256) void sf_pool_gen_ctx_kernel(SfPoolGenArgs p) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = p.D;
+  for (int c = blockIdx.x * 64 + wave; c < min(D, (int)blockIdx.x * 64 + 64); c += 4) {
     const float* wr = p.wv + (size_t)c * p.ldw;
-    const float* zr = zs + (size_t)(c / p.hd) * D;
+    const float* zr = p.z + ((size_t)f * p.heads + c / p.hd) * D;
     float t = 0.f;
     for (int d = lane; d < D; d += 64) t = fmaf(wr[d], zr[d], t);
     t = wave_sum(t);
@@ -895,14 +898,20 @@ __global__ __launch_bounds__(256) void sf_pool_generic_kernel(SfPoolGenArgs p) {
 }
 
 bool sf_pool_generic_supported(int N, int heads, int D) {
-  return heads >= 1 && heads <= 16 && N >= 1 && D >= 1 && ((size_t)heads * N + (size_t)heads * D) * sizeof(float) <= (size_t)160 * 1024;
+  return heads >= 1 && heads <= 16 && N >= 1 && D >= 1 && (size_t)heads * N * sizeof(float) <= (size_t)160 * 1024;
 }
-hipError_t sf_launch_pool_generic(const SfPoolGenArgs& a, hipStream_t s) {
-  if (!sf_pool_generic_supported(a.N, a.heads, a.D) || a.F <= 0 || a.hd <= 0 || a.D != a.heads * a.hd) return hipErrorInvalidValue;
-  const size_t lds = ((size_t)a.heads * a.N + (size_t)a.heads * a.D) * sizeof(float);
+size_t sf_pool_generic_scratch_floats(int F, int N, int heads, int D) { return (size_t)F * heads * ((size_t)N + D); }
+hipError_t sf_launch_pool_generic(const SfPoolGenArgs& a_in, hipStream_t s) {
+  SfPoolGenArgs a = a_in;
+  if (!sf_pool_generic_supported(a.N, a.heads, a.D) || a.F <= 0 || a.hd <= 0 || a.D != a.heads * a.hd || !a.scratch) return hipErrorInvalidValue;
+  a.scores = a.scratch;                                      // [F][heads][N]
+  a.z = a.scratch + (size_t)a.F * a.heads * a.N;             // [F][heads][D]
+  const size_t lds = (size_t)a.heads * a.N * sizeof(float);
   static SfPerDeviceOnce attr_set;
   if (attr_set.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(sf_pool_generic_kernel, dim3(a.F), dim3(256), lds, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_pool_gen_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(sf_pool_gen_scores_kernel, dim3((a.N + 3) / 4, a.F), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(sf_pool_gen_z_kernel, dim3((a.D + 255) / 256, a.F), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(sf_pool_gen_ctx_kernel, dim3((a.D + 63) / 64, a.F), dim3(256), 0, s, a);
   return hipGetLastError();
 }
