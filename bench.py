@@ -107,6 +107,15 @@ def timed_steps(model, x, steps, warmup, dist, world, nstreams=1):
                 model(x)
         else:
             model(x)
+    # settle (untimed, in front of the W warm-up steps): a device that comes out of idle — or out of a rocprofv3 counter pass, which leaves
+    # it in the profiling power state for a few seconds — runs its first tenths of a second at a lower clock (a 9.6 ms headline was
+    # measured that way right behind the PMC passes of profiles/collect_r06.sh, with 7.96 ms seconds later in the same process)
+    t_settle = time.perf_counter()
+    j = 0
+    while time.perf_counter() - t_settle < 1.5:
+        step(j); j += 1
+        if j % 16 == 0:
+            torch.cuda.synchronize()
     for i in range(max(warmup, nstreams)):
         step(i)
     torch.cuda.synchronize()
