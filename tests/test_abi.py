@@ -32,11 +32,17 @@ def test_create_validates_config_without_gpu():
     assert nat.lib.sf_missing_weights(h) > 200          # nothing loaded yet; message lists names
     assert b"missing" in nat.lib.sf_last_error()
     nat.lib.sf_destroy(h)
-    bad = nat.SfConfig(224, 16, 3, 16, 768, 12, 8, 3072, 0, 1, 1, 0, 1e-6)   # head_dim 96
-    assert nat.lib.sf_create(ctypes.byref(bad), 0, ctypes.byref(h)) == nat.SF_ERR_INVALID
-    assert b"head_dim" in nat.lib.sf_last_error()
-    so400m = nat.SfConfig(224, 16, 3, 16, 1152, 27, 16, 4304, 0, 1, 1, 0, 1e-6)   # SigLIP-so400m: head_dim 72
-    assert nat.lib.sf_create(ctypes.byref(so400m), 0, ctypes.byref(h)) == nat.SF_ERR_INVALID and b"head_dim 72" in nat.lib.sf_last_error()
+    # round 6: head widths other than 64 are accepted (multiples of 8 up to 128), any intermediate / patch size; what is still refused says why
+    for ok in (nat.SfConfig(224, 16, 3, 16, 768, 12, 8, 3072, 0, 1, 1, 0, 1e-6),          # head_dim 96
+               nat.SfConfig(224, 14, 3, 16, 1152, 27, 16, 4304, 0, 1, 1, 0, 1e-6)):      # SigLIP-so400m: head_dim 72, I = 4304, 14 x 14 patches
+        assert nat.lib.sf_create(ctypes.byref(ok), 0, ctypes.byref(h)) == 0
+        nat.lib.sf_destroy(h)
+    for bad in (nat.SfConfig(224, 16, 3, 16, 320, 2, 2, 640, 0, 1, 1, 0, 1e-6),          # head_dim 160 > 128
+                nat.SfConfig(224, 16, 3, 16, 192, 2, 16, 384, 0, 1, 1, 0, 1e-6)):        # head_dim 12: not a multiple of 8
+        assert nat.lib.sf_create(ctypes.byref(bad), 0, ctypes.byref(h)) == nat.SF_ERR_INVALID
+        assert b"head_dim" in nat.lib.sf_last_error()
+    narrow = nat.SfConfig(224, 16, 3, 16, 144, 2, 2, 304, 0, 1, 1, 0, 1e-6)               # hidden_size not a multiple of 64
+    assert nat.lib.sf_create(ctypes.byref(narrow), 0, ctypes.byref(h)) == nat.SF_ERR_INVALID and b"hidden_size" in nat.lib.sf_last_error()
     wide = nat.SfConfig(224, 16, 3, 16, 1280, 2, 20, 5120, 0, 1, 1, 0, 1e-6)       # 20 heads of 64
     assert nat.lib.sf_create(ctypes.byref(wide), 0, ctypes.byref(h)) == nat.SF_ERR_INVALID and b"heads" in nat.lib.sf_last_error()
 
