@@ -568,7 +568,13 @@ bool sf_gemm256_supported(const SfGemmArgs& a, bool split) {
   if (!split && a.epi == SF_EPI_ACT_BF16 && a.act != 0 && a.act != 99) return false;   // other activations: 128^2 kernel
   if (a.K % 128 || a.K < 128) return false;
   int min_n = 1024;                             // N = 768: 294 tiles on 256 CUs -> the panel / 128^2 kernels win
-  if (split) { min_n = 768; if (const char* e = sf_sw(SW_G256_SPLIT_MIN_N)) min_n = atoi(e); }    // bf16x3: 392 / 120 us against 415 / 127 on the 128^2 kernel
+  if (split) {      // bf16x3 at the BASELINE batch: 392 / 120 us against 415 / 127 on the 128^2 kernel
+    // one or two clips per call (M <= 6272): N = 768 is 60 / 120 tiles of 160 rows on 256 CUs — the 128^2 kernel's 150 / 294 tiles fill the chip
+    // better (accurate forward of one clip 5.17 -> 4.42 ms, two clips 6.38 -> 6.28; four clips lose: profiles/r06_accurate_small_batch_ab.txt).
+    // Returning false here also turns the accurate mode's LayerNorm fold off for such calls (ln_fold_acc_ok asks this function).
+    min_n = a.M <= 6272 ? 1024 : 768;
+    if (const char* e = sf_sw(SW_G256_SPLIT_MIN_N)) min_n = atoi(e);
+  }
   if (a.N % 256 || a.N < min_n) return false;
   if (a.M < 2048 || (size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return false;                 // small problems: the 128x128 kernel fills the chip better
   if (a.out_lo && !split && !planes) return false;
