@@ -169,8 +169,40 @@ __global__ __launch_bounds__(256) void sf_attention_generic_kernel(SfGenAttn p) 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every read of the images retired before the next tile overwrites them
   }
-  if (qi >= p.Lq) return;
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (a.probs && !p.temporal) {
+    // output_attentions (modeling:703-716): a second sweep over the key tiles with the final row statistics writes the fp32
+    // probabilities [frame, head, query, key] (K tiles only; every lane of the wave takes part in the staging)
+    for (int k0 = 0; k0 < Lk; k0 += 16) {
+      constexpr int CH = HD / 8;
+#pragma unroll
+      for (int it = 0; it < (16 * CH + 63) / 64; ++it) {
+        const int c = it * 64 + lane;
+        if (c < 16 * CH) {
+          const int row = c / CH, cc = c % CH;
+          float e[8];
+          ga_ld8<KIND>(a.k, krow(min(k0 + row, Lk - 1)) * a.row_pitch_kv + h * HD + cc * 8, a.lo_plane_off, e);
+          *reinterpret_cast<gf4_t*>(kt + row * GA_LD + cc * 8) = (gf4_t){e[0], e[1], e[2], e[3]};
+          *reinterpret_cast<gf4_t*>(kt + row * GA_LD + cc * 8 + 4) = (gf4_t){e[4], e[5], e[6], e[7]};
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      gf4_t s4 = {0.f, 0.f, 0.f, 0.f};
+      const float* kr = kt + l15 * GA_LD + g * HDQ;
+#pragma unroll
+      for (int s = 0; s < HDQ; ++s) s4 = ga_mfma(kr[s], qreg[s], s4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (qi < p.Lq) {
+        float* prow = a.probs + (((size_t)seq * a.heads + h) * a.N + qi) * (size_t)a.N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + 4 * g + r;
+          if (key < Lk) prow[key] = __builtin_amdgcn_exp2f((s4[r] - m_run) * c2) * inv;
+        }
+      }
+    }
+  }
+  if (qi >= p.Lq) return;
   const size_t ob = orow(qi) * a.D + h * HD;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -186,7 +218,7 @@ __global__ __launch_bounds__(256) void sf_attention_generic_kernel(SfGenAttn p) 
 }
 
 bool sf_attention_generic_supported(const SfAttnArgs& a, int head_dim) {
-  return head_dim >= 8 && head_dim <= 128 && head_dim % 8 == 0 && a.D == a.heads * head_dim && !a.probs && !a.lse2_out && !a.drop.on;
+  return head_dim >= 8 && head_dim <= 128 && head_dim % 8 == 0 && a.D == a.heads * head_dim && !a.lse2_out && !a.drop.on;
 }
 
 template <int KIND>
@@ -215,7 +247,7 @@ hipError_t sf_launch_attention_generic(const SfAttnArgs& a, int head_dim, bool t
   SfGenAttn p;
   p.a = a; p.temporal = temporal ? 1 : 0; p.hd = head_dim;
   if (temporal) {
-    if (a.B <= 0 || a.N <= 0 || a.Tq <= 0 || a.Tk <= 0) return hipErrorInvalidValue;
+    if (a.B <= 0 || a.N <= 0 || a.Tq <= 0 || a.Tk <= 0 || a.probs) return hipErrorInvalidValue;
     p.nseq = a.B * a.N; p.Lq = a.Tq;
   } else {
     if (a.frames <= 0 || a.N <= 0) return hipErrorInvalidValue;

@@ -1095,6 +1095,31 @@ def test_forward_head_widths_other_than_64_vs_reference_fixture(golden_dir, mode
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_output_attentions_at_head_dim_72(mode, tol):
+    """output_attentions=True (modeling:703-716) at a head width other than 64: the generic attention kernel's second sweep writes the
+    spatial probabilities; against the ORACLE's (collect=...), rows sum to one, hidden states unchanged by the flag."""
+    import streamformer_amd as sa
+    from streamformer_amd.configuration import StreamformerConfig
+    cfg = StreamformerConfig(enable_causal_temporal=True, **HD72W)
+    sd = make_state_dict(cfg, seed=15)
+    m = sa.TimesformerMultiTaskingModelSigLIP(cfg, compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    x = frames(151, (2, 4, 3, cfg.image_size, cfg.image_size))
+    col = {}
+    O.forward(sd, cfg, x, collect=col)
+    want = torch.stack([a.reshape(2 * 4, cfg.num_attention_heads, 9, 9) for a in col["attentions"]])
+    out = m(x.cuda(), output_attentions=True)
+    got = torch.stack(list(out.attentions)).cpu()
+    assert got.shape == want.shape and maxabs(got, want) <= tol
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-5
+    # accurate mode: with the flag q / k / v reach the kernel as fp32, without it as hi + lo planes — same numbers to rounding, not to the bit
+    plain = m(x.cuda()).last_hidden_state
+    assert torch.equal(out.last_hidden_state, plain) if mode == "bf16" else maxabs(out.last_hidden_state, plain) <= 2e-5
+
+
+@pytest.mark.gpu
 def test_so400m_shaped_layer_runs_and_matches_the_oracle():
     """The real SigLIP-so400m widths (hidden 1152, 16 heads of 72, intermediate 4304, patch 14 at 224 x 224 = 256 tokens) on ONE layer and a
     4-frame clip: the generic kernels at full width against the CPU oracle, both modes."""
