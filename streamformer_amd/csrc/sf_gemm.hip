@@ -252,6 +252,27 @@ hipError_t sf_launch_gemm(const SfGemmArgs& a, bool split, hipStream_t s) {
   if (sf_gemm_panel_supported(a, split)) return sf_launch_gemm_panel(a, s);
   if (sf_gemm256_supported(a, split)) return sf_launch_gemm256(a, s);
   if (a.resid_hi) return hipErrorInvalidValue;      // plane-form residual: panel kernel only
+  // N = 256 j + 128 (SigLIP-so400m: 1152, 3456): the first 256 j columns on the 256-column kernel, the last 128 on the 128^2 kernel — two
+  // launches on disjoint column ranges of the same rows (every epilogue here is column-local), instead of the whole problem on 128^2 tiles
+  if (a.N % 256 == 128 && a.N > 256 && !a.ln_stats && !a.ln_stats_out && a.epi != SF_EPI_EMBED_F32 && !sf_sw(SW_DISABLE_GEMM_COLSPLIT)) {
+    SfGemmArgs m = a;
+    m.N = a.N - 128;
+    if (sf_gemm256_supported(m, split)) {
+      SfGemmArgs t = a;
+      const size_t n0 = (size_t)m.N;
+      t.N = 128;
+      t.w_hi = a.w_hi + n0 * a.K; if (a.w_lo) t.w_lo = a.w_lo + n0 * a.K;
+      if (a.bias) t.bias = a.bias + n0;
+      if (a.resid) t.resid = a.resid + n0;
+      if (a.out_f32) t.out_f32 = a.out_f32 + n0;
+      if (a.out_hi) t.out_hi = a.out_hi + n0;
+      if (a.out_lo) t.out_lo = a.out_lo + n0;
+      if (a.aux) t.aux = a.aux + n0;
+      const hipError_t e = sf_launch_gemm256(m, s);
+      if (e != hipSuccess) return e;
+      return sf_launch_gemm128(t, split, s);
+    }
+  }
   return sf_launch_gemm128(a, split, s);
 }
 

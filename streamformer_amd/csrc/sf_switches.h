@@ -9,6 +9,7 @@
   X(ASSUME_CUS, "SF_ASSUME_CUS", "size persistent grids for this many CUs (CU-masked stream experiments)") \
   X(DISABLE_ACC_FOLD, "SF_DISABLE_ACC_FOLD", "accurate mode: fp32 residual + standalone LayerNorm instead of the folded plane form (A/B)") \
   X(DISABLE_G256_SPLIT, "SF_DISABLE_G256_SPLIT", "accurate mode: keep the bf16x3 GEMMs off the persistent 256-column kernel") \
+  X(DISABLE_GEMM_COLSPLIT, "SF_DISABLE_GEMM_COLSPLIT", "N = 256 j + 128 (so400m widths): the whole GEMM on 128^2 tiles instead of 256-column kernel + a 128-column tail (A/B)") \
   X(DISABLE_GEMM_MID, "SF_DISABLE_GEMM_MID", "skinny family: no 64 x 64 tiles above 512 rows") \
   X(DISABLE_GEMM_TILE, "SF_DISABLE_GEMM_TILE", "one / two clips per call: no tile-GEMM family") \
   X(DISABLE_LN_FOLD, "SF_DISABLE_LN_FOLD", "bf16 mode: standalone LayerNorm launches instead of the fold into the consumer GEMMs (A/B)") \
