@@ -79,6 +79,25 @@ SF_DEVICE void sf_lnf_stats(const bf16x8_t& f, float& s1, float& s2) {
   s1 = __builtin_amdgcn_fdot2_f32_bf16(x3, one, s1, false);
   s2 = __builtin_amdgcn_fdot2_f32_bf16(x3, x3, s2, false);
 }
+// the same for a row that arrives as hi + lo bf16 planes (fp32-accurate mode): sums of x = h + l and of x^2 = h^2 + 2 h l + l^2
+SF_DEVICE void sf_lnf_stats_split(const bf16x8_t& fh, const bf16x8_t& fl, float& s1, float& s2) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
+  const v8bf h = __builtin_bit_cast(v8bf, fh), l = __builtin_bit_cast(v8bf, fl);
+  const v2bf one = {(__bf16)1.0f, (__bf16)1.0f};
+#define SF_LNF_PAIR(A, B)                                                   \
+  {                                                                         \
+    const v2bf hh = __builtin_shufflevector(h, h, A, B), ll = __builtin_shufflevector(l, l, A, B); \
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(hh, one, s1, false);               \
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(ll, one, s1, false);               \
+    s2 = __builtin_amdgcn_fdot2_f32_bf16(hh, hh, s2, false);                \
+    float c = __builtin_amdgcn_fdot2_f32_bf16(hh, ll, 0.f, false);          \
+    s2 += 2.0f * c;                                                         \
+    s2 = __builtin_amdgcn_fdot2_f32_bf16(ll, ll, s2, false);                \
+  }
+  SF_LNF_PAIR(0, 1) SF_LNF_PAIR(2, 3) SF_LNF_PAIR(4, 5) SF_LNF_PAIR(6, 7)
+#undef SF_LNF_PAIR
+}
 SF_DEVICE void sf_lnf_finish(float s1, float s2, int K, float eps, float& mean, float& rstd) {
   const float inv_k = 1.0f / (float)K;
   mean = s1 * inv_k;

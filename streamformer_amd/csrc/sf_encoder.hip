@@ -628,8 +628,9 @@ static Workspace carve(const sf_encoder* e, void* base, int B, int T, int N, boo
   w.hn_lo = c.take<bf16_t>(F * D);
   w.hm_hi = c.take<bf16_t>(F * I);
   w.hm_lo = c.take<bf16_t>(F * I);
-  w.res_bf = (!acc && M <= (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
-  w.res_lo = (!acc && M > (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;
+  w.res_bf = (M <= (size_t)sf_infold_max_rows()) ? c.take<bf16_t>(M * D) : nullptr;      // accurate mode (round 6): the hi plane; the lo plane travels in xn_lo
+  // lo plane of the residual stream: bf16 mode at BASELINE-sized M (pm / gm); accurate mode at small M (round 6: in-kernel LayerNorm fold of streamed frames)
+  w.res_lo = ((!acc && M > (size_t)sf_infold_max_rows()) || (acc && M <= (size_t)sf_infold_max_rows())) ? c.take<bf16_t>(M * D) : nullptr;
   w.res_lo2 = (acc && M >= 2048) ? c.take<bf16_t>(M * D) : nullptr;
   w.lhs_stage = !need_tqkv ? c.take<float>(M * D) : nullptr;       // streaming carve (the cache holds the temporal qkv)
   w.pool_stage = !need_tqkv ? c.take<float>(F * D) : nullptr;
@@ -759,14 +760,18 @@ static bool ln_fold_g256_ok(const sf_encoder* e, int M) {
 // Small-M variant (the per-frame streaming step): the skinny GEMM derives the row statistics itself from the A fragments
 // it reads anyway, every residual producer only adds the bf16 copy of its output rows.
 static bool ln_fold_small_ok(const sf_encoder* e, int M) {
-  if (e->compute != SF_COMPUTE_BF16 || M > sf_infold_max_rows()) return false;
+  if (M > sf_infold_max_rows()) return false;
   const bool off = sf_sw(SW_DISABLE_STREAM_FOLD) != nullptr;
   if (off) return false;
-  auto takes = [](const SfGemmArgs& g) { return sf_gemm_skinny_supported(g, false) || sf_gemm_tile_supported(g, false); };
+  // accurate mode (round 6): the consumers take x as hi + lo planes and sum the statistics of hi + lo (32 x 32 skinny kernel only)
+  const bool acc = e->compute == SF_COMPUTE_BF16X3;
+  auto takes = [acc](const SfGemmArgs& g) { return sf_gemm_skinny_supported(g, acc) || (!acc && sf_gemm_tile_supported(g, false)); };
   SfGemmArgs g;
   memset(&g, 0, sizeof(g));
+  if (acc) { g.a_lo = (const bf16_t*)1; g.w_lo = (const bf16_t*)1; g.out_lo = (bf16_t*)1; }
   g.M = M; g.K = e->D; g.ldc = 3 * e->D; g.ln_inkernel = 1; g.ln_s = (const float*)1; g.out_hi = (bf16_t*)1;
-  g.epi = SF_EPI_BF16; g.N = 3 * e->D;
+  g.epi = acc ? SF_EPI_F32 : SF_EPI_BF16; g.N = 3 * e->D;
+  if (acc) g.out_f32 = (float*)1;
   if (!takes(g)) return false;
   g.epi = SF_EPI_ACT_BF16; g.N = e->I; g.ldc = e->I;
   if (!takes(g)) return false;
@@ -900,7 +905,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
       g.epi = SF_EPI_EMBED_F32;
       g.pos = pos_dev ? pos_dev : e->pos; g.time_rows = ws.te_rows; g.Np = N; g.Tn = T;
       if (time_folded) { g.time_rows = e->time_tab; g.time_base_dev = &sp->t_row; }
-      if (ws.res_bf && ln_fold_small_ok(e, M) && (stages & 2)) g.out_hi = ws.res_bf;   // layer 0's folded qkv reads bf16(x)
+      if (ws.res_bf && (!acc || ws.res_lo) && ln_fold_small_ok(e, M) && (stages & 2)) { g.out_hi = ws.res_bf; if (acc) g.out_lo = ws.res_lo; }   // layer 0's folded qkv reads bf16(x) (accurate: hi + lo)
       HIP_TRY(sf_launch_gemm(g, acc, s));
     }
   }
@@ -910,7 +915,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   // three per-layer LayerNorm launches disappear into the neighbouring GEMM epilogues.
   const bool fold = ln_fold_ok(e, M) && !streaming;
   // sfold: the same algebra at small M (streamed frames), statistics computed inside the consumer GEMM
-  const bool sfold = !fold && ws.res_bf && ln_fold_small_ok(e, M);
+  const bool sfold = !fold && ws.res_bf && (!acc || ws.res_lo) && ln_fold_small_ok(e, M);
   // xm: the accurate mode's counterpart of fold + pm (ln_fold_acc_ok): whole clips on the plane-fed attention kernels
   const bool two_planes = sf_sw(SW_ACC_TWO_PLANES) != nullptr;      // A/B: drop the third plane (max-abs 1.4e-4 instead of 5e-5)
   bf16_t* plo2 = two_planes ? nullptr : ws.res_lo2;
@@ -921,14 +926,15 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
   bf16_t* fold_hi = (fold || xm || gm) ? ws.xn_hi : (sfold ? ws.res_bf : nullptr);
   float* fold_st = (fold || xm || gm) ? ws.ln_stats : nullptr;
   const bf16_t* ln_in = sfold ? ws.res_bf : ws.xn_hi;       // A operand of the three LayerNorm'd Linears
+  const bf16_t* ln_in_lo = (sfold && acc) ? ws.res_lo : ws.xn_lo;      // its lo plane (accurate mode)
   const bool anyfold = fold || sfold || xm || gm;
   const bool rplanes = pm || xm || gm;                       // residual stream as two bf16 planes: hi = xn_hi, lo = plo
-  bf16_t* plo = (pm || gm) ? ws.res_lo : (xm ? ws.xn_lo : nullptr);
+  bf16_t* plo = (pm || gm) ? ws.res_lo : (xm ? ws.xn_lo : ((sfold && acc) ? ws.res_lo : nullptr));      // sfold in the accurate mode: lo plane of the residual for the folded consumers
   if (fold && (stages & 2) && !embed_emitted_stats) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, nullptr, nullptr, 1));
   if (!xm) plo2 = nullptr;
   if (xm) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, ws.xn_lo, plo2));      // embeddings -> planes + wide statistics
   if (gm) HIP_TRY(sf_launch_rowstats_cast(ws.resid, ws.xn_hi, ws.ln_stats, M, D, s, ws.res_lo, nullptr));
-  if (sfold && (stages & 2) && !(stages & 1) && !(ready & 2)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, nullptr, (size_t)M * D, s));   // sf_layers entry
+  if (sfold && (stages & 2) && !(stages & 1) && !(ready & 2)) HIP_TRY(sf_launch_split(ws.resid, ws.res_bf, acc ? ws.res_lo : nullptr, (size_t)M * D, s));   // sf_layers entry
   for (int li = la; li < lb && (stages & 2); ++li) {
     const DevLayer& l = e->layers[li];
     if (hidden_states)
@@ -971,7 +977,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     }
 #endif
     if (!t_fused_attn)
-    HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ws.xn_lo, M, tplanes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)tq, (bf16_t*)tq,
+    HIP_TRY(run_linear(e, anyfold ? l.t_qkv_f : l.t_qkv, ln_in, ln_in_lo, M, tplanes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)tq, (bf16_t*)tq,
                        tplanes ? (bf16_t*)tq + (size_t)M * 3 * D : nullptr, nullptr, 1.f,
                        3 * D, T * N, cap * N, sp ? 0 : slot * N, fold_st, nullptr, sfold, sp ? &sp->slot : nullptr, N));
     if (!t_fused_attn) {
@@ -1017,7 +1023,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
     }
 #endif
     if (!s_qkv_panel)
-    HIP_TRY(run_linear(e, anyfold ? l.s_qkv_f : l.s_qkv, ln_in, ws.xn_lo, M, planes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv,
+    HIP_TRY(run_linear(e, anyfold ? l.s_qkv_f : l.s_qkv, ln_in, ln_in_lo, M, planes ? (int)SF_EPI_BF16 : qkv_epi, s, (float*)ws.qkv, (bf16_t*)ws.qkv,
                        planes ? (bf16_t*)ws.qkv + (size_t)M * 3 * D : nullptr, nullptr, 1.f, 0, 0, 0, 0, fold_st, nullptr, sfold));
     {
       SfAttnArgs a;
@@ -1034,7 +1040,7 @@ static int run_forward(sf_encoder* e, const void* pixels, int pixel_dtype, int B
                         0, 0, 0, 0, nullptr, fold_st, false, nullptr, 0, rplanes ? fold_hi : nullptr, plo, plo2); }));
     // ---- MLP (modeling:997-1000) ---------------------------------------------------------------------
     if (!anyfold) HIP_TRY(sf_launch_layernorm(ws.resid, l.ln_a.g, l.ln_a.b, nullptr, ws.xn_hi, ws.xn_lo, M, D, c.layer_norm_eps, s));
-    HIP_TRY(run_linear(e, anyfold ? l.up_f : l.up, ln_in, ws.xn_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
+    HIP_TRY(run_linear(e, anyfold ? l.up_f : l.up, ln_in, ln_in_lo, M, SF_EPI_ACT_BF16, s, nullptr, ws.mid_hi, ws.mid_lo, nullptr, 1.f,
                        0, 0, 0, 0, fold_st, nullptr, sfold));
     HIP_TRY(prof_span(e, 1, s, [&]() {
       return run_linear(e, l.down, ws.mid_hi, ws.mid_lo, M, SF_EPI_RESID_F32, s, rplanes ? nullptr : ws.resid, fold_hi, plo, rplanes ? nullptr : ws.resid, 1.f,

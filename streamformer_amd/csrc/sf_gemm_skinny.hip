@@ -43,6 +43,21 @@ SF_DEVICE void sk_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory
 SF_DEVICE void sk_stats(const bf16x8_t& f, float& s1, float& s2) { sf_lnf_stats(f, s1, s2); }
 SF_DEVICE void sk_ln_finish(float s1, float s2, int K, float eps, float& mean, float& rstd) { sf_lnf_finish(s1, s2, K, eps, mean, rstd); }
 
+// residual producers of the small-M LayerNorm fold: the A operand of the folded Linear that follows — bf16(x) in bf16 mode, the hi + lo
+// planes of x in the accurate mode (out_lo; round 6)
+template <bool SPLIT>
+SF_DEVICE void sk_fold_copy(const SfGemmArgs& p, size_t o, const f32x4_t& v) {
+  if (!SPLIT) {
+    *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  } else {
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf(v[j], h[j], l[j]);
+    *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    if (p.out_lo) *reinterpret_cast<u32x2_t*>(p.out_lo + o) = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+  }
+}
+
 // TPS = K-tiles consumed per barrier (1 or 2): the loop is a serial chain of wait -> barrier -> LDS reads -> MFMA, a few
 // hundred cycles per step with two MFMAs of work in it, so halving the step count (12 -> 6 at K = 768) is worth more than
 // the one stage of prefetch depth it costs (STAGES - TPS tiles in flight instead of STAGES - 1).
@@ -126,11 +141,12 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
         const int kc = ks * 4 + g;
         const bf16x8_t wf = sk_frag(img, SK_BM + nt * 16 + l15, kc);
         const bf16x8_t af = sk_frag(img, mt * 16 + l15, kc);
-        if (LNF) sk_stats(af, ln1, ln2);
+        if (LNF && !SPLIT) sk_stats(af, ln1, ln2);
         if (SPLIT) {
           const char* lo = img + SK_PLANE;
           const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
           const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
+          if (LNF) sf_lnf_stats_split(af, al, ln1, ln2);      // accurate mode (round 6): statistics of x = hi + lo
           acc = sk_mfma(wl, af, acc);
           acc = sk_mfma(wf, al, acc);
         }
@@ -164,16 +180,14 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
       const f32x4_t r = p.grp_rows <= 0 ? pre_res : *reinterpret_cast<const f32x4_t*>(p.resid + o);
       v = r + p.alpha * v;
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
-      if (!SPLIT && p.out_hi)    // small-M LayerNorm fold producer: bf16 copy of the new residual rows
-        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      if (p.out_hi) sk_fold_copy<SPLIT>(p, o, v);      // small-M LayerNorm fold producer: bf16 copy (accurate mode: hi + lo planes) of the new residual rows
     } else if (EPI == SF_EPI_EMBED_F32) {
       const int pn = m % p.Np, tt = (m / p.Np) % p.Tn + (p.time_base_dev ? *p.time_base_dev : 0);
       const f32x4_t pe = *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)pn * p.N + n);
       const f32x4_t te = *reinterpret_cast<const f32x4_t*>(p.time_rows + (size_t)tt * p.N + n);
       v = v + pe + te;
       *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
-      if (!SPLIT && p.out_hi)      // small-M LayerNorm fold: bf16 copy of the embedded rows for layer 0's folded qkv
-        *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      if (p.out_hi) sk_fold_copy<SPLIT>(p, o, v);      // small-M LayerNorm fold: the embedded rows for layer 0's folded qkv
     } else {
       if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
@@ -519,8 +533,7 @@ __global__ __launch_bounds__(SK_THREADS * KG) void sf_gemm_skinny_kg_kernel(SfGe
     const f32x4_t r = p.grp_rows <= 0 ? pre_res : *reinterpret_cast<const f32x4_t*>(p.resid + o);
     v = r + p.alpha * v;
     *reinterpret_cast<f32x4_t*>(p.out_f32 + o) = v;
-    if (!SPLIT && p.out_hi)      // small-M LayerNorm fold producer: bf16 copy of the new residual rows
-      *reinterpret_cast<u32x2_t*>(p.out_hi + o) = (u32x2_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    if (p.out_hi) sk_fold_copy<SPLIT>(p, o, v);        // small-M LayerNorm fold producer
   } else {
     if (EPI == SF_EPI_ACT_BF16) {
 #pragma unroll
@@ -742,7 +755,8 @@ bool sf_gemm_skinny_supported(const SfGemmArgs& a, bool split) {
   const int max_rows = split ? (sf_skinny_max_rows() < 1024 ? sf_skinny_max_rows() : 1024) : sf_skinny_max_rows();   // bf16x3: the 128^2 kernel wins from 8 streams on
   if (a.M <= 0 || (a.M > max_rows && a.N > 64) || a.K < SK_BK || (a.K % SK_BK) || (a.N % 4) || (a.ldc % 4)) return false;
   if (a.ln_stats || a.ln_stats_out) return false;                  // the statistics-buffer fold: panel / 256^2 kernels
-  if (a.ln_inkernel && (split || !a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16))) return false;
+  if (a.ln_inkernel && (!a.ln_s || (a.epi != SF_EPI_BF16 && a.epi != SF_EPI_ACT_BF16 && !(split && a.epi == SF_EPI_F32)))) return false;
+  if (a.ln_inkernel && split && ((a.N + SK_BN - 1) / SK_BN) * ((a.M + SK_BM - 1) / SK_BM) <= 256) return false;      // accurate fold: the 32 x 32 kernel only (no K-parallel instance)
   if (split && (!a.a_lo || !a.w_lo)) return false;
   return true;
 }
@@ -785,6 +799,22 @@ hipError_t sf_launch_gemm_skinny(const SfGemmArgs& a_in, bool split, hipStream_t
   if ((int)(grid.x * grid.y) <= 256 && a.K >= 512 && a.epi != SF_EPI_EMBED_F32 && !sf_sw(SW_SKINNY_NO_KG))
     return split ? skg_launch<true, 2>(a, grid, s) : skg_launch<false, 4>(a, grid, s);
   const size_t lds = (size_t)SK_STAGES * SK_PLANE * (split ? 2 : 1);
+  if (a.ln_inkernel && split) {      // accurate mode (round 6): statistics of x = hi + lo inside the consumer, fp32 qkv / hi + lo activation outputs
+    static SfPerDeviceOnce attr_lns;
+    if (attr_lns.first()) {
+#define SK_LNSATTR(E, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sf_gemm_skinny_kernel<true, E, true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, SK_STAGES * SK_PLANE * 2);
+      SK_LNSATTR(SF_EPI_F32, 4) SK_LNSATTR(SF_EPI_F32, 1) SK_LNSATTR(SF_EPI_BF16, 4) SK_LNSATTR(SF_EPI_BF16, 1) SK_LNSATTR(SF_EPI_ACT_BF16, 4) SK_LNSATTR(SF_EPI_ACT_BF16, 1)
+#undef SK_LNSATTR
+    }
+    const bool four = ((a.K / SK_BK) % 4) == 0;
+#define SK_LNSGO(E) do { if (four) hipLaunchKernelGGL((sf_gemm_skinny_kernel<true, E, true, 4>), grid, dim3(SK_THREADS), lds, s, a); \
+                         else hipLaunchKernelGGL((sf_gemm_skinny_kernel<true, E, true, 1>), grid, dim3(SK_THREADS), lds, s, a); } while (0)
+    if (a.epi == SF_EPI_F32) SK_LNSGO(SF_EPI_F32);
+    else if (a.epi == SF_EPI_BF16) SK_LNSGO(SF_EPI_BF16);
+    else SK_LNSGO(SF_EPI_ACT_BF16);
+#undef SK_LNSGO
+    return hipGetLastError();
+  }
   if (a.ln_inkernel && !split && a.M <= 256 && ((a.K / SK_BK) % 4) == 0 && (int)(grid.x * grid.y) > 512) {
     // one streamed frame, more than two 32 x 32 tiles per CU (MLP-up: 672): the narrowest wider tile that gives every workgroup its
     // own CU (sf_gemm_skinny_wide_kernel) — 32 x 96 for MLP-up (224 workgroups): 10.2 -> 8.5 us per launch, p50 0.733 -> 0.716 ms
