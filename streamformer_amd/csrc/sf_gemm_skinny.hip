@@ -146,7 +146,9 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
           const char* lo = img + SK_PLANE;
           const bf16x8_t wl = sk_frag(lo, SK_BM + nt * 16 + l15, kc);
           const bf16x8_t al = sk_frag(lo, mt * 16 + l15, kc);
-          if (LNF) sf_lnf_stats_split(af, al, ln1, ln2);      // accurate mode (round 6): statistics of x = hi + lo
+          // accurate mode (round 6): statistics of x = hi + lo.  The two waves that share these 16 rows (nt = 0 / 1) take one k-half of
+          // every K-tile each and exchange their sums after the loop (20 v_dot2 per fragment pair: 3-4 us per launch when every wave did all)
+          if (LNF && ks == nt) sf_lnf_stats_split(af, al, ln1, ln2);
           acc = sk_mfma(wl, af, acc);
           acc = sk_mfma(wf, al, acc);
         }
@@ -157,6 +159,16 @@ __global__ __launch_bounds__(SK_THREADS) void sf_gemm_skinny_kernel(SfGemmArgs p
   if (LNF) {       // the four k-groups of row l15 (all 64 lanes still active here)
     ln1 += __shfl_xor(ln1, 16, 64); ln1 += __shfl_xor(ln1, 32, 64);
     ln2 += __shfl_xor(ln2, 16, 64); ln2 += __shfl_xor(ln2, 32, 64);
+    if (SPLIT) {   // the partner wave's k-half (same rows, other nt): through the now idle ring; a + b on both sides, bit-identical
+      __syncthreads();
+      float* xs = reinterpret_cast<float*>(smem);
+      if (g == 0) { xs[(wave * 16 + l15) * 2] = ln1; xs[(wave * 16 + l15) * 2 + 1] = ln2; }
+      __syncthreads();
+      const int pw = wave ^ 2;
+      const float o1 = xs[(pw * 16 + l15) * 2], o2 = xs[(pw * 16 + l15) * 2 + 1];
+      ln1 = nt ? o1 + ln1 : ln1 + o1;          // same operand order in both waves
+      ln2 = nt ? o2 + ln2 : ln2 + o2;
+    }
   }
 
   // ---- epilogue: lane holds C[m = tile row l15][n = tile col 4g .. 4g+3] ----------------------------------
