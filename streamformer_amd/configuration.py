@@ -103,10 +103,13 @@ class StreamformerConfig:
         if os.path.isdir(path):
             path = os.path.join(path, "config.json")
         if not os.path.isfile(path):
-            raise OSError(
-                f"{name_or_dir!r} is not a local directory with a config.json "
-                "(there is no hub access in this build)"
-            )
+            # a hub id, as HF's PretrainedConfig.from_pretrained takes it (configuration_streamformer.py:90-135 inherits it): cache first, then the network
+            try:
+                from huggingface_hub import hf_hub_download
+                path = hf_hub_download(repo_id=name_or_dir, filename="config.json")
+            except Exception as e:
+                raise OSError(f"{name_or_dir!r} is not a local directory with a config.json and could not be fetched from the hub "
+                              f"({type(e).__name__}: {e})") from e
         with open(path) as f:
             d = json.load(f)
         d.update(overrides)

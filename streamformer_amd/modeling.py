@@ -505,8 +505,17 @@ class TimesformerMultiTaskingModelSigLIP(nn.Module):
                         torch_dtype: Any = None, **kwargs):
         path = str(pretrained_model_name_or_path)
         if not os.path.isdir(path):
-            raise OSError(f"{path!r} is not a local directory.  This build has no hub access: download the checkpoint "
-                          "(config.json + model.safetensors or pytorch_model.bin) and pass its directory")
+            # a hub id ("org/name"), as the reference's HF classmethod takes it (modeling:1066-1075): resolve it to a local snapshot through
+            # huggingface_hub (cache first, then the network); every failure — no network, no such repo, library absent — names the fix
+            try:
+                from huggingface_hub import snapshot_download
+                path = snapshot_download(repo_id=path, revision=kwargs.pop("revision", None), cache_dir=kwargs.pop("cache_dir", None),
+                                         local_files_only=bool(kwargs.pop("local_files_only", False)),
+                                         allow_patterns=["config.json", "*.safetensors", "pytorch_model.bin", "model.bin"])
+            except Exception as e:
+                raise OSError(f"{pretrained_model_name_or_path!r} is not a local directory and could not be fetched from the hub "
+                              f"({type(e).__name__}: {e}).  Download the checkpoint (config.json + model.safetensors or pytorch_model.bin) "
+                              "and pass its directory") from e
         cfg_over = {k: kwargs.pop(k) for k in list(kwargs) if k in StreamformerConfig().to_dict()}
         cfg = config or StreamformerConfig.from_pretrained(path, **cfg_over)
         sd = None

@@ -120,7 +120,7 @@ def test_module_protocol_without_a_gpu():
     tower = sa.TimesformerVisionTower(m, streaming_mode=True, context_length=4)
     assert (tower.hidden_size, tower.num_patches, tower.num_patches_per_side, tower.image_size) == (128, 9, 3, 48)
     assert tower.device.type == "cpu" and tower.dtype == torch.bfloat16 and tower.is_loaded
-    with pytest.raises(OSError, match="no hub access"):
+    with pytest.raises(OSError, match="could not be fetched from the hub"):      # no network here: the hub id is tried (huggingface_hub) and the failure names the fix
         sa.TimesformerVisionTower("Go2Heart/StreamFormer-timesformer-siglip")
     # the module copies and pickles like any nn.Module (native state is rebuilt from the parameters on first use)
     import copy, io
