@@ -135,7 +135,8 @@ def test_op_linear_shape_sweep(sa):
     every (M, N, K) must give the same numbers whichever kernel it lands on."""
     rng = np.random.default_rng(7)
     shapes = [(25088, 768, 768), (25088, 2304, 768), (6272, 768, 3072), (3136, 3072, 768),
-              (784, 2304, 768), (1568, 768, 3072), (600, 1000, 128), (2048, 3072, 768)]      # several streams per call: the 64 x 64 tiles
+              (784, 2304, 768), (1568, 768, 3072), (600, 1000, 128), (2048, 3072, 768),      # several streams per call: the 64 x 64 tiles
+              (4096, 1152, 1152), (2304, 3456, 1152), (3000, 1152, 4352)]      # N = 256 j + 128 (so400m widths): 256-column kernel + 128-column tail
     for _ in range(14):
         shapes.append((int(rng.integers(513, 9000)), int(rng.choice([768, 1024, 1536, 2304, 3072])), int(rng.choice([128, 256, 384, 768, 1152]))))
     for M, N, K in shapes:
