@@ -96,6 +96,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
   // an A row panel is fetched once per column group.  Which tile a workgroup computes changes, nothing inside a tile does: bit-identical.
   const int walk_cg = (stagger_groups >> 8) & 15;
   const bool store_wt = (stagger_groups >> 12) & 1;
+  const bool store_nt = (stagger_groups >> 13) & 1;
   stagger_groups &= 255;
   const int walk_ngrp = walk_cg ? (tiles_n + walk_cg - 1) / walk_cg : 1;
   const int walk_per = (ntiles + 7) >> 3;
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(G_THREADS) void sf_gemm256_kernel(SfGemmArgs p, int
                               bf2f(v[j] >> 16) * gelu_grad_fast(bf2f(a[j] >> 16)));
           }
           if (store_wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p.out_hi + o), "v"(v) : "memory");     // leaves the XCD's L2 to the operands
+          else if (store_nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p.out_hi + o), "v"(v) : "memory");      // streamed once: do not displace the residual planes from L2 / Infinity Cache
           else *reinterpret_cast<u32x4_t*>(p.out_hi + o) = v;
         }
       }
@@ -647,7 +649,7 @@ static hipError_t launch_bm(const SfGemmArgs& a_in, hipStream_t s) {
     int cg = 0;
     if (const char* we = sf_sw(SW_G256_WALK)) cg = atoi(we);
     if (cg < 0 || cg > 15 || (cg != 15 && cg >= a.N / 256)) cg = 0;      // 15 = row-major with per-stagger-group runs
-    sgroups = (sgroups & 255) | (cg << 8) | (sf_sw(SW_G256_STORE_WT) ? 1 << 12 : 0);
+    sgroups = (sgroups & 255) | (cg << 8) | (sf_sw(SW_G256_STORE_WT) ? 1 << 12 : 0) | (sf_sw(SW_G256_STORE_NT) ? 1 << 13 : 0);
   }
 #define SF_LAUNCH256(E, L, SP) hipLaunchKernelGGL((sf_gemm256_kernel<E, L, BM, SP>), grid, block, lds, s, a, tiles, stagger, sgroups)
   if (a.a_lo && a.w_lo) {      // fp32-accurate mode: hi + lo planes of both operands, three products per fragment pair

@@ -33,6 +33,7 @@
   X(G256_SPLIT_MIN_N, "SF_G256_SPLIT_MIN_N", "accurate mode: smallest N the persistent kernel takes") \
   X(G256_WALK, "SF_G256_WALK", "256-column kernel: column-group width (tiles) of the column-group-major tile walk, 0 = row-major (A/B of the fabric traffic)") \
   X(G256_STORE_WT, "SF_G256_STORE_WT", "256-column kernel: bf16 outputs leave with write-through (sc1) stores that do not stay in the XCD's L2 (A/B)") \
+  X(G256_STORE_NT, "SF_G256_STORE_NT", "256-column kernel: bf16 outputs leave with non-temporal stores (A/B: do the residual planes then survive in the Infinity Cache?)") \
   X(G256_STAGGER_GROUPS, "SF_G256_STAGGER_GROUPS", "256-column kernel: phase-stagger groups per XCD") \
   X(G256_STAGGER_NS, "SF_G256_STAGGER_NS", "256-column kernel: stagger step in ns (overrides the percentage)") \
   X(G256_STAGGER_ONLY, "SF_G256_STAGGER_ONLY", "256-column kernel: stagger only some launches (A/B)") \
